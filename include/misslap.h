@@ -1,0 +1,174 @@
+/*
+ * misslap.h -- C ABI of libmisslap.so, the MI355X (gfx950) auction LAP solver.
+ *
+ * This is the drop-in boundary for the reference's bid/assign hot path
+ * (OllieBoyne/sslap v0.2.5).  The reference has no C ABI: its boundary is the
+ * Python -> Cython `cpdef` layer.  Each entry point below names the reference
+ * interface it replaces (file:line relative to the reference checkout).  Plain
+ * pointers and sizes only; no torch / numpy types.  All functions return
+ * MISSLAP_OK (0) or an error code; misslap_last_error() gives the text.
+ *
+ * Threading: a handle is single-owner (not thread-safe); distinct handles are
+ * independent.  Host arrays are borrowed for the duration of a call only.
+ * There is NO CPU fallback: every entry point that computes needs a gfx950 GPU
+ * and fails with MISSLAP_ERR_NO_DEVICE / MISSLAP_ERR_HIP otherwise.
+ */
+#ifndef MISSLAP_H
+#define MISSLAP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MISSLAP_ABI_VERSION 1
+
+#define MISSLAP_OK 0
+#define MISSLAP_ERR_INVALID 1    /* malformed arguments / input contract violated */
+#define MISSLAP_ERR_HIP 2        /* a HIP runtime call failed */
+#define MISSLAP_ERR_NO_DEVICE 3  /* no usable GPU */
+#define MISSLAP_ERR_STATE 4      /* call not valid in the handle's current state */
+
+typedef struct misslap_solver misslap_solver;
+
+/* Options of misslap_create.  Zero-initialise, set struct_size = sizeof, then fill. */
+typedef struct misslap_options {
+    int32_t struct_size;
+    int32_t device;          /* HIP device ordinal */
+    int32_t maximize;        /* 1 = problem 'max', 0 = 'min' (auction_.pyx:236-237) */
+    float eps_start;         /* > 0 overrides eps0 = C/2 (auction_.pyx:251-252) */
+    int64_t max_iter;        /* rounds, auction_.pyx:204,:308 */
+    int32_t input_on_device; /* loc / val are device pointers already resident in HBM */
+    int32_t tail_threshold;  /* rounds with K <= this run in the persistent one-workgroup kernel;
+                                < 0 = library default; 0 = grid kernels only; max 1024 */
+    int32_t force_f64_values;/* keep 12 B/edge (int32 col + fp64 val) even when values are fp32-exact */
+    int32_t profile;         /* record HIP events around every bid-kernel / tail-kernel launch */
+    int32_t shard_rank;      /* multi-GPU: this process bids for U positions of its shard only */
+    int32_t shard_world;     /* number of shards (1 = single GPU) */
+    int32_t rounds_per_sync; /* grid rounds enqueued between host status reads; <= 0 = default */
+    int32_t reserved[8];
+} misslap_options;
+
+/* Result block of misslap_finish: the reference's `meta` dict (auction_.pyx:264,:297-304)
+ * plus GPU-side measurements. */
+typedef struct misslap_meta {
+    float start_eps;     /* auction_.pyx:264 (unrounded fp32) */
+    float final_eps;     /* :303 */
+    float target_eps;    /* :247 */
+    int32_t eCE;         /* :297 */
+    int32_t soln_found;  /* :300 */
+    int32_t nreductions; /* :299 */
+    int64_t its;         /* :298 */
+    int64_t n_assigned;  /* :301 */
+    int64_t n_rows, n_cols, nnz;
+    float obj_f32;       /* get_obj() returns a C float, :489 */
+    double obj_f64;      /* the same sum before the cast */
+    double setup_ms;     /* :206-207,:265 */
+    double solve_ms;     /* :270,:294 */
+    /* GPU-side counters */
+    uint64_t edges_scanned;      /* sum over all bids of the bidder's row length */
+    uint64_t bids_made;
+    int64_t grid_rounds;         /* rounds executed by grid kernels */
+    int64_t tail_rounds;         /* rounds executed inside the persistent kernel */
+    int32_t bytes_per_edge;      /* 8 (int32 col + fp32 val) or 12 (int32 col + fp64 val) */
+    int32_t profiled;
+    /* valid when options.profile != 0 (HIP-event timings, ms) */
+    int64_t bid_launches;        /* grid bid-kernel launches that did work */
+    double bid_ms;               /* their summed duration */
+    uint64_t bid_edges;          /* edges they scanned */
+    int64_t fullscan_launches;   /* of which K == n_rows (every row scanned) */
+    double fullscan_ms;
+    uint64_t fullscan_edges;
+    int64_t tail_launches;
+    double tail_ms;
+    uint64_t tail_edges;
+    double reserved_d[4];
+} misslap_meta;
+
+/* Snapshot of the round state (tests / multi-GPU driver). */
+typedef struct misslap_status {
+    int64_t its;          /* rounds done (auction_.pyx:273) */
+    int32_t K;            /* num_unassigned (auction_.pyx:198) */
+    int32_t nreductions;
+    float eps;
+    float target_eps;
+    int32_t finished;     /* solve loop has broken out (auction_.pyx:275-281) */
+    int32_t error_bits;   /* device-side invariant violations (0 = none) */
+} misslap_status;
+
+/* ---- construction: replaces AuctionSolver.__init__ (auction_.pyx:202-265) as reached through
+ * _from_sparse (auction_.pyx:575-617) / _from_matrix (:528-571).
+ * loc: int32[nnz][2] (row, col), rows ascending with no empty row (the input contract of
+ * cumulative_idxs, auction_.pyx:33-48; violations -> MISSLAP_ERR_INVALID instead of the reference's
+ * silent garbage); val: double[nnz].  N = max row + 1, M = max col + 1 (:209-210).  The CSR build,
+ * |val| maximum (eps0), sign flip for 'min' and the (col, val) edge layout are done on the GPU.
+ * The caller's arrays are never written (the Python front-end reproduces the reference's in-place
+ * negation of `val` itself). */
+int misslap_create(misslap_solver **out, int64_t nnz, const int32_t *loc, const double *val,
+                   const misslap_options *opt);
+
+/* ---- dense ingest: replaces the row-major `v >= 0` scan of _from_matrix (auction_.pyx:546-557).
+ * mat: double[n_rows][n_cols] on the host; entries < 0 (and NaN) are invalid.  The scan / stream
+ * compaction runs on the GPU.  *nnz_out receives the number of valid entries (for the
+ * "Fewer than N valid values" guard of :559 the caller compares it with n_rows BEFORE solving;
+ * create fails with MISSLAP_ERR_INVALID when a row is empty). */
+int misslap_create_dense(misslap_solver **out, int64_t n_rows, int64_t n_cols, const double *mat,
+                         const misslap_options *opt, int64_t *nnz_out);
+
+int misslap_destroy(misslap_solver *h);
+
+/* N, M, nnz as the solver sees them (auction_.pyx:209-212). */
+int misslap_dims(const misslap_solver *h, int64_t *n_rows, int64_t *n_cols, int64_t *nnz);
+
+/* ---- the whole solve loop: replaces AuctionSolver.solve() (auction_.pyx:268-306).
+ * person_to_object_out: int32[n_rows] on the host (-1 = unassigned), may be NULL. */
+int misslap_solve(misslap_solver *h, int32_t *person_to_object_out, misslap_meta *meta);
+
+/* ---- stepwise interface (multi-GPU driver, round-level parity tests).  One grid round is
+ *   misslap_round_bid      bid phase (auction_.pyx:339-365) over this shard's bidders + per-object
+ *                          maximum of the shard's bids (first half of :375-385)
+ *   [exchange: all-reduce MAX over the best-key buffer, see misslap_exchange_buffers]
+ *   misslap_round_tiebreak earliest bidder in list order wins equal bids (strict '>' of :379)
+ *   [exchange: all-reduce MIN over the best-position buffer]
+ *   misslap_round_apply    assignment phase (:388-429) + push_all_left (:137-162, :430); its += 1
+ * Every call is a no-op once K == 0, K <= tail_threshold or its >= max_iter, so a driver may
+ * enqueue rounds blindly and read the status afterwards. */
+int misslap_round_bid(misslap_solver *h);
+int misslap_round_tiebreak(misslap_solver *h);
+int misslap_round_apply(misslap_solver *h);
+/* All remaining rounds with 0 < K <= tail_threshold, inside one persistent kernel launch. */
+int misslap_run_tail(misslap_solver *h);
+/* Synchronise and read the round state. */
+int misslap_get_status(misslap_solver *h, misslap_status *st);
+/* Loop control of solve() after a round (auction_.pyx:275-292): terminate(), eps reduction and
+ * assignment reset.  Sets *finished. */
+int misslap_phase_end(misslap_solver *h, int32_t *finished);
+/* eps-complementary-slackness test, eCE_satisfied (auction_.pyx:443-485), on the current state. */
+int misslap_check_ece(misslap_solver *h, float eps, int32_t *satisfied);
+/* meta + result copy-out (auction_.pyx:297-306). */
+int misslap_finish(misslap_solver *h, int32_t *person_to_object_out, misslap_meta *meta);
+
+/* Device pointers of the two per-object exchange buffers (int64 best key = bid bits + 1, 0 = none;
+ * int32 best position, INT32_MAX = none), n_objects entries each, for RCCL all-reduces. */
+int misslap_exchange_buffers(misslap_solver *h, void **best_key, void **best_pos, int64_t *n_objects);
+/* Run all of the handle's GPU work on this hipStream_t (default: a private stream). */
+int misslap_set_stream(misslap_solver *h, void *hip_stream);
+
+/* ---- state copy-out for parity tests (all host buffers, any may be NULL):
+ * prices double[M] (auction_.pyx:169), unassigned list int32[N] (first K valid, :199),
+ * person_to_object int32[N] (:177), object_to_person int32[M] (:178). */
+int misslap_get_state(misslap_solver *h, double *prices, int32_t *unassigned, int32_t *person_to_object,
+                      int32_t *object_to_person);
+
+/* Device properties of the GPU the handle runs on (name buffer >= 128 bytes). */
+int misslap_device_info(int32_t device, char *name, int32_t name_len, int32_t *compute_units,
+                        int64_t *hbm_bytes);
+
+const char *misslap_last_error(void);
+int misslap_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MISSLAP_H */

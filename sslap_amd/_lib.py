@@ -1,0 +1,98 @@
+"""ctypes binding of libmisslap.so (include/misslap.h).  There is no fallback: if the HIP library
+is missing or no GPU is usable, every solver call raises."""
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libmisslap.so")
+
+MISSLAP_OK, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_STATE = 0, 1, 2, 3, 4
+
+
+class Options(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32), ("device", C.c_int32), ("maximize", C.c_int32), ("eps_start", C.c_float),
+        ("max_iter", C.c_int64), ("input_on_device", C.c_int32), ("tail_threshold", C.c_int32),
+        ("force_f64_values", C.c_int32), ("profile", C.c_int32), ("shard_rank", C.c_int32),
+        ("shard_world", C.c_int32), ("rounds_per_sync", C.c_int32), ("reserved", C.c_int32 * 8),
+    ]
+
+
+class Meta(C.Structure):
+    _fields_ = [
+        ("start_eps", C.c_float), ("final_eps", C.c_float), ("target_eps", C.c_float),
+        ("eCE", C.c_int32), ("soln_found", C.c_int32), ("nreductions", C.c_int32),
+        ("its", C.c_int64), ("n_assigned", C.c_int64),
+        ("n_rows", C.c_int64), ("n_cols", C.c_int64), ("nnz", C.c_int64),
+        ("obj_f32", C.c_float), ("obj_f64", C.c_double), ("setup_ms", C.c_double), ("solve_ms", C.c_double),
+        ("edges_scanned", C.c_uint64), ("bids_made", C.c_uint64),
+        ("grid_rounds", C.c_int64), ("tail_rounds", C.c_int64),
+        ("bytes_per_edge", C.c_int32), ("profiled", C.c_int32),
+        ("bid_launches", C.c_int64), ("bid_ms", C.c_double), ("bid_edges", C.c_uint64),
+        ("fullscan_launches", C.c_int64), ("fullscan_ms", C.c_double), ("fullscan_edges", C.c_uint64),
+        ("tail_launches", C.c_int64), ("tail_ms", C.c_double), ("tail_edges", C.c_uint64),
+        ("reserved_d", C.c_double * 4),
+    ]
+
+
+class Status(C.Structure):
+    _fields_ = [
+        ("its", C.c_int64), ("K", C.c_int32), ("nreductions", C.c_int32), ("eps", C.c_float),
+        ("target_eps", C.c_float), ("finished", C.c_int32), ("error_bits", C.c_int32),
+    ]
+
+
+# every symbol include/misslap.h declares: (name, restype, argtypes)
+_VP, _I32P = C.c_void_p, C.POINTER(C.c_int32)
+SYMBOLS = {
+    "misslap_create": (C.c_int, [C.POINTER(_VP), C.c_int64, _VP, _VP, C.POINTER(Options)]),
+    "misslap_create_dense": (C.c_int, [C.POINTER(_VP), C.c_int64, C.c_int64, _VP, C.POINTER(Options),
+                                       C.POINTER(C.c_int64)]),
+    "misslap_destroy": (C.c_int, [_VP]),
+    "misslap_dims": (C.c_int, [_VP, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "misslap_solve": (C.c_int, [_VP, _VP, C.POINTER(Meta)]),
+    "misslap_round_bid": (C.c_int, [_VP]),
+    "misslap_round_tiebreak": (C.c_int, [_VP]),
+    "misslap_round_apply": (C.c_int, [_VP]),
+    "misslap_run_tail": (C.c_int, [_VP]),
+    "misslap_get_status": (C.c_int, [_VP, C.POINTER(Status)]),
+    "misslap_phase_end": (C.c_int, [_VP, _I32P]),
+    "misslap_check_ece": (C.c_int, [_VP, C.c_float, _I32P]),
+    "misslap_finish": (C.c_int, [_VP, _VP, C.POINTER(Meta)]),
+    "misslap_exchange_buffers": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(C.c_int64)]),
+    "misslap_set_stream": (C.c_int, [_VP, _VP]),
+    "misslap_get_state": (C.c_int, [_VP, _VP, _VP, _VP, _VP]),
+    "misslap_device_info": (C.c_int, [C.c_int32, C.c_char_p, C.c_int32, _I32P, C.POINTER(C.c_int64)]),
+    "misslap_last_error": (C.c_char_p, []),
+    "misslap_abi_version": (C.c_int, []),
+}
+
+_LIB = None
+
+
+def load():
+    """Load libmisslap.so and bind every exported symbol; raises if the library is absent."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m sslap_amd.build` "
+                "(hipcc --offload-arch=gfx950).  sslap_amd has no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            f = getattr(lib, name)
+            f.restype, f.argtypes = res, args
+        if lib.misslap_abi_version() != 1:
+            raise RuntimeError("libmisslap.so ABI version mismatch")
+        _LIB = lib
+    return _LIB
+
+
+def check(rc):
+    """Map a C status code to the Python exception the reference's callers expect."""
+    if rc == MISSLAP_OK:
+        return
+    msg = load().misslap_last_error().decode("utf-8", "replace")
+    if rc == ERR_INVALID:
+        raise ValueError(msg)
+    raise RuntimeError(f"libmisslap error {rc}: {msg}")

@@ -1,0 +1,320 @@
+"""Python front-end of the MI355X auction solver: same names, arguments, return values and error
+behaviour as the reference's front-end, on top of libmisslap.so (include/misslap.h).
+
+Mirrors  sslap/auction_solve.py:6-55      -> auction_solve(...)
+         sslap/auction_.pyx:528-571       -> from_matrix(...)   (reference: _from_matrix)
+         sslap/auction_.pyx:575-617       -> from_sparse(...)   (reference: _from_sparse)
+         sslap/auction_.pyx:164-306       -> AuctionSolver(loc, val, ...).solve() / .meta
+
+All solver arithmetic runs on the GPU; there is no CPU fallback.  The adapters' documented quirks
+ are reproduced where they are observable and well defined: the `fast` epsilon and
+the "fewer than N entries" guard use the adapter's own (mis)computed N, `val` is negated in place
+for problem='min' on the loc/val and coo_mat entries, float32 `val` is rejected.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+
+_ENV_DEVICE = "MISSLAP_DEVICE"
+_ENV_TAIL = "MISSLAP_TAIL_THRESHOLD"
+_ENV_PROFILE = "MISSLAP_PROFILE"
+_ENV_RPS = "MISSLAP_ROUNDS_PER_SYNC"
+
+
+def _options(problem, eps_start, max_iter, device=None, tail_threshold=None, profile=None, force_f64=False,
+             input_on_device=False, shard=None, rounds_per_sync=None):
+    if problem not in ("min", "max"):
+        # the reference treats every string other than 'min' as 'max' (auction_.pyx:236, :502)
+        problem = "max" if problem != "min" else "min"
+    o = _lib.Options()
+    o.struct_size = C.sizeof(_lib.Options)
+    o.device = int(os.environ.get(_ENV_DEVICE, 0)) if device is None else int(device)
+    o.maximize = 1 if problem == "max" else 0
+    o.eps_start = float(np.float32(eps_start))
+    o.max_iter = int(max_iter)
+    o.input_on_device = 1 if input_on_device else 0
+    o.tail_threshold = int(os.environ.get(_ENV_TAIL, -1)) if tail_threshold is None else int(tail_threshold)
+    o.force_f64_values = 1 if force_f64 else 0
+    o.profile = int(os.environ.get(_ENV_PROFILE, 0)) if profile is None else int(bool(profile))
+    o.rounds_per_sync = int(os.environ.get(_ENV_RPS, 0)) if rounds_per_sync is None else int(rounds_per_sync)
+    if shard is not None:
+        o.shard_rank, o.shard_world = int(shard[0]), int(shard[1])
+    return o
+
+
+class AuctionSolver:
+    """GPU-resident auction solver (reference: cdef class AuctionSolver, auction_.pyx:164-523).
+
+    `loc` is int32[nnz, 2] with rows ascending and no empty row, `val` is float64[nnz].  As in the
+    reference the constructor's num_rows / num_cols are ignored: N, M come from `loc` (:209-212).
+    """
+
+    def __init__(self, loc, val, num_rows=0, num_cols=0, problem="min", max_iter=1000000, eps_start=0,
+                 **gpu_opts):
+        lib = _lib.load()
+        loc, val = self._check_buffers(loc, val)
+        self._h = C.c_void_p()
+        self._opts = _options(problem, eps_start, max_iter, **gpu_opts)
+        self._problem = problem
+        loc_c = np.ascontiguousarray(loc)
+        val_c = np.ascontiguousarray(val)
+        _lib.check(lib.misslap_create(C.byref(self._h), loc_c.shape[0], loc_c.ctypes.data, val_c.ctypes.data,
+                                      C.byref(self._opts)))
+        if problem == "min":
+            # the reference negates the caller's buffer in place (mult_ndarray_by, auction_.pyx:236-237)
+            np.multiply(val, -1, out=val)
+        self._post_create()
+
+    # -- alternative constructors -------------------------------------------------------------
+    @classmethod
+    def _from_handle(cls, handle, opts, problem):
+        self = cls.__new__(cls)
+        self._h, self._opts, self._problem = handle, opts, problem
+        self._post_create()
+        return self
+
+    @classmethod
+    def from_dense(cls, mat, problem="min", max_iter=1000000, eps_start=0, **gpu_opts):
+        """Dense (N, M) float64 matrix, entries < 0 invalid: the `v >= 0` scan of auction_.pyx:546-557
+        runs on the GPU.  Returns (solver, number_of_valid_entries)."""
+        lib = _lib.load()
+        h = C.c_void_p()
+        opts = _options(problem, eps_start, max_iter, **gpu_opts)
+        matc = np.ascontiguousarray(mat)
+        nnz = C.c_int64(-1)
+        rc = lib.misslap_create_dense(C.byref(h), matc.shape[0], matc.shape[1], matc.ctypes.data, C.byref(opts),
+                                      C.byref(nnz))
+        return rc, h, opts, int(nnz.value)
+
+    @classmethod
+    def from_device_pointers(cls, loc_ptr, val_ptr, nnz, problem="min", max_iter=1000000, eps_start=0,
+                             **gpu_opts):
+        """COO input already resident in HBM (loc int32[nnz,2], val float64[nnz] device pointers)."""
+        lib = _lib.load()
+        h = C.c_void_p()
+        opts = _options(problem, eps_start, max_iter, input_on_device=True, **gpu_opts)
+        _lib.check(lib.misslap_create(C.byref(h), int(nnz), C.c_void_p(int(loc_ptr)), C.c_void_p(int(val_ptr)),
+                                      C.byref(opts)))
+        return cls._from_handle(h, opts, problem)
+
+    @staticmethod
+    def _check_buffers(loc, val):
+        # Cython buffer checks of auction_.pyx:202 (np.ndarray[DTYPE_int_t, ndim=2], np.ndarray[DTYPE_t, ndim=1])
+        if not isinstance(loc, np.ndarray) or not isinstance(val, np.ndarray):
+            raise TypeError("loc and val must be numpy arrays")
+        if loc.ndim != 2:
+            raise ValueError(f"Buffer has wrong number of dimensions (expected 2, got {loc.ndim})")
+        if loc.dtype != np.int32:
+            raise ValueError(f"Buffer dtype mismatch, expected 'DTYPE_int_t' but got '{loc.dtype.name}'")
+        if val.ndim != 1:
+            raise ValueError(f"Buffer has wrong number of dimensions (expected 1, got {val.ndim})")
+        if val.dtype != np.float64:
+            raise ValueError(f"Buffer dtype mismatch, expected 'DTYPE_t' but got '{_cname(val.dtype)}'")
+        if loc.shape[1] != 2 or loc.shape[0] != val.shape[0]:
+            raise ValueError("loc must have shape (nnz, 2) and val shape (nnz,)")
+        return loc, val
+
+    def _post_create(self):
+        lib = _lib.load()
+        n, m, z = C.c_int64(), C.c_int64(), C.c_int64()
+        _lib.check(lib.misslap_dims(self._h, C.byref(n), C.byref(m), C.byref(z)))
+        self.num_rows, self.num_cols, self.nnz = n.value, m.value, z.value
+        st = self.status()
+        self.meta = {"start_eps": round(float(st.eps), 3)}  # auction_.pyx:264
+        self.gpu = {}
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                _lib.load().misslap_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    # -- reference API ---------------------------------------------------------------------------
+    def solve(self):
+        """Run the auction (auction_.pyx:268-306); returns person_to_object as int32[N]."""
+        lib = _lib.load()
+        sol = np.empty(self.num_rows, dtype=np.int32)
+        meta = _lib.Meta()
+        _lib.check(lib.misslap_solve(self._h, sol.ctypes.data, C.byref(meta)))
+        self._fill_meta(meta)
+        return sol
+
+    def _fill_meta(self, m):
+        # auction_.pyx:297-304
+        self.meta["eCE"] = int(m.eCE)
+        self.meta["its"] = int(m.its)
+        self.meta["nreductions"] = int(m.nreductions)
+        self.meta["soln_found"] = int(m.soln_found)
+        self.meta["n_assigned"] = int(m.n_assigned)
+        self.meta["obj"] = round(float(m.obj_f32), 3)
+        self.meta["final_eps"] = round(float(m.final_eps), 3)
+        self.meta["timer"] = {"setup": f"{m.setup_ms:.2f}ms", "solve": f"{m.solve_ms:.2f}ms"}
+        g = dict(obj_f64=float(m.obj_f64), edges_scanned=int(m.edges_scanned), bids_made=int(m.bids_made),
+                 grid_rounds=int(m.grid_rounds), tail_rounds=int(m.tail_rounds), bytes_per_edge=int(m.bytes_per_edge),
+                 setup_ms=float(m.setup_ms), solve_ms=float(m.solve_ms), final_eps_f32=float(m.final_eps),
+                 start_eps_f32=float(m.start_eps), tail_edges=int(m.tail_edges))
+        if m.profiled:
+            g.update(bid_launches=int(m.bid_launches), bid_ms=float(m.bid_ms), bid_edges=int(m.bid_edges),
+                     fullscan_launches=int(m.fullscan_launches), fullscan_ms=float(m.fullscan_ms),
+                     fullscan_edges=int(m.fullscan_edges), tail_launches=int(m.tail_launches),
+                     tail_ms=float(m.tail_ms))
+        self.gpu = g
+        self.meta["gpu"] = g
+
+    # -- stepwise API (tests, multi-GPU driver) ----------------------------------------------------
+    def status(self):
+        st = _lib.Status()
+        _lib.check(_lib.load().misslap_get_status(self._h, C.byref(st)))
+        return st
+
+    def state(self):
+        """Snapshot dict(K, U[:K], p, p2o, o2p, eps, its) of the device state."""
+        st = self.status()
+        p = np.empty(self.num_cols, dtype=np.float64)
+        U = np.empty(self.num_rows, dtype=np.int32)
+        p2o = np.empty(self.num_rows, dtype=np.int32)
+        o2p = np.empty(self.num_cols, dtype=np.int32)
+        _lib.check(_lib.load().misslap_get_state(self._h, p.ctypes.data, U.ctypes.data, p2o.ctypes.data,
+                                                 o2p.ctypes.data))
+        return dict(K=int(st.K), U=U[:st.K].copy(), p=p, p2o=p2o, o2p=o2p, eps=float(st.eps), its=int(st.its),
+                    nreductions=int(st.nreductions))
+
+    def round_bid(self):
+        _lib.check(_lib.load().misslap_round_bid(self._h))
+
+    def round_tiebreak(self):
+        _lib.check(_lib.load().misslap_round_tiebreak(self._h))
+
+    def round_apply(self):
+        _lib.check(_lib.load().misslap_round_apply(self._h))
+
+    def run_tail(self):
+        _lib.check(_lib.load().misslap_run_tail(self._h))
+
+    def phase_end(self):
+        fin = C.c_int32(0)
+        _lib.check(_lib.load().misslap_phase_end(self._h, C.byref(fin)))
+        return bool(fin.value)
+
+    def check_ece(self, eps):
+        ok = C.c_int32(0)
+        _lib.check(_lib.load().misslap_check_ece(self._h, float(np.float32(eps)), C.byref(ok)))
+        return bool(ok.value)
+
+    def finish(self):
+        sol = np.empty(self.num_rows, dtype=np.int32)
+        meta = _lib.Meta()
+        _lib.check(_lib.load().misslap_finish(self._h, sol.ctypes.data, C.byref(meta)))
+        self._fill_meta(meta)
+        return sol
+
+    def exchange_buffers(self):
+        k, p, n = C.c_void_p(), C.c_void_p(), C.c_int64()
+        _lib.check(_lib.load().misslap_exchange_buffers(self._h, C.byref(k), C.byref(p), C.byref(n)))
+        return k.value, p.value, n.value
+
+    def set_stream(self, hip_stream):
+        _lib.check(_lib.load().misslap_set_stream(self._h, C.c_void_p(int(hip_stream))))
+
+
+def _cname(dt):
+    return {"float32": "float", "float64": "double", "int64": "long", "int32": "int"}.get(dt.name, dt.name)
+
+
+def _cardinality(loc, n_rows, n_cols):
+    """Maximum-matching cardinality for the optional feasibility guard (reference: c_hopcroft_solve,
+    feasibility_.pyx:95-225, called at auction_.pyx:562-566 / :608-612).  Only the cardinality reaches
+    the auction path; this host-side Hopcroft-Karp (scipy) is outside the hot path."""
+    from scipy.sparse import csr_matrix
+    from scipy.sparse.csgraph import maximum_bipartite_matching
+    g = csr_matrix((np.ones(loc.shape[0], dtype=np.int8), (loc[:, 0], loc[:, 1])), shape=(n_rows, n_cols))
+    match = maximum_bipartite_matching(g, perm_type="column")
+    return int((match >= 0).sum())
+
+
+def from_matrix(mat, problem="min", eps_start=0, max_iter=1000000, fast=False, cardinality_check=True,
+                **gpu_opts):
+    """AuctionSolver from a dense (N, M) matrix where invalid entries are -1 (auction_.pyx:528-571)."""
+    if not isinstance(mat, np.ndarray):
+        raise TypeError("Argument 'mat' has incorrect type (expected numpy.ndarray)")
+    if mat.ndim != 2:
+        raise ValueError(f"Buffer has wrong number of dimensions (expected 2, got {mat.ndim})")
+    if mat.dtype != np.float64:  # `cdef double[:, :] matmv = mat` (:544)
+        raise ValueError(f"Buffer dtype mismatch, expected 'double' but got '{_cname(mat.dtype)}'")
+    N, M = mat.shape
+    if fast:
+        eps_start = 1 / N  # :568-569, converted to C float by _options
+    rc, h, opts, ctr = AuctionSolver.from_dense(mat, problem=problem, max_iter=max_iter, eps_start=eps_start,
+                                                **gpu_opts)
+    if rc != 0 and 0 <= ctr < N:  # :559-560
+        raise ValueError(f"Matrix is infeasible - Fewer than {N} valid values provided for {N} rows.")
+    _lib.check(rc)
+    solver = AuctionSolver._from_handle(h, opts, problem)
+    if cardinality_check:  # :562-566
+        r, c = np.nonzero(mat >= 0)
+        cardinality = _cardinality(np.stack([r, c], axis=1), N, M)
+        if cardinality < N:
+            raise ValueError(f"Matrix is infeasible (Maximum matching possible only involves {cardinality} "
+                             f"out of {N} rows.)")
+    return solver
+
+
+def from_sparse(loc, val, problem="min", eps_start=0, max_iter=1000000, fast=False, size=None,
+                cardinality_check=True, **gpu_opts):
+    """AuctionSolver for sparse entries (auction_.pyx:575-617).
+
+    loc: (nnz, 2) integer (i, j) indices, rows ascending; val: (nnz,) float64.  N and M of the
+    guard / `fast` epsilon are computed exactly like the reference does (:591-595), quirks included.
+    """
+    if size is not None:
+        M, N = size  # sic, :592
+    else:
+        N = int(loc[:, 0].max())  # sic (no +1), :594
+        M = int(loc[:, 1].max())
+    num_entries = loc.shape[0]
+    loc_long = loc.astype(np.int32)  # :601
+    if num_entries < N:  # :604-605
+        raise ValueError(f"Matrix is infeasible - Fewer than {N} valid values provided for {N} rows.")
+    if cardinality_check:  # :608-612 (on the true graph; the reference indexes out of bounds here)
+        n_true, m_true = int(loc_long[:, 0].max()) + 1, int(loc_long[:, 1].max()) + 1
+        cardinality = _cardinality(loc_long, n_true, m_true)
+        if cardinality < n_true:
+            raise ValueError(f"Matrix is infeasible (Maximum matching possible only involves {cardinality} "
+                             f"out of {n_true} rows.)")
+    if fast:
+        eps_start = 1 / N  # :614-615
+    return AuctionSolver(loc_long, val, problem=problem, eps_start=eps_start, max_iter=max_iter, **gpu_opts)
+
+
+# the reference's private names
+_from_matrix = from_matrix
+_from_sparse = from_sparse
+
+
+def auction_solve(mat=None, loc=None, val=None, coo_mat=None, problem="min", eps_start=0., max_iter=1000000,
+                  fast=False, size=None, cardinality_check=True):
+    """Solve an Auction Algorithm problem (drop-in for sslap.auction_solve, sslap/auction_solve.py:6-55).
+
+    Input, one of: `mat` (N x M ndarray, -1 = no edge), (`loc`, `val`) sparse triplets, or `coo_mat`
+    (scipy COO matrix).  Returns dict(sol=int32[N] assignment i -> j, meta=dict).
+    """
+    kw = dict(problem=problem, eps_start=eps_start, max_iter=max_iter, fast=fast, cardinality_check=cardinality_check)
+    if mat is not None:
+        solver = from_matrix(mat=mat, **kw)
+    elif loc is not None and val is not None:
+        solver = from_sparse(loc=loc, val=val, size=size, **kw)
+    elif coo_mat is not None:
+        row, col = coo_mat.row, coo_mat.col
+        loc, val, size = np.stack([row, col], axis=-1), coo_mat.data, coo_mat.shape
+        solver = from_sparse(loc=loc, val=val, size=size, **kw)
+    else:
+        raise ValueError("One of the following formats is expected as input to auction solve: "
+                         "mat OR (loc & val) OR coo_mat.")
+    sol = solver.solve()
+    return dict(sol=sol, meta=solver.meta)

@@ -1,0 +1,124 @@
+// kernels_check.hpp -- full-CSR reductions that run once per eps-phase / once per solve:
+// the eps-complementary-slackness test (auction_.pyx:443-485) and the objective (:489-523).
+#pragma once
+#include "device_common.hpp"
+
+namespace misslap {
+
+// eCE_satisfied(eps), one wavefront per person (only called with K == 0: everybody assigned).
+//   choice_cost = value of the LAST stored entry of row i whose column is p2o[i]      (:467-471)
+//   LHS = (choice_cost - p[j]) + tol                                                  (:475)
+//   violated if for some entry k of the row  LHS < (val_k - p[col_k]) - eps           (:482)
+// x -> fl(x - eps) is monotone, so "some k" is equivalent to testing the row maximum of
+// (val_k - p[col_k]) only; choice and maximum are found in ONE pass over the row.
+template <class E>
+__global__ __launch_bounds__(256) void k_ece(Ctl *ctl, E ed, const int *row_ptr, const double *price,
+                                             const int *p2o, int n_rows, float eps_f) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const double tol = 1e-7;  // auction_.pyx:16
+    const double eps = (double)eps_f;
+    const double ninf = -__builtin_huge_val();
+    for (int i = blockIdx.x * 4 + wave; i < n_rows; i += gridDim.x * 4) {
+        const int s = row_ptr[i], e = row_ptr[i + 1];
+        const int j = p2o[i];
+        double vmax = ninf;
+        int gsel = -1;
+        for (int g = s + lane; g < e; g += kWave) {
+            int c;
+            double cost;
+            ed.load(g, c, cost);
+            const double v = cost - price[c];
+            vmax = v > vmax ? v : vmax;
+            if (c == j) gsel = g;  // ascending g per lane: keeps the last match
+        }
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double v2 = shfl_xor_f64(vmax, off);
+            const int g2 = __shfl_xor(gsel, off);
+            vmax = v2 > vmax ? v2 : vmax;
+            gsel = g2 > gsel ? g2 : gsel;
+        }
+        if (lane == 0) {
+            bool bad = true;  // an assigned column that is not in the row cannot happen
+            if (gsel >= 0) {
+                int c;
+                double choice_cost;
+                ed.load(gsel, c, choice_cost);
+                const double lhs = (choice_cost - price[j]) + tol;
+                bad = lhs < (vmax - eps);
+            }
+            if (bad) atomicOr(&ctl->ece_fail, 1);
+        }
+    }
+}
+
+// get_obj, step 1 (parallel): the contribution of every person, in row order inside the row:
+// contrib[i] = +val / -val of the stored entry (i, p2o[i]) ('max' / 'min'; val is the sign-flipped
+// copy, so obj -= val restores the caller's sign, :518-521).  Rows whose assigned column is stored
+// more than once are flagged and re-added sequentially in step 2.
+template <class E>
+__global__ __launch_bounds__(256) void k_obj_rows(Ctl *ctl, E ed, const int *row_ptr, const int *p2o,
+                                                  int n_rows, int maximize, double *contrib, int *nmatch) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int i = blockIdx.x * 4 + wave; i < n_rows; i += gridDim.x * 4) {
+        const int j = p2o[i];
+        int cnt = 0, gsel = -1;
+        if (j != -1) {  // :508
+            const int s = row_ptr[i], e = row_ptr[i + 1];
+            for (int g = s + lane; g < e; g += kWave) {
+                int c;
+                double v;
+                ed.load(g, c, v);
+                if (c == j) {
+                    cnt += 1;
+                    gsel = g;
+                }
+            }
+        }
+        for (int off = 32; off >= 1; off >>= 1) {
+            cnt += __shfl_xor(cnt, off);
+            const int g2 = __shfl_xor(gsel, off);
+            gsel = g2 > gsel ? g2 : gsel;
+        }
+        if (lane == 0) {
+            double cv = 0.0;
+            if (cnt == 1) {
+                int c;
+                double v;
+                ed.load(gsel, c, v);
+                cv = maximize ? v : -v;
+            }
+            contrib[i] = cv;
+            nmatch[i] = cnt;
+            if (cnt > 1) atomicAdd(&ctl->dup_rows, 1);
+        }
+    }
+}
+
+// get_obj, step 2: the reference adds in person order into ONE double (:491, :519-521); floating-point
+// addition is not associative, so the sum is reproduced sequentially by a single lane.
+template <class E>
+__global__ void k_obj_sum(Ctl *ctl, E ed, const int *row_ptr, const int *p2o, int n_rows, int maximize,
+                          const double *contrib, const int *nmatch) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double obj = 0.0;
+    if (ctl->dup_rows == 0) {
+        for (int i = 0; i < n_rows; ++i) obj += contrib[i];  // adding +0.0 for skipped rows is exact
+    } else {
+        for (int i = 0; i < n_rows; ++i) {
+            if (nmatch[i] <= 1) {
+                obj += contrib[i];
+            } else {
+                const int j = p2o[i];
+                for (int g = row_ptr[i]; g < row_ptr[i + 1]; ++g) {
+                    int c;
+                    double v;
+                    ed.load(g, c, v);
+                    if (c == j) obj += maximize ? v : -v;
+                }
+            }
+        }
+    }
+    ctl->obj = obj;
+}
+
+}  // namespace misslap

@@ -1,0 +1,272 @@
+// kernels_round.hpp -- one Jacobi auction round as grid kernels (rounds with many bidders).
+//
+// Reference: AuctionSolver.bid_and_assign, sslap/auction_.pyx:313-430.
+//   k_bid       BID phase (:339-365) + running per-object maximum (first half of RESOLVE, :375-385)
+//   k_tiebreak  "first bidder in list order wins equal bids" (strict '>' at :379)
+//   k_apply     ASSIGN phase (:388-427), one thread per object instead of the O(M) sequential walk
+//   k_compact_* push_all_left (:137-162, called at :430) as two counting passes + scatter
+//   k_round_end K += evicted - assigned (:429), nits += 1 (:273)
+// Every kernel is a no-op unless the round is live (K > tail_threshold, nits < max_iter), so the
+// host can enqueue several rounds without reading K back.
+#pragma once
+#include "device_common.hpp"
+
+namespace misslap {
+
+struct RoundArgs {
+    Ctl *ctl;
+    const int *row_ptr;
+    double *price;
+    int *p2o;
+    int *o2p;
+    int *U;
+    unsigned long long *bid_key;  // [N] bid of U position n (as key)
+    int *bid_obj;                 // [N] object bid on by U position n
+    unsigned long long *best_key; // [M]
+    int *best_pos;                // [M]
+    int *cnt;                     // [2 * nblocks_compact] per-chunk (left holes, movers)
+    int *hole_list;               // [N] positions of left holes
+    int *mover_list;              // [N] persons to move left
+    unsigned long long *launch_edges;  // per-bid-launch edge counters (profiling), may be null
+    int n_rows, n_cols;
+    int thr;                      // tail threshold
+    int rank, world;              // bidder shard
+    float eps;
+    int launch_idx;
+};
+
+__device__ __forceinline__ bool round_live(const Ctl *c, int thr) {
+    return c->K > thr && c->K > 0 && c->nits < c->max_iter;
+}
+__device__ __forceinline__ void shard_range(int K, int rank, int world, int &lo, int &hi) {
+    lo = (int)(((long long)K * rank) / world);
+    hi = (int)(((long long)K * (rank + 1)) / world);
+}
+
+constexpr int kBidBlock = 256;  // 4 wavefronts; one wavefront per bidder
+template <class E>
+__global__ __launch_bounds__(kBidBlock) void k_bid(RoundArgs a, E ed) {
+    const Ctl *ctl = a.ctl;
+    if (!round_live(ctl, a.thr)) return;
+    int lo, hi;
+    shard_range(ctl->K, a.rank, a.world, lo, hi);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wpb = kBidBlock / kWave;
+    const double eps = (double)a.eps;  // float promoted to double, auction_.pyx:360
+    unsigned long long edges = 0;
+    int nb = 0, err = 0;
+    for (int n = lo + blockIdx.x * wpb + wave; n < hi; n += gridDim.x * wpb) {
+        const int i = a.U[n];
+        const int s = a.row_ptr[i], e = a.row_ptr[i + 1];
+        unsigned long long key;
+        int obj;
+        wave_bid(ed, a.price, s, e, eps, key, obj, err);
+        if (lane == 0) {
+            a.bid_key[n] = key;
+            a.bid_obj[n] = obj;
+            atomicMax(&a.best_key[obj], key);
+        }
+        edges += (unsigned long long)(e - s);
+        nb += 1;
+    }
+    __shared__ unsigned long long s_edges[kBidBlock / kWave];
+    __shared__ int s_nb[kBidBlock / kWave];
+    if (lane == 0) {
+        s_edges[wave] = edges;
+        s_nb[wave] = nb;
+        if (err) atomicOr(&a.ctl->err, err);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long te = 0;
+        int tb = 0;
+        for (int w = 0; w < wpb; ++w) {
+            te += s_edges[w];
+            tb += s_nb[w];
+        }
+        if (tb) {
+            atomicAdd(&a.ctl->edges, te);
+            atomicAdd(&a.ctl->bids, (unsigned long long)tb);
+            if (a.launch_edges) atomicAdd(&a.launch_edges[a.launch_idx], te);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_tiebreak(RoundArgs a) {
+    const Ctl *ctl = a.ctl;
+    if (!round_live(ctl, a.thr)) return;
+    int lo, hi;
+    shard_range(ctl->K, a.rank, a.world, lo, hi);
+    for (int n = lo + blockIdx.x * blockDim.x + threadIdx.x; n < hi; n += gridDim.x * blockDim.x) {
+        const int j = a.bid_obj[n];
+        if (a.bid_key[n] == a.best_key[j]) atomicMin(&a.best_pos[j], n);
+    }
+}
+
+// One thread per object.  All writes of one round are disjoint: winners are distinct unassigned
+// persons, evicted owners are distinct assigned persons, and a winner's slot in U is its own.
+__global__ __launch_bounds__(256) void k_apply(RoundArgs a) {
+    Ctl *ctl = a.ctl;
+    if (!round_live(ctl, a.thr)) return;
+    int holes = 0;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < a.n_cols; j += gridDim.x * blockDim.x) {
+        const int n = a.best_pos[j];
+        if (n != kPosNone) {
+            const int i = a.U[n];
+            a.price[j] = key_to_bid(a.best_key[j]);  // p[j] = best_bids[j]   (:397)
+            const int prev = a.o2p[j];               // :401
+            if (prev != -1) {
+                a.p2o[prev] = -1;                    // :404
+                a.U[n] = prev;                       // :409 evicted owner inherits the slot
+            } else {
+                a.U[n] = -1;                         // :412 hole
+                holes += 1;
+            }
+            a.p2o[i] = j;                            // :417
+            a.o2p[j] = i;                            // :418
+            a.best_key[j] = 0ull;                    // :421-422
+            a.best_pos[j] = kPosNone;
+        }
+    }
+    // one atomic per wavefront
+    for (int off = 32; off >= 1; off >>= 1) holes += __shfl_xor(holes, off);
+    if ((threadIdx.x & 63) == 0 && holes) atomicAdd(&ctl->nholes, holes);
+}
+
+// push_all_left: the k-th empty slot in [0, K') receives the k-th person found in [K', K).
+constexpr int kChunk = 1024;  // U positions per block (256 threads x 4)
+__global__ __launch_bounds__(256) void k_compact_count(RoundArgs a) {
+    const Ctl *ctl = a.ctl;
+    if (!round_live(ctl, a.thr)) return;
+    const int K = ctl->K, Kn = K - ctl->nholes;
+    if (ctl->nholes == 0) return;
+    const int nchunks = (K + kChunk - 1) / kChunk;
+    __shared__ int sl[4], sm[4];
+    for (int b = blockIdx.x; b < nchunks; b += gridDim.x) {
+        int l = 0, m = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = b * kChunk + q * 256 + threadIdx.x;
+            if (n < K) {
+                const int u = a.U[n];
+                l += (n < Kn && u == -1);
+                m += (n >= Kn && u != -1);
+            }
+        }
+        for (int off = 32; off >= 1; off >>= 1) {
+            l += __shfl_xor(l, off);
+            m += __shfl_xor(m, off);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            sl[threadIdx.x >> 6] = l;
+            sm[threadIdx.x >> 6] = m;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            a.cnt[2 * b] = sl[0] + sl[1] + sl[2] + sl[3];
+            a.cnt[2 * b + 1] = sm[0] + sm[1] + sm[2] + sm[3];
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_compact_scatter(RoundArgs a) {
+    Ctl *ctl = a.ctl;
+    if (!round_live(ctl, a.thr)) return;
+    const int K = ctl->K, Kn = K - ctl->nholes;
+    if (ctl->nholes == 0) return;
+    const int nchunks = (K + kChunk - 1) / kChunk;
+    __shared__ int s_red[2][4];
+    __shared__ int s_wl[4], s_wm[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int b = blockIdx.x; b < nchunks; b += gridDim.x) {
+        // exclusive offsets of this chunk = sum of the counts of all earlier chunks
+        int pl = 0, pm = 0;
+        for (int c = threadIdx.x; c < b; c += 256) {
+            pl += a.cnt[2 * c];
+            pm += a.cnt[2 * c + 1];
+        }
+        for (int off = 32; off >= 1; off >>= 1) {
+            pl += __shfl_xor(pl, off);
+            pm += __shfl_xor(pm, off);
+        }
+        if (lane == 0) {
+            s_red[0][wave] = pl;
+            s_red[1][wave] = pm;
+        }
+        __syncthreads();
+        int offl = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+        int offm = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = b * kChunk + q * 256 + threadIdx.x;
+            int u = -1;
+            if (n < K) u = a.U[n];
+            const bool isl = (n < Kn) && (u == -1);
+            const bool ism = (n >= Kn) && (n < K) && (u != -1);
+            const unsigned long long bl = __ballot(isl), bm = __ballot(ism);
+            if (lane == 0) {
+                s_wl[wave] = __popcll(bl);
+                s_wm[wave] = __popcll(bm);
+            }
+            __syncthreads();
+            int wl = 0, wm = 0, tl = 0, tm = 0;
+            for (int w2 = 0; w2 < 4; ++w2) {
+                if (w2 < wave) {
+                    wl += s_wl[w2];
+                    wm += s_wm[w2];
+                }
+                tl += s_wl[w2];
+                tm += s_wm[w2];
+            }
+            if (isl) a.hole_list[offl + wl + __popcll(bl & lanemask_lt())] = n;
+            if (ism) {
+                a.mover_list[offm + wm + __popcll(bm & lanemask_lt())] = u;
+                a.U[n] = -1;  // data[right_track] = -1   (:159)
+            }
+            offl += tl;
+            offm += tm;
+            __syncthreads();
+        }
+        if (b == nchunks - 1 && threadIdx.x == 0) ctl->nleft = offl;  // total left holes (== movers)
+    }
+}
+
+__global__ __launch_bounds__(256) void k_compact_fill(RoundArgs a) {
+    const Ctl *ctl = a.ctl;
+    if (!round_live(ctl, a.thr)) return;
+    if (ctl->nholes == 0) return;
+    const int nl = ctl->nleft;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nl; k += gridDim.x * blockDim.x)
+        a.U[a.hole_list[k]] = a.mover_list[k];  // data[left_track] = i   (:158)
+}
+
+__global__ void k_round_end(RoundArgs a) {
+    Ctl *ctl = a.ctl;
+    if (!round_live(ctl, a.thr)) return;
+    ctl->K = ctl->K - ctl->nholes;  // :429
+    ctl->nholes = 0;
+    ctl->nleft = 0;
+    ctl->nits += 1;                 // :273
+    ctl->grid_rounds += 1;
+}
+
+// eps-phase restart (auction_.pyx:286-290): forget assignments, keep prices.
+__global__ __launch_bounds__(256) void k_reset_phase(Ctl *ctl, int *p2o, int *o2p, int *U, int n_rows,
+                                                     int n_cols) {
+    const int stride = gridDim.x * blockDim.x;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int i = t; i < n_rows; i += stride) {
+        p2o[i] = -1;
+        U[i] = i;
+    }
+    for (int j = t; j < n_cols; j += stride) o2p[j] = -1;
+    if (t == 0) {
+        ctl->K = n_rows;
+        ctl->nholes = 0;
+        ctl->nleft = 0;
+    }
+}
+
+}  // namespace misslap

@@ -1,0 +1,216 @@
+// kernels_tail.hpp -- the long tail of tiny rounds inside ONE persistent workgroup.
+//
+// At the BASELINE sizes > 98 % of all rounds have <= 64 bidders and
+// every round depends on the prices of the previous one, so the tail is a latency chain, not a
+// bandwidth problem.  One 1024-thread workgroup (16 wavefronts, one CU) loops over rounds on the
+// device: the unassigned list lives in LDS, each wavefront bids for one person at a time
+// (auction_.pyx:339-365), conflicts are resolved in LDS (:375-385), winners are applied (:388-427)
+// and the list is compacted (push_all_left, :137-162) without leaving the kernel.  K never grows
+// inside an eps-phase (every winner evicts at most one owner), so once K <= threshold the whole
+// rest of the phase runs here.  The kernel exits when K == 0 or nits == max_iter.
+//
+// Visibility: prices / o2p / p2o are written and re-read by this one workgroup only (same CU, same
+// vector L1, __syncthreads() between phases); the CSR is read-only.  No other workgroup runs.
+#pragma once
+#include "device_common.hpp"
+
+namespace misslap {
+
+struct TailArgs {
+    Ctl *ctl;
+    const int *row_ptr;
+    double *price;
+    int *p2o;
+    int *o2p;
+    int *U;
+    int thr;
+    float eps;
+};
+
+constexpr int kHashSize = 2048;  // LDS open-addressing table for K > 64 (load factor <= 0.5)
+
+__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int l) {
+    const int lo = __builtin_amdgcn_readlane((int)(unsigned)(v & 0xffffffffull), l);
+    const int hi = __builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+    return ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo;
+}
+
+// assignment of one winner (auction_.pyx:396-418); returns the new content of its U slot
+__device__ __forceinline__ int apply_winner(const TailArgs &a, int person, int obj, int prev,
+                                            unsigned long long key) {
+    a.price[obj] = key_to_bid(key);
+    a.o2p[obj] = person;
+    a.p2o[person] = obj;
+    if (prev != -1) {
+        a.p2o[prev] = -1;
+        return prev;  // evicted owner inherits the slot (:409)
+    }
+    return -1;        // hole (:412)
+}
+
+template <class E>
+__global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
+    __shared__ int sU[kTailMax];
+    __shared__ unsigned long long sKey[kTailMax];
+    __shared__ int sObj[kTailMax];
+    __shared__ int sPrev[kTailMax];
+    __shared__ int sList[kTailMax];
+    __shared__ int hObj[kHashSize];
+    __shared__ unsigned long long hKey[kHashSize];
+    __shared__ int hPos[kHashSize];
+    __shared__ int sCnt[3][kTailMax / kWave];
+    __shared__ int sK;
+
+    Ctl *ctl = a.ctl;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    constexpr int nwaves = kTailMax / kWave;
+    int K = ctl->K;
+    long long nits = ctl->nits;
+    const long long max_iter = ctl->max_iter;
+    if (K == 0 || K > a.thr || nits >= max_iter) return;  // uniform
+    const int K0 = K;
+    const long long nits0 = nits;
+    sU[t] = (t < K) ? a.U[t] : -1;
+    for (int h = t; h < kHashSize; h += kTailMax) {
+        hObj[h] = -1;
+        hKey[h] = 0ull;
+        hPos[h] = kPosNone;
+    }
+    const double eps = (double)a.eps;
+    unsigned long long edges = 0, bids = 0;
+    int err = 0;
+    __syncthreads();
+
+    for (;;) {
+        // ---- BID: one wavefront per bidder ---------------------------------------------------
+        for (int n = wave; n < K; n += nwaves) {
+            const int i = sU[n];
+            const int s = a.row_ptr[i], e = a.row_ptr[i + 1];
+            unsigned long long key;
+            int obj;
+            wave_bid(ed, a.price, s, e, eps, key, obj, err);
+            if (lane == 0) {
+                sKey[n] = key;
+                sObj[n] = obj;
+                // owner at the start of the round == what the assignment phase reads (:401): o2p[obj]
+                // is only rewritten by this round's winner of obj, after every bid has been made.
+                sPrev[n] = __hip_atomic_load(&a.o2p[obj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            edges += (unsigned long long)(e - s);
+            bids += 1;
+        }
+        __syncthreads();
+
+        if (K <= kWave) {
+            // ---- fast path: the whole rest of the round in wavefront 0, no LDS atomics ------------
+            if (wave == 0) {
+                const bool act = lane < K;
+                const unsigned long long key = act ? sKey[lane] : 0ull;
+                const int obj = act ? sObj[lane] : (-2 - lane);
+                bool lose = false;
+                for (int m = 0; m < K; ++m) {  // RESOLVE (:375-385): K <= 64 all-pairs via readlane
+                    const unsigned long long km = readlane_u64(key, m);
+                    const int om = __builtin_amdgcn_readlane(obj, m);
+                    lose |= (om == obj) && (km > key || (km == key && m < lane));
+                }
+                int u = act ? sU[lane] : -1;
+                if (act && !lose) u = apply_winner(a, u, obj, sPrev[lane], key);
+                // push_all_left with ballots
+                const unsigned long long kmask = (K >= 64) ? ~0ull : ((1ull << K) - 1ull);
+                const unsigned long long holes = __ballot(act && u == -1) & kmask;
+                const int Kn = K - __popcll(holes);
+                const unsigned long long lmask = (Kn >= 64) ? ~0ull : ((1ull << Kn) - 1ull);
+                const unsigned long long hl = holes & lmask;            // empty slots left of K'
+                const unsigned long long mv = ~holes & ~lmask & kmask;  // persons right of K'
+                const bool is_hl = (hl >> lane) & 1ull, is_mv = (mv >> lane) & 1ull;
+                if (is_hl) sList[__popcll(hl & lanemask_lt())] = lane;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (is_mv) sU[sList[__popcll(mv & lanemask_lt())]] = u;
+                if (act) {
+                    if (lane >= Kn) sU[lane] = -1;
+                    else if (!is_hl) sU[lane] = u;
+                }
+                if (lane == 0) sK = Kn;
+            }
+        } else {
+            // ---- general path (64 < K <= 1024): LDS hash table keyed by object ---------------------
+            const bool act = t < K;
+            unsigned long long key = 0ull;
+            int obj = -1, h = 0;
+            if (act) {
+                key = sKey[t];
+                obj = sObj[t];
+                h = (int)(((unsigned)obj * 2654435761u) >> 21) & (kHashSize - 1);
+                for (;;) {
+                    const int old = atomicCAS(&hObj[h], -1, obj);
+                    if (old == -1 || old == obj) break;
+                    h = (h + 1) & (kHashSize - 1);
+                }
+                atomicMax(&hKey[h], key);
+            }
+            __syncthreads();
+            if (act && hKey[h] == key) atomicMin(&hPos[h], t);
+            __syncthreads();
+            const bool win = act && hPos[h] == t;
+            __syncthreads();
+            if (act) {  // several threads may clear one slot: identical values
+                hObj[h] = -1;
+                hKey[h] = 0ull;
+                hPos[h] = kPosNone;
+            }
+            int u = act ? sU[t] : -1;
+            if (win) u = apply_winner(a, u, obj, sPrev[t], key);
+            const bool hole = act && u == -1;
+            const unsigned long long bh = __ballot(hole);
+            if (lane == 0) sCnt[0][wave] = __popcll(bh);
+            __syncthreads();
+            int total = 0;
+            for (int w2 = 0; w2 < nwaves; ++w2) total += sCnt[0][w2];
+            const int Kn = K - total;
+            const bool is_hl = hole && t < Kn;
+            const bool is_mv = act && !hole && t >= Kn;
+            const unsigned long long bl = __ballot(is_hl), bm = __ballot(is_mv);
+            if (lane == 0) {
+                sCnt[1][wave] = __popcll(bl);
+                sCnt[2][wave] = __popcll(bm);
+            }
+            __syncthreads();
+            int pl = __popcll(bl & lanemask_lt()), pm = __popcll(bm & lanemask_lt());
+            for (int w2 = 0; w2 < wave; ++w2) {
+                pl += sCnt[1][w2];
+                pm += sCnt[2][w2];
+            }
+            if (is_hl) sList[pl] = t;
+            __syncthreads();
+            if (is_mv) sU[sList[pm]] = u;
+            if (act) {
+                if (t >= Kn) sU[t] = -1;
+                else if (!is_hl) sU[t] = u;
+            }
+            if (t == 0) sK = Kn;
+        }
+        __syncthreads();
+        K = sK;
+        nits += 1;
+        if (K == 0 || nits >= max_iter) break;
+    }
+
+    if (t < K0) a.U[t] = sU[t];
+    if (lane == 0) {
+        if (edges) {
+            atomicAdd(&ctl->edges, edges);
+            atomicAdd(&ctl->tail_edges, edges);
+            atomicAdd(&ctl->bids, bids);
+        }
+        if (err) atomicOr(&ctl->err, err);
+    }
+    if (t == 0) {
+        ctl->K = K;
+        ctl->nits = nits;
+        ctl->tail_rounds += nits - nits0;
+    }
+}
+
+}  // namespace misslap

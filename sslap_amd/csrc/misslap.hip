@@ -1,0 +1,760 @@
+// misslap.hip -- host driver + C ABI of libmisslap.so (MI355X / gfx950 only).
+//
+// Host side of the reference's AuctionSolver (sslap/auction_.pyx:164-523): construction (CSR build on
+// the GPU), the eps-scaling outer loop of solve() (:268-306) and the result / meta extraction.  All
+// per-edge and per-person work is in the kernels_*.hpp headers; this file only sequences launches on
+// one HIP stream and reads back a 100-byte control block when the loop needs a decision.
+//
+// Build: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -shared -fPIC misslap.hip -o libmisslap.so
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/misslap.h"
+#include "device_common.hpp"
+#include "kernels_check.hpp"
+#include "kernels_ingest.hpp"
+#include "kernels_round.hpp"
+#include "kernels_tail.hpp"
+
+using namespace misslap;
+
+#define MISSLAP_API extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            return fail(MISSLAP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                        __LINE__);                                                                 \
+    } while (0)
+
+double now_ms() {
+    using clk = std::chrono::steady_clock;
+    return std::chrono::duration<double, std::milli>(clk::now().time_since_epoch()).count();
+}
+
+constexpr int kDefaultTailThreshold = 256;
+constexpr int kDefaultRoundsPerSync = 4;
+constexpr int kMaxGridBlocks = 2048;  // 256 CUs x 8 resident 256-thread blocks
+
+struct ProfRec {
+    hipEvent_t start, stop;
+    int kind;        // 0 = grid bid kernel, 1 = tail kernel
+    int fullscan;    // bid launch with K == n_rows
+    int launch_idx;  // index into launch_edges (kind 0)
+};
+
+}  // namespace
+
+struct misslap_solver {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int64_t nnz = 0;
+    int n_rows = 0, n_cols = 0;
+    int maximize = 0;
+    bool f32 = true;
+    // device buffers
+    int2 *edges32 = nullptr;
+    int *col = nullptr;
+    double *val64 = nullptr;
+    int *row_ptr = nullptr;
+    double *price = nullptr;
+    int *p2o = nullptr, *o2p = nullptr, *U = nullptr;
+    unsigned long long *bid_key = nullptr;
+    int *bid_obj = nullptr;
+    unsigned long long *best_key = nullptr;
+    int *best_pos = nullptr;
+    int *cnt = nullptr, *hole_list = nullptr, *mover_list = nullptr;
+    Ctl *ctl = nullptr;
+    double *contrib = nullptr;
+    int *nmatch = nullptr;
+    unsigned long long *launch_edges = nullptr;
+    int launch_edges_cap = 0;
+    Ctl *h_ctl = nullptr;  // pinned mirror
+    // scalar solver state (auction_.pyx:180-187)
+    float eps = 0, target_eps = 0, theta = 0, start_eps = 0;
+    int nreductions = 0;
+    bool finished = false;
+    int64_t max_iter = 0;
+    int thr = kDefaultTailThreshold;
+    int rounds_per_sync = kDefaultRoundsPerSync;
+    int rank = 0, world = 1;
+    bool profile = false;
+    int K_ub = 0;  // host-side upper bound of K (K never grows inside a phase)
+    bool phase_fresh = true;  // no round of the current eps-phase has been enqueued yet
+    std::vector<ProfRec> prof;
+    size_t prof_used = 0;
+    int launch_idx = 0;
+    double setup_ms = 0, solve_ms = 0;
+};
+
+namespace {
+
+template <class T>
+int dev_alloc(T **p, size_t n) {
+    HIP_TRY(hipMalloc((void **)p, (n ? n : 1) * sizeof(T)));
+    return MISSLAP_OK;
+}
+
+RoundArgs round_args(misslap_solver *h) {
+    RoundArgs a;
+    a.ctl = h->ctl;
+    a.row_ptr = h->row_ptr;
+    a.price = h->price;
+    a.p2o = h->p2o;
+    a.o2p = h->o2p;
+    a.U = h->U;
+    a.bid_key = h->bid_key;
+    a.bid_obj = h->bid_obj;
+    a.best_key = h->best_key;
+    a.best_pos = h->best_pos;
+    a.cnt = h->cnt;
+    a.hole_list = h->hole_list;
+    a.mover_list = h->mover_list;
+    a.launch_edges = h->profile ? h->launch_edges : nullptr;
+    a.n_rows = h->n_rows;
+    a.n_cols = h->n_cols;
+    a.thr = h->thr;
+    a.rank = h->rank;
+    a.world = h->world;
+    a.eps = h->eps;
+    a.launch_idx = 0;
+    return a;
+}
+
+int blocks_for(long long items, int per_block) {
+    long long b = (items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > kMaxGridBlocks) b = kMaxGridBlocks;
+    return (int)b;
+}
+
+ProfRec *prof_next(misslap_solver *h, int kind) {
+    if (h->prof_used == h->prof.size()) {
+        ProfRec r{};
+        if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return nullptr;
+        h->prof.push_back(r);
+    }
+    ProfRec *r = &h->prof[h->prof_used++];
+    r->kind = kind;
+    r->fullscan = 0;
+    r->launch_idx = -1;
+    return r;
+}
+
+int read_ctl(misslap_solver *h) {
+    HIP_TRY(hipMemcpyAsync(h->h_ctl, h->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->K_ub = h->h_ctl->K;
+    if (h->h_ctl->err)
+        return fail(MISSLAP_ERR_STATE, "device-side invariant violated (error bits 0x%x)", h->h_ctl->err);
+    return MISSLAP_OK;
+}
+
+int launch_bid(misslap_solver *h) {
+    RoundArgs a = round_args(h);
+    const long long share = ((long long)h->K_ub + h->world - 1) / h->world;
+    const int grid = blocks_for(share, kBidBlock / kWave);
+    ProfRec *pr = nullptr;
+    if (h->profile) {
+        if (h->launch_idx >= h->launch_edges_cap)
+            return fail(MISSLAP_ERR_STATE, "profile buffer exhausted (%d bid launches)", h->launch_idx);
+        pr = prof_next(h, 0);
+        if (!pr) return fail(MISSLAP_ERR_HIP, "hipEventCreate failed");
+        pr->fullscan = h->phase_fresh && h->world == 1;
+        pr->launch_idx = a.launch_idx = h->launch_idx++;
+        HIP_TRY(hipEventRecord(pr->start, h->stream));
+    }
+    if (h->f32) {
+        EdgesF32 ed{h->edges32};
+        hipLaunchKernelGGL(k_bid<EdgesF32>, dim3(grid), dim3(kBidBlock), 0, h->stream, a, ed);
+    } else {
+        EdgesF64 ed{h->col, h->val64};
+        hipLaunchKernelGGL(k_bid<EdgesF64>, dim3(grid), dim3(kBidBlock), 0, h->stream, a, ed);
+    }
+    if (pr) HIP_TRY(hipEventRecord(pr->stop, h->stream));
+    HIP_TRY(hipGetLastError());
+    h->phase_fresh = false;
+    return MISSLAP_OK;
+}
+
+int launch_tiebreak(misslap_solver *h) {
+    RoundArgs a = round_args(h);
+    const long long share = ((long long)h->K_ub + h->world - 1) / h->world;
+    hipLaunchKernelGGL(k_tiebreak, dim3(blocks_for(share, 256)), dim3(256), 0, h->stream, a);
+    HIP_TRY(hipGetLastError());
+    return MISSLAP_OK;
+}
+
+int launch_apply(misslap_solver *h) {
+    RoundArgs a = round_args(h);
+    hipLaunchKernelGGL(k_apply, dim3(blocks_for(h->n_cols, 256)), dim3(256), 0, h->stream, a);
+    const int cb = blocks_for(h->K_ub, kChunk);
+    hipLaunchKernelGGL(k_compact_count, dim3(cb), dim3(256), 0, h->stream, a);
+    hipLaunchKernelGGL(k_compact_scatter, dim3(cb), dim3(256), 0, h->stream, a);
+    hipLaunchKernelGGL(k_compact_fill, dim3(blocks_for(h->K_ub, 256)), dim3(256), 0, h->stream, a);
+    hipLaunchKernelGGL(k_round_end, dim3(1), dim3(1), 0, h->stream, a);
+    HIP_TRY(hipGetLastError());
+    return MISSLAP_OK;
+}
+
+int launch_tail(misslap_solver *h) {
+    if (h->thr <= 0) return MISSLAP_OK;
+    TailArgs a;
+    a.ctl = h->ctl;
+    a.row_ptr = h->row_ptr;
+    a.price = h->price;
+    a.p2o = h->p2o;
+    a.o2p = h->o2p;
+    a.U = h->U;
+    a.thr = h->thr;
+    a.eps = h->eps;
+    ProfRec *pr = nullptr;
+    if (h->profile) {
+        pr = prof_next(h, 1);
+        if (!pr) return fail(MISSLAP_ERR_HIP, "hipEventCreate failed");
+        HIP_TRY(hipEventRecord(pr->start, h->stream));
+    }
+    if (h->f32) {
+        EdgesF32 ed{h->edges32};
+        hipLaunchKernelGGL(k_tail<EdgesF32>, dim3(1), dim3(kTailMax), 0, h->stream, a, ed);
+    } else {
+        EdgesF64 ed{h->col, h->val64};
+        hipLaunchKernelGGL(k_tail<EdgesF64>, dim3(1), dim3(kTailMax), 0, h->stream, a, ed);
+    }
+    if (pr) HIP_TRY(hipEventRecord(pr->stop, h->stream));
+    HIP_TRY(hipGetLastError());
+    h->phase_fresh = false;
+    return MISSLAP_OK;
+}
+
+int run_ece(misslap_solver *h, float eps, int *ok) {
+    int rc = read_ctl(h);
+    if (rc) return rc;
+    if (h->h_ctl->K > 0) {  // auction_.pyx:446-447
+        *ok = 0;
+        return MISSLAP_OK;
+    }
+    HIP_TRY(hipMemsetAsync(&h->ctl->ece_fail, 0, sizeof(int), h->stream));
+    const int grid = blocks_for(h->n_rows, 4);
+    if (h->f32) {
+        EdgesF32 ed{h->edges32};
+        hipLaunchKernelGGL(k_ece<EdgesF32>, dim3(grid), dim3(256), 0, h->stream, h->ctl, ed, h->row_ptr, h->price,
+                           h->p2o, h->n_rows, eps);
+    } else {
+        EdgesF64 ed{h->col, h->val64};
+        hipLaunchKernelGGL(k_ece<EdgesF64>, dim3(grid), dim3(256), 0, h->stream, h->ctl, ed, h->row_ptr, h->price,
+                           h->p2o, h->n_rows, eps);
+    }
+    HIP_TRY(hipGetLastError());
+    rc = read_ctl(h);
+    if (rc) return rc;
+    *ok = h->h_ctl->ece_fail ? 0 : 1;
+    return MISSLAP_OK;
+}
+
+void free_all(misslap_solver *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    void *ptrs[] = {h->edges32, h->col,     h->val64,     h->row_ptr,    h->price,   h->p2o,     h->o2p,
+                    h->U,       h->bid_key, h->bid_obj,   h->best_key,   h->best_pos, h->cnt,    h->hole_list,
+                    h->mover_list, h->ctl,  h->contrib,   h->nmatch,     h->launch_edges};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (h->h_ctl) (void)hipHostFree(h->h_ctl);
+    for (auto &r : h->prof) {
+        (void)hipEventDestroy(r.start);
+        (void)hipEventDestroy(r.stop);
+    }
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+// Shared tail of the two constructors: d_loc / d_val are device-resident COO arrays.
+int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_val, int last_row,
+                          const misslap_options *opt) {
+    const int64_t nnz = h->nnz;
+    if (last_row < 0) return fail(MISSLAP_ERR_INVALID, "negative row index");
+    h->n_rows = last_row + 1;  // auction_.pyx:209 (rows are ascending, so the last one is the maximum)
+    int rc;
+    IngestStats *d_st = nullptr;
+    if ((rc = dev_alloc(&d_st, 1))) return rc;
+    HIP_TRY(hipMemsetAsync(d_st, 0, sizeof(IngestStats), h->stream));
+    {
+        const int init = -1;
+        HIP_TRY(hipMemcpyAsync(&d_st->max_col, &init, sizeof(int), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));  // `init` lives on this stack frame
+    }
+    if ((rc = dev_alloc(&h->row_ptr, (size_t)h->n_rows + 1))) return rc;
+    const int grid = blocks_for(nnz, 256 * 8);
+    hipLaunchKernelGGL(k_ingest_rows, dim3(grid), dim3(256), 0, h->stream, d_loc, (long long)nnz, h->n_rows,
+                       h->row_ptr, d_st);
+    hipLaunchKernelGGL(k_ingest_vals, dim3(grid), dim3(256), 0, h->stream, d_val, (long long)nnz, d_st);
+    IngestStats st;
+    HIP_TRY(hipMemcpyAsync(&st, d_st, sizeof(st), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    (void)hipFree(d_st);
+    if (st.err & kErrColNegative) return fail(MISSLAP_ERR_INVALID, "loc holds a negative row or column index");
+    if (st.err & kErrRowsUnsorted)
+        return fail(MISSLAP_ERR_INVALID, "loc rows must be sorted in ascending order (auction_.pyx:33-48 contract)");
+    if (st.err & kErrRowGap)
+        return fail(MISSLAP_ERR_INVALID,
+                    "every row 0..N-1 must have at least one entry (auction_.pyx:33-48 contract)");
+    if (st.err & kErrNonFinite) return fail(MISSLAP_ERR_INVALID, "val holds a NaN or an infinity");
+    h->n_cols = st.max_col + 1;  // auction_.pyx:210
+    h->f32 = !st.not_f32 && !opt->force_f64_values;
+    const int flip = h->maximize ? 0 : 1;
+    if (h->f32) {
+        if ((rc = dev_alloc(&h->edges32, (size_t)nnz))) return rc;
+        hipLaunchKernelGGL(k_build_edges_f32, dim3(grid), dim3(256), 0, h->stream, d_loc, d_val, (long long)nnz,
+                           flip, h->edges32);
+    } else {
+        if ((rc = dev_alloc(&h->col, (size_t)nnz))) return rc;
+        if ((rc = dev_alloc(&h->val64, (size_t)nnz))) return rc;
+        hipLaunchKernelGGL(k_build_edges_f64, dim3(grid), dim3(256), 0, h->stream, d_loc, d_val, (long long)nnz,
+                           flip, h->col, h->val64);
+    }
+    const size_t N = (size_t)h->n_rows, M = (size_t)h->n_cols;
+    if ((rc = dev_alloc(&h->price, M))) return rc;
+    if ((rc = dev_alloc(&h->p2o, N))) return rc;
+    if ((rc = dev_alloc(&h->o2p, M))) return rc;
+    if ((rc = dev_alloc(&h->U, N))) return rc;
+    if ((rc = dev_alloc(&h->bid_key, N))) return rc;
+    if ((rc = dev_alloc(&h->bid_obj, N))) return rc;
+    if ((rc = dev_alloc(&h->best_key, M))) return rc;
+    if ((rc = dev_alloc(&h->best_pos, M))) return rc;
+    if ((rc = dev_alloc(&h->cnt, 2 * ((N + kChunk - 1) / kChunk) + 2))) return rc;
+    if ((rc = dev_alloc(&h->hole_list, N))) return rc;
+    if ((rc = dev_alloc(&h->mover_list, N))) return rc;
+    if ((rc = dev_alloc(&h->ctl, 1))) return rc;
+    if ((rc = dev_alloc(&h->contrib, N))) return rc;
+    if ((rc = dev_alloc(&h->nmatch, N))) return rc;
+    HIP_TRY(hipHostMalloc((void **)&h->h_ctl, sizeof(Ctl)));
+    if (h->profile) {
+        h->launch_edges_cap = 1 << 20;
+        if ((rc = dev_alloc(&h->launch_edges, (size_t)h->launch_edges_cap))) return rc;
+        HIP_TRY(hipMemsetAsync(h->launch_edges, 0, sizeof(unsigned long long) * h->launch_edges_cap, h->stream));
+    }
+    h->max_iter = opt->max_iter < 1 ? 1 : opt->max_iter;  // the loop body runs before the first test (:271-275)
+    hipLaunchKernelGGL(k_init_state, dim3(blocks_for((long long)(N > M ? N : M), 256)), dim3(256), 0, h->stream,
+                       h->ctl, h->price, h->p2o, h->o2p, h->U, h->best_key, h->best_pos, h->n_rows, h->n_cols,
+                       (long long)h->max_iter);
+    HIP_TRY(hipGetLastError());
+    // eps schedule, fp32 exactly as the generated C of the reference
+    double max_abs;
+    {
+        const long long b = (long long)st.max_abs_bits;
+        std::memcpy(&max_abs, &b, sizeof(double));
+    }
+    const float C = (float)max_abs;               // auction_.pyx:242-243
+    h->eps = (float)((double)C / 2.0);            // :246
+    h->target_eps = (float)(1.0 / (double)h->n_rows);  // :247
+    h->theta = (float)0.15;                       // :248
+    if (opt->eps_start > 0) h->eps = opt->eps_start;  // :251-252
+    h->start_eps = h->eps;
+    h->K_ub = h->n_rows;
+    h->phase_fresh = true;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return MISSLAP_OK;
+}
+
+int new_handle(misslap_solver **out, const misslap_options *opt, misslap_solver **hp) {
+    if (!out || !opt) return fail(MISSLAP_ERR_INVALID, "null argument");
+    if (opt->struct_size != (int32_t)sizeof(misslap_options))
+        return fail(MISSLAP_ERR_INVALID, "misslap_options.struct_size mismatch (ABI %d)", MISSLAP_ABI_VERSION);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(MISSLAP_ERR_NO_DEVICE, "no HIP device available: libmisslap has no CPU fallback");
+    if (opt->device < 0 || opt->device >= ndev) return fail(MISSLAP_ERR_INVALID, "device %d out of range", opt->device);
+    if (opt->tail_threshold > kTailMax)
+        return fail(MISSLAP_ERR_INVALID, "tail_threshold %d exceeds %d", opt->tail_threshold, kTailMax);
+    if (opt->shard_world < 0 || (opt->shard_world > 0 && (opt->shard_rank < 0 || opt->shard_rank >= opt->shard_world)))
+        return fail(MISSLAP_ERR_INVALID, "bad shard rank/world");
+    HIP_TRY(hipSetDevice(opt->device));
+    misslap_solver *h = new misslap_solver();
+    h->device = opt->device;
+    h->maximize = opt->maximize ? 1 : 0;
+    h->thr = opt->tail_threshold < 0 ? kDefaultTailThreshold : opt->tail_threshold;
+    h->rounds_per_sync = opt->rounds_per_sync > 0 ? opt->rounds_per_sync : kDefaultRoundsPerSync;
+    h->world = opt->shard_world > 0 ? opt->shard_world : 1;
+    h->rank = opt->shard_world > 0 ? opt->shard_rank : 0;
+    h->profile = opt->profile != 0;
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        return fail(MISSLAP_ERR_HIP, "hipStreamCreate failed");
+    }
+    h->own_stream = true;
+    *hp = h;
+    return MISSLAP_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+MISSLAP_API int misslap_abi_version(void) { return MISSLAP_ABI_VERSION; }
+MISSLAP_API const char *misslap_last_error(void) { return g_err.c_str(); }
+
+MISSLAP_API int misslap_device_info(int32_t device, char *name, int32_t name_len, int32_t *compute_units,
+                                    int64_t *hbm_bytes) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(MISSLAP_ERR_NO_DEVICE, "no HIP device available");
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, device));
+    if (name && name_len > 0) snprintf(name, (size_t)name_len, "%s (%s)", p.name, p.gcnArchName);
+    if (compute_units) *compute_units = p.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)p.totalGlobalMem;
+    return MISSLAP_OK;
+}
+
+MISSLAP_API int misslap_create(misslap_solver **out, int64_t nnz, const int32_t *loc, const double *val,
+                               const misslap_options *opt) {
+    const double t0 = now_ms();
+    if (!loc || !val) return fail(MISSLAP_ERR_INVALID, "null loc / val");
+    if (nnz <= 0) return fail(MISSLAP_ERR_INVALID, "empty problem (nnz = %lld)", (long long)nnz);
+    if (nnz >= (int64_t)0x7fffffff) return fail(MISSLAP_ERR_INVALID, "nnz must be < 2^31 (int32 row pointers)");
+    misslap_solver *h = nullptr;
+    int rc = new_handle(out, opt, &h);
+    if (rc) return rc;
+    h->nnz = nnz;
+    const int *d_loc = nullptr;
+    const double *d_val = nullptr;
+    int *own_loc = nullptr;
+    double *own_val = nullptr;
+    int last_row = -1;
+    auto cleanup = [&](int code) {
+        if (own_loc) (void)hipFree(own_loc);
+        if (own_val) (void)hipFree(own_val);
+        if (code) free_all(h);
+        return code;
+    };
+    if (opt->input_on_device) {
+        d_loc = loc;
+        d_val = val;
+        if (hipMemcpy(&last_row, loc + 2 * (nnz - 1), sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
+            return cleanup(fail(MISSLAP_ERR_HIP, "cannot read loc from the device"));
+    } else {
+        if ((rc = dev_alloc(&own_loc, (size_t)nnz * 2))) return cleanup(rc);
+        if ((rc = dev_alloc(&own_val, (size_t)nnz))) return cleanup(rc);
+        if (hipMemcpyAsync(own_loc, loc, sizeof(int) * 2 * (size_t)nnz, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+            hipMemcpyAsync(own_val, val, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice, h->stream) != hipSuccess)
+            return cleanup(fail(MISSLAP_ERR_HIP, "host-to-device copy of the COO input failed"));
+        d_loc = own_loc;
+        d_val = own_val;
+        last_row = loc[2 * (nnz - 1)];
+    }
+    rc = build_from_device_coo(h, d_loc, d_val, last_row, opt);
+    if (rc) return cleanup(rc);
+    cleanup(0);
+    h->setup_ms = now_ms() - t0;
+    *out = h;
+    return MISSLAP_OK;
+}
+
+MISSLAP_API int misslap_create_dense(misslap_solver **out, int64_t n_rows, int64_t n_cols, const double *mat,
+                                     const misslap_options *opt, int64_t *nnz_out) {
+    const double t0 = now_ms();
+    if (!mat) return fail(MISSLAP_ERR_INVALID, "null mat");
+    if (n_rows <= 0 || n_cols <= 0 || n_rows > 0x7ffffffe || n_cols > 0x7ffffffe)
+        return fail(MISSLAP_ERR_INVALID, "bad dense shape");
+    misslap_solver *h = nullptr;
+    int rc = new_handle(out, opt, &h);
+    if (rc) return rc;
+    double *d_mat = nullptr, *d_val = nullptr;
+    int *d_cnt = nullptr, *d_ptr = nullptr, *d_loc = nullptr;
+    IngestStats *d_st = nullptr;
+    auto cleanup = [&](int code) {
+        for (void *p : {(void *)d_mat, (void *)d_val, (void *)d_cnt, (void *)d_ptr, (void *)d_loc, (void *)d_st})
+            if (p) (void)hipFree(p);
+        if (code) free_all(h);
+        return code;
+    };
+    const size_t cells = (size_t)n_rows * (size_t)n_cols;
+    if ((rc = dev_alloc(&d_mat, cells))) return cleanup(rc);
+    if ((rc = dev_alloc(&d_cnt, (size_t)n_rows))) return cleanup(rc);
+    if ((rc = dev_alloc(&d_ptr, (size_t)n_rows + 1))) return cleanup(rc);
+    if ((rc = dev_alloc(&d_st, 1))) return cleanup(rc);
+    const void *src = mat;
+    if (hipMemsetAsync(d_st, 0, sizeof(IngestStats), h->stream) != hipSuccess ||
+        hipMemcpyAsync(d_mat, src, sizeof(double) * cells,
+                       opt->input_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream) != hipSuccess)
+        return cleanup(fail(MISSLAP_ERR_HIP, "copy of the dense input failed"));
+    const int g4 = blocks_for(n_rows, 4);
+    hipLaunchKernelGGL(k_dense_count, dim3(g4), dim3(256), 0, h->stream, d_mat, (int)n_rows, (int)n_cols, d_cnt);
+    hipLaunchKernelGGL(k_dense_scan, dim3(1), dim3(1024), 0, h->stream, d_cnt, (int)n_rows, d_ptr, d_st);
+    int total = 0;
+    IngestStats st;
+    if (hipMemcpyAsync(&total, d_ptr + n_rows, sizeof(int), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        hipMemcpyAsync(&st, d_st, sizeof(st), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        hipStreamSynchronize(h->stream) != hipSuccess)
+        return cleanup(fail(MISSLAP_ERR_HIP, "dense ingest failed: %s", hipGetErrorString(hipGetLastError())));
+    if (nnz_out) *nnz_out = total;
+    if (total < n_rows)  // the caller raises the reference's ValueError (auction_.pyx:559-560)
+        return cleanup(fail(MISSLAP_ERR_INVALID, "Fewer than %lld valid values provided for %lld rows.",
+                            (long long)n_rows, (long long)n_rows));
+    if (st.err & kErrRowGap)
+        return cleanup(fail(MISSLAP_ERR_INVALID, "every row must have at least one valid (>= 0) entry"));
+    h->nnz = total;
+    if ((rc = dev_alloc(&d_loc, (size_t)total * 2))) return cleanup(rc);
+    if ((rc = dev_alloc(&d_val, (size_t)total))) return cleanup(rc);
+    hipLaunchKernelGGL(k_dense_fill, dim3(g4), dim3(256), 0, h->stream, d_mat, (int)n_rows, (int)n_cols, d_ptr,
+                       d_loc, d_val);
+    rc = build_from_device_coo(h, d_loc, d_val, (int)n_rows - 1, opt);
+    if (rc) return cleanup(rc);
+    cleanup(0);
+    h->setup_ms = now_ms() - t0;
+    *out = h;
+    return MISSLAP_OK;
+}
+
+MISSLAP_API int misslap_destroy(misslap_solver *h) {
+    free_all(h);
+    return MISSLAP_OK;
+}
+
+MISSLAP_API int misslap_dims(const misslap_solver *h, int64_t *n_rows, int64_t *n_cols, int64_t *nnz) {
+    if (!h) return fail(MISSLAP_ERR_INVALID, "null handle");
+    if (n_rows) *n_rows = h->n_rows;
+    if (n_cols) *n_cols = h->n_cols;
+    if (nnz) *nnz = h->nnz;
+    return MISSLAP_OK;
+}
+
+MISSLAP_API int misslap_set_stream(misslap_solver *h, void *hip_stream) {
+    if (!h) return fail(MISSLAP_ERR_INVALID, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->own_stream) (void)hipStreamDestroy(h->stream);
+    h->stream = (hipStream_t)hip_stream;
+    h->own_stream = false;
+    return MISSLAP_OK;
+}
+
+MISSLAP_API int misslap_exchange_buffers(misslap_solver *h, void **best_key, void **best_pos, int64_t *n_objects) {
+    if (!h) return fail(MISSLAP_ERR_INVALID, "null handle");
+    if (best_key) *best_key = h->best_key;
+    if (best_pos) *best_pos = h->best_pos;
+    if (n_objects) *n_objects = h->n_cols;
+    return MISSLAP_OK;
+}
+
+MISSLAP_API int misslap_round_bid(misslap_solver *h) {
+    if (!h) return fail(MISSLAP_ERR_INVALID, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    return launch_bid(h);
+}
+MISSLAP_API int misslap_round_tiebreak(misslap_solver *h) {
+    if (!h) return fail(MISSLAP_ERR_INVALID, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    return launch_tiebreak(h);
+}
+MISSLAP_API int misslap_round_apply(misslap_solver *h) {
+    if (!h) return fail(MISSLAP_ERR_INVALID, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    return launch_apply(h);
+}
+MISSLAP_API int misslap_run_tail(misslap_solver *h) {
+    if (!h) return fail(MISSLAP_ERR_INVALID, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    return launch_tail(h);
+}
+
+MISSLAP_API int misslap_get_status(misslap_solver *h, misslap_status *st) {
+    if (!h || !st) return fail(MISSLAP_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    int rc = read_ctl(h);
+    st->error_bits = h->h_ctl->err;
+    st->its = h->h_ctl->nits;
+    st->K = h->h_ctl->K;
+    st->nreductions = h->nreductions;
+    st->eps = h->eps;
+    st->target_eps = h->target_eps;
+    st->finished = h->finished ? 1 : 0;
+    return rc;
+}
+
+MISSLAP_API int misslap_check_ece(misslap_solver *h, float eps, int32_t *satisfied) {
+    if (!h || !satisfied) return fail(MISSLAP_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    int ok = 0;
+    int rc = run_ece(h, eps, &ok);
+    *satisfied = ok;
+    return rc;
+}
+
+// Loop control after the rounds of a phase, auction_.pyx:275-292.
+MISSLAP_API int misslap_phase_end(misslap_solver *h, int32_t *finished) {
+    if (!h) return fail(MISSLAP_ERR_INVALID, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    int rc = read_ctl(h);
+    if (rc) return rc;
+    const Ctl &c = *h->h_ctl;
+    if (c.nits >= h->max_iter) {  // terminate(), first clause (:308-309)
+        h->finished = true;
+    } else if (c.K == 0) {
+        int ok = 0;
+        if ((rc = run_ece(h, h->target_eps, &ok))) return rc;  // is_optimal() (:433-439)
+        if (ok) {
+            h->finished = true;
+        } else if (h->eps < h->target_eps) {  // :280
+            h->finished = true;
+        } else {
+            h->eps = h->eps * h->theta;  // :283 (fp32 product)
+            hipLaunchKernelGGL(k_reset_phase, dim3(blocks_for(h->n_rows > h->n_cols ? h->n_rows : h->n_cols, 256)),
+                               dim3(256), 0, h->stream, h->ctl, h->p2o, h->o2p, h->U, h->n_rows, h->n_cols);
+            HIP_TRY(hipGetLastError());
+            h->nreductions += 1;  // :292
+            h->K_ub = h->n_rows;
+            h->phase_fresh = true;
+        }
+    }
+    if (finished) *finished = h->finished ? 1 : 0;
+    return MISSLAP_OK;
+}
+
+MISSLAP_API int misslap_finish(misslap_solver *h, int32_t *person_to_object_out, misslap_meta *meta) {
+    if (!h) return fail(MISSLAP_ERR_INVALID, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    int rc;
+    int ece = 0;
+    if ((rc = run_ece(h, h->target_eps, &ece))) return rc;  // :297 / :300
+    // objective (:302, :489-523)
+    HIP_TRY(hipMemsetAsync(&h->ctl->dup_rows, 0, sizeof(int), h->stream));
+    const int grid = blocks_for(h->n_rows, 4);
+    if (h->f32) {
+        EdgesF32 ed{h->edges32};
+        hipLaunchKernelGGL(k_obj_rows<EdgesF32>, dim3(grid), dim3(256), 0, h->stream, h->ctl, ed, h->row_ptr, h->p2o,
+                           h->n_rows, h->maximize, h->contrib, h->nmatch);
+        hipLaunchKernelGGL(k_obj_sum<EdgesF32>, dim3(1), dim3(64), 0, h->stream, h->ctl, ed, h->row_ptr, h->p2o,
+                           h->n_rows, h->maximize, h->contrib, h->nmatch);
+    } else {
+        EdgesF64 ed{h->col, h->val64};
+        hipLaunchKernelGGL(k_obj_rows<EdgesF64>, dim3(grid), dim3(256), 0, h->stream, h->ctl, ed, h->row_ptr, h->p2o,
+                           h->n_rows, h->maximize, h->contrib, h->nmatch);
+        hipLaunchKernelGGL(k_obj_sum<EdgesF64>, dim3(1), dim3(64), 0, h->stream, h->ctl, ed, h->row_ptr, h->p2o,
+                           h->n_rows, h->maximize, h->contrib, h->nmatch);
+    }
+    HIP_TRY(hipGetLastError());
+    if (person_to_object_out)
+        HIP_TRY(hipMemcpyAsync(person_to_object_out, h->p2o, sizeof(int) * (size_t)h->n_rows, hipMemcpyDeviceToHost,
+                               h->stream));
+    if ((rc = read_ctl(h))) return rc;
+    if (!meta) return MISSLAP_OK;
+    const Ctl &c = *h->h_ctl;
+    std::memset(meta, 0, sizeof(*meta));
+    meta->start_eps = h->start_eps;
+    meta->final_eps = h->eps;
+    meta->target_eps = h->target_eps;
+    meta->eCE = ece;
+    meta->soln_found = (c.K == 0) ? ece : 0;
+    meta->nreductions = h->nreductions;
+    meta->its = c.nits;
+    meta->n_assigned = (int64_t)h->n_rows - c.K;
+    meta->n_rows = h->n_rows;
+    meta->n_cols = h->n_cols;
+    meta->nnz = h->nnz;
+    meta->obj_f64 = c.obj;
+    meta->obj_f32 = (float)c.obj;  // get_obj returns a C float (:489)
+    meta->setup_ms = h->setup_ms;
+    meta->solve_ms = h->solve_ms;
+    meta->edges_scanned = c.edges;
+    meta->bids_made = c.bids;
+    meta->grid_rounds = c.grid_rounds;
+    meta->tail_rounds = c.tail_rounds;
+    meta->tail_edges = c.tail_edges;
+    meta->bytes_per_edge = h->f32 ? 8 : 12;
+    meta->profiled = h->profile ? 1 : 0;
+    if (h->profile && h->prof_used) {
+        std::vector<unsigned long long> le((size_t)h->launch_idx);
+        if (h->launch_idx)
+            HIP_TRY(hipMemcpy(le.data(), h->launch_edges, sizeof(unsigned long long) * le.size(),
+                              hipMemcpyDeviceToHost));
+        for (size_t k = 0; k < h->prof_used; ++k) {
+            const ProfRec &r = h->prof[k];
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, r.start, r.stop) != hipSuccess) continue;
+            if (r.kind == 0) {
+                const unsigned long long e = le[(size_t)r.launch_idx];
+                if (e == 0) continue;  // self-skipped launch
+                meta->bid_launches += 1;
+                meta->bid_ms += ms;
+                meta->bid_edges += e;
+                if (r.fullscan) {
+                    meta->fullscan_launches += 1;
+                    meta->fullscan_ms += ms;
+                    meta->fullscan_edges += e;
+                }
+            } else {
+                meta->tail_launches += 1;
+                meta->tail_ms += ms;
+            }
+        }
+    }
+    return MISSLAP_OK;
+}
+
+// AuctionSolver.solve(), auction_.pyx:268-306.
+MISSLAP_API int misslap_solve(misslap_solver *h, int32_t *person_to_object_out, misslap_meta *meta) {
+    if (!h) return fail(MISSLAP_ERR_INVALID, "null handle");
+    if (h->world != 1) return fail(MISSLAP_ERR_STATE, "misslap_solve drives one GPU; sharded handles use the round API");
+    HIP_TRY(hipSetDevice(h->device));
+    const double t0 = now_ms();
+    int rc;
+    while (!h->finished) {
+        for (;;) {  // rounds of the current eps-phase
+            if ((rc = read_ctl(h))) return rc;
+            const Ctl &c = *h->h_ctl;
+            if (c.K == 0 || c.nits >= h->max_iter) break;
+            if (c.K > h->thr) {
+                for (int r = 0; r < h->rounds_per_sync; ++r) {
+                    if ((rc = launch_bid(h))) return rc;
+                    if ((rc = launch_tiebreak(h))) return rc;
+                    if ((rc = launch_apply(h))) return rc;
+                }
+            } else {
+                if ((rc = launch_tail(h))) return rc;
+            }
+        }
+        int fin = 0;
+        if ((rc = misslap_phase_end(h, &fin))) return rc;
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->solve_ms += now_ms() - t0;
+    return misslap_finish(h, person_to_object_out, meta);
+}
+
+MISSLAP_API int misslap_get_state(misslap_solver *h, double *prices, int32_t *unassigned, int32_t *person_to_object,
+                                  int32_t *object_to_person) {
+    if (!h) return fail(MISSLAP_ERR_INVALID, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (prices) HIP_TRY(hipMemcpy(prices, h->price, sizeof(double) * (size_t)h->n_cols, hipMemcpyDeviceToHost));
+    if (unassigned) HIP_TRY(hipMemcpy(unassigned, h->U, sizeof(int) * (size_t)h->n_rows, hipMemcpyDeviceToHost));
+    if (person_to_object)
+        HIP_TRY(hipMemcpy(person_to_object, h->p2o, sizeof(int) * (size_t)h->n_rows, hipMemcpyDeviceToHost));
+    if (object_to_person)
+        HIP_TRY(hipMemcpy(object_to_person, h->o2p, sizeof(int) * (size_t)h->n_cols, hipMemcpyDeviceToHost));
+    return MISSLAP_OK;
+}

@@ -1,0 +1,153 @@
+"""Golden-vector case definitions, shared by make_golden.py (which runs the real
+reference in the build container) and by the tests (which replay the same inputs
+through the oracle / the HIP path).  Inputs are either regenerated from
+sslap_amd.synth (counter-based, machine independent) or, for the reference's
+own np.random-seeded demo inputs, stored in the fixture itself.
+"""
+import numpy as np
+
+from sslap_amd import synth
+
+
+def _shuffle_within_rows(loc, val, seed):
+    """Permute the stored order of entries inside every row (rows stay sorted)."""
+    n = loc.shape[0]
+    key = synth._stream(seed, 77, n)
+    order = np.lexsort((key, loc[:, 0]))
+    return np.ascontiguousarray(loc[order]), np.ascontiguousarray(val[order])
+
+
+def _single_entry_rows(n, density, seed, n_single):
+    """Square instance whose first n_single rows keep ONLY their guaranteed-matching edge
+    (one-entry rows: w = -inf, +inf bids, inf prices -- auction_.pyx:344,:360)."""
+    loc, val = synth.gen_sparse(n, n, density, seed=seed)
+    keys = synth._stream(seed, 1, n)
+    perm = np.argsort(keys, kind="stable")[:n]
+    keep = (loc[:, 0] >= n_single) | (loc[:, 1] == perm[loc[:, 0]])
+    return np.ascontiguousarray(loc[keep]), np.ascontiguousarray(val[keep])
+
+
+def _with_duplicates(n, density, seed, integer_values):
+    """Instance where some (i, j) entries appear twice with different values."""
+    loc, val = synth.gen_sparse(n, n, density, seed=seed, integer_values=integer_values)
+    pick = np.nonzero(synth._stream(seed, 78, loc.shape[0]) % np.uint64(7) == 0)[0]
+    loc2 = np.concatenate([loc, loc[pick]], axis=0)
+    val2 = np.concatenate([val, val[pick] + 1.0], axis=0)
+    order = np.argsort(loc2[:, 0], kind="stable")
+    return np.ascontiguousarray(loc2[order]), np.ascontiguousarray(val2[order])
+
+
+def _full_double(n, density, seed):
+    """Values with 53 random mantissa bits (NOT fp32-representable): the 12 B/edge kernel path."""
+    loc, _ = synth.gen_sparse(n, n, density, seed=seed)
+    h = synth._stream(seed, 9, loc.shape[0])
+    val = (h >> np.uint64(11)).astype(np.float64) * (100.0 / float(1 << 53))
+    return loc, val
+
+
+def synth_inputs(spec):
+    """spec: dict(kind=..., ...) -> (loc, val)."""
+    kind = spec["kind"]
+    if kind == "sparse":
+        loc, val = synth.gen_sparse(spec["n"], spec["m"], spec["density"], seed=spec.get("seed", 1),
+                                    integer_values=spec.get("ints", 0))
+    elif kind == "shuffled":
+        loc, val = synth.gen_sparse(spec["n"], spec["m"], spec["density"], seed=spec.get("seed", 1),
+                                    integer_values=spec.get("ints", 0))
+        loc, val = _shuffle_within_rows(loc, val, spec.get("seed", 1))
+    elif kind == "single":
+        loc, val = _single_entry_rows(spec["n"], spec["density"], spec.get("seed", 1), spec["n_single"])
+    elif kind == "dups":
+        loc, val = _with_duplicates(spec["n"], spec["density"], spec.get("seed", 1), spec["ints"])
+    elif kind == "f64":
+        loc, val = _full_double(spec["n"], spec["density"], spec.get("seed", 1))
+    elif kind == "config":
+        loc, val = synth.gen_config(spec["name"], seed=spec.get("seed", 1))
+    else:
+        raise KeyError(kind)
+    return loc, val
+
+
+def _sq(n, d, **kw):
+    return dict(kind="sparse", n=n, m=n, density=d, **kw)
+
+
+# name -> (input spec, auction_solve kwargs, entry point)
+# entry: "locval" (loc=, val=), "locval_size" (… size=(n,m)), "mat" (dense, -1 = invalid), "coo"
+SMALL_CASES = {}
+for _n in (64, 257, 1000):
+    for _prob in ("max", "min"):
+        SMALL_CASES[f"sq{_n}_{_prob}"] = (_sq(_n, 0.05), dict(problem=_prob), "locval")
+SMALL_CASES.update({
+    "sq300_fast_sizeNone": (_sq(300, 0.05), dict(problem="max", fast=True), "locval"),
+    "sq300_fast_size": (_sq(300, 0.05), dict(problem="max", fast=True), "locval_size"),
+    "sq300_fast_mat": (_sq(300, 0.05), dict(problem="max", fast=True), "mat"),
+    "sq300_mat_min": (_sq(300, 0.05), dict(problem="min"), "mat"),
+    "sq300_coo_max": (_sq(300, 0.05), dict(problem="max"), "coo"),
+    "sq300_eps1": (_sq(300, 0.05), dict(problem="max", eps_start=1.0), "locval"),
+    "sq300_eps_tiny": (_sq(300, 0.05), dict(problem="min", eps_start=1e-4), "locval"),
+    "sq300_maxiter10": (_sq(300, 0.05), dict(problem="max", max_iter=10), "locval"),
+    "sq300_maxiter1": (_sq(300, 0.05), dict(problem="max", max_iter=1), "locval"),
+    "sq300_maxiter0": (_sq(300, 0.05), dict(problem="max", max_iter=0), "locval"),
+    "sq200_int3": (_sq(200, 0.05, ints=3), dict(problem="max"), "locval"),
+    "sq200_int10": (_sq(200, 0.05, ints=10), dict(problem="max"), "locval"),
+    "sq200_int100_min": (_sq(200, 0.05, ints=100), dict(problem="min"), "locval"),
+    "sq500_int5_dense": (_sq(500, 0.2, ints=5), dict(problem="max"), "locval"),
+    "sq200_shuffled_int4": (dict(kind="shuffled", n=200, m=200, density=0.08, ints=4), dict(problem="max"), "locval"),
+    "sq400_shuffled": (dict(kind="shuffled", n=400, m=400, density=0.05), dict(problem="min"), "locval"),
+    "sq200_single10": (dict(kind="single", n=200, density=0.05, n_single=10), dict(problem="max"), "locval"),
+    "sq200_single10_min": (dict(kind="single", n=200, density=0.05, n_single=10), dict(problem="min"), "locval"),
+    "sq150_dups_int6": (dict(kind="dups", n=150, density=0.06, ints=6), dict(problem="max"), "locval"),
+    "sq300_f64": (dict(kind="f64", n=300, density=0.05), dict(problem="max"), "locval"),
+    "sq300_f64_min": (dict(kind="f64", n=300, density=0.05), dict(problem="min"), "locval"),
+    "rect100x150_max": (dict(kind="sparse", n=100, m=150, density=0.1), dict(problem="max"), "locval"),
+    "rect100x150_min": (dict(kind="sparse", n=100, m=150, density=0.1), dict(problem="min"), "locval_size"),
+    "rect1000x1500_max": (dict(kind="sparse", n=1000, m=1500, density=0.02), dict(problem="max"), "locval"),
+    "rect1000x1500_min": (dict(kind="sparse", n=1000, m=1500, density=0.02), dict(problem="min"), "locval"),
+    "sq2000_max": (_sq(2000, 0.01), dict(problem="max"), "locval"),
+    "sq3000_int20": (_sq(3000, 0.01, ints=20), dict(problem="max"), "locval"),
+})
+
+# per-round trace: person_to_object after r = 1..TRACE_ROUNDS rounds (max_iter = r)
+TRACE_CASES = {
+    "trace_sq300": (_sq(300, 0.05), dict(problem="max")),
+    "trace_sq200_int4": (_sq(200, 0.08, ints=4), dict(problem="max")),
+    "trace_rect100x150": (dict(kind="sparse", n=100, m=150, density=0.1), dict(problem="min")),
+}
+TRACE_ROUNDS = 80
+
+# hash-only cases: the BASELINE.json configs (max_iter = 1e8)
+LARGE_CASES = {
+    "C1": (dict(kind="config", name="C1"), dict(problem="max", max_iter=10**8)),
+    "C1_min": (dict(kind="config", name="C1"), dict(problem="min", max_iter=10**8)),
+    "C2": (dict(kind="config", name="C2"), dict(problem="max", max_iter=10**8)),
+    "C3": (dict(kind="config", name="C3"), dict(problem="max", max_iter=10**8)),
+    "C4": (dict(kind="config", name="C4"), dict(problem="max", max_iter=10**8)),
+    "C5": (dict(kind="config", name="C5"), dict(problem="max", max_iter=10**8)),
+}
+
+
+def dense_from(loc, val, n, m):
+    """Dense matrix for the `mat=` entry: -1 marks an invalid cell (auction_.pyx:549)."""
+    mat = np.full((n, m), -1.0, dtype=np.float64)
+    mat[loc[:, 0], loc[:, 1]] = val
+    return mat
+
+
+def call_kwargs(entry, loc, val, spec):
+    """Build the keyword arguments of auction_solve for an entry point."""
+    n = spec.get("n") or synth.CONFIGS[spec["name"]]["n_rows"]
+    m = spec.get("m", n) if "n" in spec else synth.CONFIGS[spec["name"]]["n_cols"]
+    if entry == "locval":
+        return dict(loc=loc, val=val)
+    if entry == "locval_size":
+        return dict(loc=loc, val=val, size=(n, m))
+    if entry == "mat":
+        return dict(mat=dense_from(loc, val, n, m))
+    if entry == "coo":
+        from scipy.sparse import coo_matrix
+        return dict(coo_mat=coo_matrix((val, (loc[:, 0], loc[:, 1])), shape=(n, m)))
+    raise KeyError(entry)
+
+
+META_KEYS = ("start_eps", "eCE", "its", "nreductions", "soln_found", "n_assigned", "obj", "final_eps")

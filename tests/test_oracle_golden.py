@@ -1,0 +1,100 @@
+"""CPU suite, part 1: the C oracle (oracle/) against the committed golden vectors that were captured
+from the real reference (tests/golden/make_golden.py), and the input generator against its digests."""
+import numpy as np
+import pytest
+
+import cases
+from oracle import oracle as orc
+from sslap_amd import synth
+
+
+def _run_oracle(spec, kw, entry):
+    loc, val = cases.synth_inputs(spec)
+    call = cases.call_kwargs(entry, loc, val.copy(), spec)  # 'min' negates the passed val in place
+    return orc.auction_solve(cardinality_check=False, **call, **kw), loc, val, call
+
+
+@pytest.mark.parametrize("name", sorted(cases.SMALL_CASES))
+def test_oracle_matches_reference_small(name, golden_small):
+    manifest, arrays = golden_small
+    spec, kw, entry = cases.SMALL_CASES[name]
+    res, loc, val, call = _run_oracle(spec, kw, entry)
+    g = manifest["cases"][name]
+    assert synth.input_digest(loc, val) == g["input_sha256"], "generator drifted"
+    assert np.array_equal(res["sol"], arrays[name + "/sol"])
+    for k in cases.META_KEYS:
+        assert res["meta"][k] == g["meta"][k], k
+    if "val" in call:  # in-place negation quirk (auction_.pyx:236-237)
+        assert (not np.array_equal(call["val"], val)) == g["val_mutated"]
+
+
+def test_oracle_matches_reference_demo(golden_demo):
+    from scipy.sparse import coo_matrix
+    manifest, arrays = golden_demo
+    for name, g in manifest["cases"].items():
+        mat = arrays[name + "/mat"]
+        prob = "min" if name.endswith("_min") else "max"
+        if name == "demo_coo_max":
+            res = orc.auction_solve(coo_mat=coo_matrix(mat), problem=prob, cardinality_check=False)
+        else:
+            res = orc.auction_solve(mat=mat.copy(), problem=prob, cardinality_check=False)
+        assert np.array_equal(res["sol"], arrays[name + "/sol"]), name
+        for k in cases.META_KEYS:
+            assert res["meta"][k] == g["meta"][k], (name, k)
+
+
+def test_known_answers_of_reference_examples(golden_demo):
+    """The reference's only written-down answers."""
+    manifest, arrays = golden_demo
+    assert arrays["demo_dense_min/sol"].tolist() == [0, 1, 4, 3, 2]
+    assert arrays["demo_sparse_max/sol"].tolist() == [0, 3, 4, 2, 1]
+    assert arrays["demo_coo_max/sol"].tolist() == [0, 3, 4, 2, 1]
+    m = manifest["cases"]["demo_dense_min"]["meta"]
+    assert (m["its"], m["nreductions"], m["start_eps"], m["final_eps"], m["obj"]) == (10, 2, 4.841, 0.109, 10.845)
+
+
+@pytest.mark.parametrize("name", sorted(cases.TRACE_CASES))
+def test_oracle_round_trace(name, golden_trace):
+    """person_to_object after r = 1..R rounds equals the reference run with max_iter = r."""
+    manifest, arrays = golden_trace
+    spec, kw = cases.TRACE_CASES[name]
+    loc, val = cases.synth_inputs(spec)
+    assert synth.input_digest(loc, val) == manifest["cases"][name]["input_sha256"]
+    want = arrays[name + "/p2o"]
+    its = manifest["cases"][name]["its"]
+    for r in range(1, manifest["rounds"] + 1):
+        # a fresh solve capped at r rounds, exactly how the fixture was made (stepping one solver would
+        # show the eps-phase reset of auction_.pyx:286-290, which a capped solve breaks out before)
+        res = orc.auction_solve(loc=loc, val=val.copy(), cardinality_check=False, max_iter=r, **kw)
+        assert res["meta"]["its"] == its[r - 1]
+        assert np.array_equal(res["sol"], want[r - 1]), f"round {r}"
+
+
+@pytest.mark.parametrize("name", ["C1", "C1_min", "C4", "C2"])
+def test_oracle_matches_reference_large(name, golden_large):
+    g = golden_large["cases"].get(name)
+    if g is None:
+        pytest.skip(f"{name} fixture not generated")
+    spec, kw = cases.LARGE_CASES[name]
+    loc, val = cases.synth_inputs(spec)
+    assert synth.input_digest(loc, val) == g["input_sha256"]
+    assert loc.shape[0] == g["nnz"]
+    res = orc.auction_solve(loc=loc, val=val, cardinality_check=False, **kw)
+    assert synth.sol_digest(res["sol"]) == g["sol_sha256"]
+    for k in cases.META_KEYS:
+        assert res["meta"][k] == g["meta"][k], k
+    assert res["extra"]["obj_f64"] == g["obj_f64"]
+    assert res["extra"]["edges_scanned"] == g["edges_scanned"]
+
+
+def test_oracle_solution_properties():
+    """Domain properties on a fresh instance (no fixture): valid assignment, eps-CS, scipy-optimal cost."""
+    from scipy.optimize import linear_sum_assignment
+    loc, val = synth.gen_sparse(400, 400, 0.05, seed=11)
+    res = orc.auction_solve(loc=loc, val=val.copy(), problem="max", cardinality_check=False)
+    sol = res["sol"]
+    assert sorted(sol.tolist()) == list(range(400))
+    dense = np.full((400, 400), -1e9)
+    dense[loc[:, 0], loc[:, 1]] = val
+    r, c = linear_sum_assignment(dense, maximize=True)
+    assert abs(dense[r, c].sum() - res["extra"]["obj_f64"]) <= 1e-6 * abs(dense[r, c].sum())
