@@ -74,7 +74,7 @@ typedef struct misslap_meta {
     int32_t bytes_per_edge;      /* 8 (int32 col + fp32 val) or 12 (int32 col + fp64 val) */
     int32_t profiled;
     /* valid when options.profile != 0 (HIP-event timings, ms) */
-    int64_t bid_launches;        /* grid bid-kernel launches that did work */
+    int64_t bid_launches;        /* grid bid-kernel launches (no-op launches past the end of a phase included) */
     double bid_ms;               /* their summed duration */
     uint64_t bid_edges;          /* edges they scanned */
     int64_t fullscan_launches;   /* of which K == n_rows (every row scanned) */

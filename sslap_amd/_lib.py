@@ -78,6 +78,14 @@ def load():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -m sslap_amd.build` "
                 "(hipcc --offload-arch=gfx950).  sslap_amd has no CPU fallback.")
+        try:
+            # One HIP runtime per process: the PyTorch-ROCm wheel bundles its own libamdhip64.so.7 /
+            # libhsa-runtime64 and a second copy (the system one libmisslap would otherwise pull in)
+            # cannot open the GPU again.  Importing torch first makes the dynamic linker resolve
+            # libmisslap's libamdhip64.so.7 dependency to the copy torch already loaded.
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             f = getattr(lib, name)

@@ -697,8 +697,7 @@ MISSLAP_API int misslap_finish(misslap_solver *h, int32_t *person_to_object_out,
             if (hipEventElapsedTime(&ms, r.start, r.stop) != hipSuccess) continue;
             if (r.kind == 0) {
                 const unsigned long long e = le[(size_t)r.launch_idx];
-                if (e == 0) continue;  // self-skipped launch
-                meta->bid_launches += 1;
+                meta->bid_launches += 1;  // self-skipped (no-op) launches included, like a kernel trace
                 meta->bid_ms += ms;
                 meta->bid_edges += e;
                 if (r.fullscan) {

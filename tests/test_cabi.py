@@ -1,0 +1,98 @@
+"""CPU suite, part 2: the C-ABI library loads and exports every symbol include/misslap.h declares,
+the ctypes structs match the header, and the front-end's host logic (argument validation, error texts)
+behaves like the reference's -- without any compute call (no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from sslap_amd import _lib, auction_solve, from_sparse
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header():
+    return open(os.path.join(ROOT, "include", "misslap.h")).read()
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    declared = set(re.findall(r"\b(misslap_[a-z_0-9]+)\s*\(", _header()))
+    assert declared, "no prototypes found"
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.misslap_abi_version() == int(re.search(r"MISSLAP_ABI_VERSION (\d+)", _header()).group(1))
+
+
+def test_struct_layouts_match_header():
+    """Compile a tiny C program against the header and compare sizeof / offsetof with ctypes."""
+    import subprocess
+    import tempfile
+    fields = {"misslap_options": ["max_iter", "tail_threshold", "rounds_per_sync"],
+              "misslap_meta": ["its", "obj_f64", "edges_scanned", "bid_ms", "tail_edges"],
+              "misslap_status": ["K", "error_bits"]}
+    prog = ['#include <stdio.h>', '#include <stddef.h>', '#include "misslap.h"', 'int main(void){']
+    for s, fs in fields.items():
+        prog.append(f'printf("{s} %zu\\n", sizeof({s}));')
+        for f in fs:
+            prog.append(f'printf("{s}.{f} %zu\\n", offsetof({s}, {f}));')
+    prog.append("return 0;}")
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "t.c")
+        open(src, "w").write("\n".join(prog))
+        exe = os.path.join(d, "t")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
+        out = dict(l.split() for l in subprocess.check_output([exe], text=True).splitlines())
+    types = {"misslap_options": _lib.Options, "misslap_meta": _lib.Meta, "misslap_status": _lib.Status}
+    for s, t in types.items():
+        assert int(out[s]) == C.sizeof(t), s
+        for f in fields[s]:
+            assert int(out[f"{s}.{f}"]) == getattr(t, f).offset, (s, f)
+
+
+def test_no_cpu_fallback_without_gpu():
+    """On a box without a GPU every solver call must raise, never compute on the host."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    loc = np.array([[0, 0], [1, 1]], dtype=np.int32)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        auction_solve(loc=loc, val=np.array([1.0, 2.0]), cardinality_check=False)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        auction_solve(mat=np.ones((2, 2)))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "sslap_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.replace("# oracle-free", ""), f"{f} mentions the oracle"
+
+
+def test_frontend_validation_before_ffi():
+    loc = np.array([[0, 0], [0, 1], [1, 0], [1, 1]], dtype=np.int64)
+    with pytest.raises(ValueError, match="One of the following formats is expected"):
+        auction_solve()
+    with pytest.raises(ValueError, match="Buffer dtype mismatch, expected 'DTYPE_t' but got 'float'"):
+        auction_solve(loc=loc, val=np.ones(4, dtype=np.float32), cardinality_check=False)
+    with pytest.raises(ValueError, match="expected 'double' but got 'float'"):
+        auction_solve(mat=np.ones((2, 2), dtype=np.float32))
+    with pytest.raises(ValueError, match="expected 'double' but got 'long'"):
+        auction_solve(mat=np.ones((2, 2), dtype=np.int64))
+    with pytest.raises(ValueError, match="wrong number of dimensions"):
+        auction_solve(loc=loc, val=np.ones((4, 1)), cardinality_check=False)
+    # "fewer than N entries" guard with the adapter's own N (auction_.pyx:592-595, :604)
+    few = np.array([[0, 0], [5, 1]], dtype=np.int64)
+    with pytest.raises(ValueError, match="Fewer than 5 valid values provided for 5 rows"):
+        from_sparse(few, np.ones(2), cardinality_check=False)
+    with pytest.raises(ValueError, match="Fewer than 9 valid values provided for 9 rows"):
+        from_sparse(few, np.ones(2), size=(6, 9), cardinality_check=False)  # `M, N = size` (sic)
+    # infeasible graph caught by the (host) cardinality guard before any GPU work
+    inf_loc = np.array([[0, 0], [1, 0]], dtype=np.int64)
+    with pytest.raises(ValueError, match="Maximum matching possible only involves 1 out of 2 rows"):
+        auction_solve(loc=inf_loc, val=np.ones(2), size=(2, 2))
