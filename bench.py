@@ -111,7 +111,9 @@ def main():
         from sslap_amd import dist as mdist
         s = AuctionSolver.from_device_pointers(d_loc.data_ptr(), d_val.data_ptr(), nnz, problem="max",
                                                max_iter=10**8, shard=(rank, world), **gpu_opts)
+        t_s = time.perf_counter()
         sol = mdist.solve_sharded(s)
+        s.gpu["solve_ms"] = 1e3 * (time.perf_counter() - t_s)
         return s, sol
 
     for _ in range(args.warmup):
@@ -128,9 +130,12 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        e = torch.tensor([sum(g["edges_scanned"] for _, g in runs)], dtype=torch.int64, device="cuda")
-        dist.all_reduce(e, op=dist.ReduceOp.SUM)  # every rank counts the bids of its own shard + the tail
-        edges_all = int(e.item())
+        # a rank counts the bids of its own shard in exchanged rounds plus the (replicated) tail rounds:
+        # unique work = sum over ranks of the sharded part + the tail once
+        tail_e = sum(g["tail_edges"] for _, g in runs)
+        e = torch.tensor([sum(g["edges_scanned"] for _, g in runs) - tail_e], dtype=torch.int64, device="cuda")
+        dist.all_reduce(e, op=dist.ReduceOp.SUM)
+        edges_all = int(e.item()) + tail_e
     else:
         edges_all = sum(g["edges_scanned"] for _, g in runs)
 

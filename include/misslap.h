@@ -95,6 +95,8 @@ typedef struct misslap_status {
     float target_eps;
     int32_t finished;     /* solve loop has broken out (auction_.pyx:275-281) */
     int32_t error_bits;   /* device-side invariant violations (0 = none) */
+    int32_t tail_threshold;   /* effective value (library default resolved) */
+    int32_t rounds_per_sync;  /* effective value */
 } misslap_status;
 
 /* ---- construction: replaces AuctionSolver.__init__ (auction_.pyx:202-265) as reached through

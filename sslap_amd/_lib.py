@@ -39,6 +39,7 @@ class Status(C.Structure):
     _fields_ = [
         ("its", C.c_int64), ("K", C.c_int32), ("nreductions", C.c_int32), ("eps", C.c_float),
         ("target_eps", C.c_float), ("finished", C.c_int32), ("error_bits", C.c_int32),
+        ("tail_threshold", C.c_int32), ("rounds_per_sync", C.c_int32),
     ]
 
 

@@ -123,6 +123,7 @@ class AuctionSolver:
         _lib.check(lib.misslap_dims(self._h, C.byref(n), C.byref(m), C.byref(z)))
         self.num_rows, self.num_cols, self.nnz = n.value, m.value, z.value
         st = self.status()
+        self.tail_threshold, self.rounds_per_sync = int(st.tail_threshold), int(st.rounds_per_sync)
         self.meta = {"start_eps": round(float(st.eps), 3)}  # auction_.pyx:264
         self.gpu = {}
 

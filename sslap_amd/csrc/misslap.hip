@@ -592,6 +592,8 @@ MISSLAP_API int misslap_get_status(misslap_solver *h, misslap_status *st) {
     st->eps = h->eps;
     st->target_eps = h->target_eps;
     st->finished = h->finished ? 1 : 0;
+    st->tail_threshold = h->thr;
+    st->rounds_per_sync = h->rounds_per_sync;
     return rc;
 }
 
