@@ -43,11 +43,13 @@ typedef struct misslap_options {
     int32_t tail_threshold;  /* rounds with K <= this run in the persistent one-workgroup kernel;
                                 < 0 = library default; 0 = grid kernels only; max 1024 */
     int32_t force_f64_values;/* keep 12 B/edge (int32 col + fp64 val) even when values are fp32-exact */
-    int32_t profile;         /* record HIP events around every bid-kernel / tail-kernel launch */
+    int32_t profile;         /* 1: record HIP events around every bid-kernel / tail-kernel launch;
+                                2: additionally run the stamped (diagnostic) tail kernel */
     int32_t shard_rank;      /* multi-GPU: this process bids for U positions of its shard only */
     int32_t shard_world;     /* number of shards (1 = single GPU) */
     int32_t rounds_per_sync; /* grid rounds enqueued between host status reads; <= 0 = default */
-    int32_t reserved[8];
+    int32_t reserved[8];     /* [0]: LDS-tiled bid kernel: 0 = default threshold, < 0 = never, > 0 = minimum K;
+                                [1]: its launch shape (tuning knob, 0..5; see misslap.hip:kShapes) */
 } misslap_options;
 
 /* Result block of misslap_finish: the reference's `meta` dict (auction_.pyx:264,:297-304)
@@ -83,7 +85,12 @@ typedef struct misslap_meta {
     int64_t tail_launches;
     double tail_ms;
     uint64_t tail_edges;
-    double reserved_d[4];
+    int64_t tiled_launches;      /* launches of the LDS-tiled bid kernel (k_bid_tiled), no-ops included */
+    double tiled_ms;
+    uint64_t tiled_edges;
+    int32_t tiled_active;        /* the tile-major edge copy exists and big rounds use k_bid_tiled */
+    int32_t tiled_min_K;         /* rounds with K >= this use it */
+    double reserved_d[12];       /* diagnostic cycle counters of the stamped tail build */
 } misslap_meta;
 
 /* Snapshot of the round state (tests / multi-GPU driver). */
@@ -166,6 +173,10 @@ int misslap_get_state(misslap_solver *h, double *prices, int32_t *unassigned, in
 /* Device properties of the GPU the handle runs on (name buffer >= 128 bytes). */
 int misslap_device_info(int32_t device, char *name, int32_t name_len, int32_t *compute_units,
                         int64_t *hbm_bytes);
+
+/* Diagnostics only: average duration (ms) of `reps` launches of an ablated full-scan bid kernel
+ * (mode 0 complete, 1 no price gather, 2 no cross-lane reduction, 3 edge stream only); results discarded. */
+int misslap_debug_time_bid(misslap_solver *h, int32_t mode, int32_t reps, float *ms_avg);
 
 const char *misslap_last_error(void);
 int misslap_abi_version(void);

@@ -48,6 +48,10 @@ typedef struct oracle_solver {
     uint64_t edges_scanned, bids_made;
     double t_bid, t_total;
     int time_phases;
+    /* optional trace of the bidders of small rounds (analysis tooling, tools/tail_reuse.py) */
+    int32_t *trace_buf;
+    int64_t trace_cap, trace_len;
+    int trace_thr;
 } oracle_solver;
 
 static double now_s(void) {
@@ -173,6 +177,10 @@ static void bid_and_assign(oracle_solver *s) {
     int *person_to_object = s->person_to_object, *object_to_person = s->object_to_person;
     const double eps = (double)s->eps; /* float promoted in ':360' */
 
+    if (s->trace_buf && (int)num_bidders <= s->trace_thr && s->trace_len + (int64_t)num_bidders + 1 <= s->trace_cap) {
+        for (size_t n = 0; n < num_bidders; ++n) s->trace_buf[s->trace_len++] = unassigned_people[n];
+        s->trace_buf[s->trace_len++] = -1; /* round separator */
+    }
     double t0 = s->time_phases ? now_s() : 0.0;
     /* BIDDING PHASE :339-365 */
     for (size_t nbidder = 0; nbidder < num_bidders; ++nbidder) {
@@ -369,6 +377,13 @@ ORACLE_API void oracle_get_meta(const oracle_solver *s, oracle_meta *m) {
 }
 
 ORACLE_API void oracle_set_timing(oracle_solver *s, int on) { s->time_phases = on; }
+ORACLE_API void oracle_set_trace(oracle_solver *s, int32_t *buf, int64_t cap, int thr) {
+    s->trace_buf = buf;
+    s->trace_cap = cap;
+    s->trace_len = 0;
+    s->trace_thr = thr;
+}
+ORACLE_API int64_t oracle_trace_len(const oracle_solver *s) { return s->trace_len; }
 ORACLE_API const int *oracle_person_to_object(const oracle_solver *s) { return s->person_to_object; }
 ORACLE_API const int *oracle_object_to_person(const oracle_solver *s) { return s->object_to_person; }
 ORACLE_API const double *oracle_prices(const oracle_solver *s) { return s->p; }

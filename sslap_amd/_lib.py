@@ -31,7 +31,9 @@ class Meta(C.Structure):
         ("bid_launches", C.c_int64), ("bid_ms", C.c_double), ("bid_edges", C.c_uint64),
         ("fullscan_launches", C.c_int64), ("fullscan_ms", C.c_double), ("fullscan_edges", C.c_uint64),
         ("tail_launches", C.c_int64), ("tail_ms", C.c_double), ("tail_edges", C.c_uint64),
-        ("reserved_d", C.c_double * 4),
+        ("tiled_launches", C.c_int64), ("tiled_ms", C.c_double), ("tiled_edges", C.c_uint64),
+        ("tiled_active", C.c_int32), ("tiled_min_K", C.c_int32),
+        ("reserved_d", C.c_double * 12),
     ]
 
 
@@ -64,6 +66,7 @@ SYMBOLS = {
     "misslap_set_stream": (C.c_int, [_VP, _VP]),
     "misslap_get_state": (C.c_int, [_VP, _VP, _VP, _VP, _VP]),
     "misslap_device_info": (C.c_int, [C.c_int32, C.c_char_p, C.c_int32, _I32P, C.POINTER(C.c_int64)]),
+    "misslap_debug_time_bid": (C.c_int, [_VP, C.c_int32, C.c_int32, C.POINTER(C.c_float)]),
     "misslap_last_error": (C.c_char_p, []),
     "misslap_abi_version": (C.c_int, []),
 }

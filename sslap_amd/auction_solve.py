@@ -22,10 +22,11 @@ _ENV_DEVICE = "MISSLAP_DEVICE"
 _ENV_TAIL = "MISSLAP_TAIL_THRESHOLD"
 _ENV_PROFILE = "MISSLAP_PROFILE"
 _ENV_RPS = "MISSLAP_ROUNDS_PER_SYNC"
+_ENV_TILED = "MISSLAP_TILED_MIN_K"  # 0 default, < 0 never use the LDS-tiled bid kernel, > 0 minimum K
 
 
 def _options(problem, eps_start, max_iter, device=None, tail_threshold=None, profile=None, force_f64=False,
-             input_on_device=False, shard=None, rounds_per_sync=None):
+             input_on_device=False, shard=None, rounds_per_sync=None, tiled_min_k=None, tiled_shape=None):
     if problem not in ("min", "max"):
         # the reference treats every string other than 'min' as 'max' (auction_.pyx:236, :502)
         problem = "max" if problem != "min" else "min"
@@ -38,10 +39,12 @@ def _options(problem, eps_start, max_iter, device=None, tail_threshold=None, pro
     o.input_on_device = 1 if input_on_device else 0
     o.tail_threshold = int(os.environ.get(_ENV_TAIL, -1)) if tail_threshold is None else int(tail_threshold)
     o.force_f64_values = 1 if force_f64 else 0
-    o.profile = int(os.environ.get(_ENV_PROFILE, 0)) if profile is None else int(bool(profile))
+    o.profile = int(os.environ.get(_ENV_PROFILE, 0)) if profile is None else int(profile)
     o.rounds_per_sync = int(os.environ.get(_ENV_RPS, 0)) if rounds_per_sync is None else int(rounds_per_sync)
     if shard is not None:
         o.shard_rank, o.shard_world = int(shard[0]), int(shard[1])
+    o.reserved[0] = int(os.environ.get(_ENV_TILED, 0)) if tiled_min_k is None else int(tiled_min_k)
+    o.reserved[1] = int(os.environ.get("MISSLAP_TILED_SHAPE", 0)) if tiled_shape is None else int(tiled_shape)
     return o
 
 
@@ -159,12 +162,15 @@ class AuctionSolver:
         g = dict(obj_f64=float(m.obj_f64), edges_scanned=int(m.edges_scanned), bids_made=int(m.bids_made),
                  grid_rounds=int(m.grid_rounds), tail_rounds=int(m.tail_rounds), bytes_per_edge=int(m.bytes_per_edge),
                  setup_ms=float(m.setup_ms), solve_ms=float(m.solve_ms), final_eps_f32=float(m.final_eps),
-                 start_eps_f32=float(m.start_eps), tail_edges=int(m.tail_edges))
+                 start_eps_f32=float(m.start_eps), tail_edges=int(m.tail_edges),
+                 tiled_active=int(m.tiled_active), tiled_min_K=int(m.tiled_min_K))
         if m.profiled:
+            g["tail_stamp_cycles"] = [float(x) for x in m.reserved_d]
             g.update(bid_launches=int(m.bid_launches), bid_ms=float(m.bid_ms), bid_edges=int(m.bid_edges),
                      fullscan_launches=int(m.fullscan_launches), fullscan_ms=float(m.fullscan_ms),
                      fullscan_edges=int(m.fullscan_edges), tail_launches=int(m.tail_launches),
-                     tail_ms=float(m.tail_ms))
+                     tail_ms=float(m.tail_ms), tiled_launches=int(m.tiled_launches), tiled_ms=float(m.tiled_ms),
+                     tiled_edges=int(m.tiled_edges))
         self.gpu = g
         self.meta["gpu"] = g
 

@@ -45,6 +45,7 @@ struct Ctl {
     long long tail_rounds;
     unsigned long long tail_edges;
     double obj;            // objective accumulator (auction_.pyx:491)
+    unsigned long long dbg[16]; // diagnostic cycle counters of the stamped tail build (profile == 2)
 };
 
 // ---- edge storage ------------------------------------------------------------------------------
@@ -82,20 +83,109 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int off) {
     return __hiloint2double(hi, lo);
 }
 
+// Diagnostic stamp hook: drains the memory counters, then adds the s_memtime delta to slot k.
+struct NoStamp {
+    __device__ __forceinline__ void operator()(int) const {}
+};
+struct CycleStamp {
+    unsigned long long *acc;
+    unsigned long long *prev;
+    bool on;
+    __device__ __forceinline__ void operator()(int k) const {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        if (on) acc[k] += t - *prev;
+        *prev = t;
+    }
+};
+
+// ---- cross-lane exchange without LDS: DPP lane permutations ----------------------------------------
+constexpr int kDppXor1 = 0xB1;        // quad_perm [1,0,3,2]
+constexpr int kDppXor2 = 0x4E;        // quad_perm [2,3,0,1]
+constexpr int kDppHalfMirror = 0x141; // lane l <-> 7-l inside each 8 lanes
+constexpr int kDppMirror = 0x140;     // lane l <-> 15-l inside each 16 lanes
+constexpr int kDppBcast15 = 0x142;    // lane 15 of every row -> all lanes of the next row
+constexpr int kDppBcast31 = 0x143;    // lane 31 -> all lanes of rows 2 and 3
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ int dpp_i32(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false);  // disabled rows keep v
+}
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = dpp_i32<CTRL, ROW_MASK>(__double2loint(v));
+    const int hi = dpp_i32<CTRL, ROW_MASK>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+// all-reduce maximum over the 64 lanes, result uniform: 4 in-row DPP steps (xor 1, xor 2, mirrors),
+// two row-broadcast steps that leave the total in lane 63, one v_readlane.  No LDS (ds_bpermute).
+#define MISSLAP_WAVE_MAX_STEP(T, EXCH) \
+    {                                  \
+        const T o = EXCH;              \
+        v = o > v ? o : v;             \
+    }
+__device__ __forceinline__ int wave_max_i32(int v) {
+    MISSLAP_WAVE_MAX_STEP(int, dpp_i32<kDppXor1>(v))
+    MISSLAP_WAVE_MAX_STEP(int, dpp_i32<kDppXor2>(v))
+    MISSLAP_WAVE_MAX_STEP(int, dpp_i32<kDppHalfMirror>(v))
+    MISSLAP_WAVE_MAX_STEP(int, dpp_i32<kDppMirror>(v))
+    MISSLAP_WAVE_MAX_STEP(int, (dpp_i32<kDppBcast15, 0xA>(v)))
+    MISSLAP_WAVE_MAX_STEP(int, (dpp_i32<kDppBcast31, 0xC>(v)))
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ double wave_max_f64(double v) {  // no NaNs on this path
+    MISSLAP_WAVE_MAX_STEP(double, dpp_f64<kDppXor1>(v))
+    MISSLAP_WAVE_MAX_STEP(double, dpp_f64<kDppXor2>(v))
+    MISSLAP_WAVE_MAX_STEP(double, dpp_f64<kDppHalfMirror>(v))
+    MISSLAP_WAVE_MAX_STEP(double, dpp_f64<kDppMirror>(v))
+    MISSLAP_WAVE_MAX_STEP(double, (dpp_f64<kDppBcast15, 0xA>(v)))
+    MISSLAP_WAVE_MAX_STEP(double, (dpp_f64<kDppBcast31, 0xC>(v)))
+    return readlane_f64(v, 63);
+}
+#undef MISSLAP_WAVE_MAX_STEP
+
+// running top-2 of a set of (value, stored index): best value v, its index g, second-best value w
+// (counting multiplicity), with the reference's ">=" rule: among equal values the LAST stored index is
+// the best one (auction_.pyx:351).
+struct Top2 {
+    double v, w;
+    int g;
+};
+// Wave-wide top-2 from per-lane top-2s, as three scalar all-reduces:
+//   V = max v;  G = max{ g : v == V } (last index wins ties);  W = max( w of G's lane, v of every other lane ).
+// A lane other than G's whose best equals V contributes V to W: multiplicity is counted like the
+// reference's sequential scan does (wi = vbest on a repeated maximum, :353).
+__device__ __forceinline__ Top2 top2_wave_reduce(const Top2 &x) {
+    Top2 r;
+    r.v = wave_max_f64(x.v);
+    r.g = wave_max_i32(x.v == r.v ? x.g : -1);
+    r.w = wave_max_f64(x.g == r.g ? x.w : x.v);
+    return r;
+}
+
 // ---- the bid of one person, computed by one wavefront (auction_.pyx:339-365) ----------------------
-// Row [s, e) of the CSR.  Per lane: running (v1 = best value, g1 = its stored index, w = second
+// Row [s, e) of the CSR.  Per lane: running (v = best value, g = its stored index, w = second
 // best value counting multiplicity) over its elements in ascending stored index, with the
-// reference's ">=" rule (a later equal value replaces the best, :351).  Lanes are then merged by
-// a butterfly with  A (+) B = B if (vB > vA) or (vB == vA and gB > gA) else A,
-// second = max(loser's best, winner's second).  Every lane ends with the row's result.
-// Returns bid key and the chosen object in (key, obj); valid in all lanes.
-template <class E>
+// reference's ">=" rule (a later equal value replaces the best, :351); the lane also remembers the
+// (col, cost) of its own best element.  Lanes are merged by top2_wave_reduce; the winning element's
+// (col, cost) is then read from the lane that owns it.  Returns bid key and the chosen object in
+// (key, obj), uniform over the wavefront.
+template <class E, class S = NoStamp>
 __device__ __forceinline__ void wave_bid(const E &ed, const double *price, int s, int e, double eps,
-                                         unsigned long long &key, int &obj, int &err) {
+                                         unsigned long long &key, int &obj, int &err, const S &stamp = S()) {
     const int lane = threadIdx.x & (kWave - 1);
     const double ninf = -__builtin_huge_val();
-    double v1 = ninf, w = ninf;
-    int g1 = -1;
+    Top2 x;
+    x.v = ninf;
+    x.w = ninf;
+    x.g = -1;
+    int c1 = 0;
+    double a1 = 0.0;
     for (int base = s; base < e; base += 4 * kWave) {
         int c[4];
         double a[4], pr[4];
@@ -106,38 +196,37 @@ __device__ __forceinline__ void wave_bid(const E &ed, const double *price, int s
             a[u] = 0.0;
             if (g < e) ed.load(g, c[u], a[u]);
         }
+        stamp(1);  // edges landed
 #pragma unroll
         for (int u = 0; u < 4; ++u) pr[u] = (c[u] >= 0) ? price[c[u]] : 0.0;
+        stamp(2);  // prices landed
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (c[u] >= 0) {
                 const double v = a[u] - pr[u];  // vi = cost - p[j]   (:350)
-                if (v >= v1) {                  // :351
-                    w = v1;
-                    v1 = v;
-                    g1 = base + u * kWave + lane;
-                } else if (v > w) {             // :357
-                    w = v;
+                if (v >= x.v) {                 // :351
+                    x.w = x.v;
+                    x.v = v;
+                    x.g = base + u * kWave + lane;
+                    c1 = c[u];
+                    a1 = a[u];
+                } else if (v > x.w) {           // :357
+                    x.w = v;
                 }
             }
         }
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const double v2 = shfl_xor_f64(v1, off);
-        const double w2 = shfl_xor_f64(w, off);
-        const int g2 = __shfl_xor(g1, off);
-        const bool take = (v2 > v1) || (v2 == v1 && g2 > g1);
-        const double lose_v = take ? v1 : v2;
-        const double win_w = take ? w2 : w;
-        w = lose_v > win_w ? lose_v : win_w;
-        v1 = take ? v2 : v1;
-        g1 = take ? g2 : g1;
-    }
-    int col;
-    double cost;
-    ed.load(g1, col, cost);  // g1 >= s: every row has at least one entry
-    const double bid = (cost - w) + eps;  // bbest = costbest - wi + eps   (:360)
+    const int g_mine = x.g;
+    x = top2_wave_reduce(x);
+    stamp(3);  // reduction done
+    // the lane whose own best element is the row's best holds its column and cost (every row has
+    // at least one entry, so exactly one lane matches)
+    const unsigned long long owner = __ballot(g_mine == x.g);
+    const int src = __ffsll((long long)owner) - 1;
+    const int col = __builtin_amdgcn_readlane(c1, src);
+    const double cost = readlane_f64(a1, src);
+    stamp(4);
+    const double bid = (cost - x.w) + eps;  // bbest = costbest - wi + eps   (:360)
     if (!(bid >= 0.0)) err |= kErrNegativeBid;
     key = bid_to_key(bid);
     obj = col;

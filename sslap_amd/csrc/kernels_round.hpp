@@ -33,6 +33,7 @@ struct RoundArgs {
     int rank, world;              // bidder shard
     float eps;
     int launch_idx;
+    int gather_max_K;             // k_bid runs only for K < gather_max_K (k_bid_tiled takes the rest); 0 = no limit
 };
 
 __device__ __forceinline__ bool round_live(const Ctl *c, int thr) {
@@ -48,6 +49,7 @@ template <class E>
 __global__ __launch_bounds__(kBidBlock) void k_bid(RoundArgs a, E ed) {
     const Ctl *ctl = a.ctl;
     if (!round_live(ctl, a.thr)) return;
+    if (a.gather_max_K > 0 && ctl->K >= a.gather_max_K) return;
     int lo, hi;
     shard_range(ctl->K, a.rank, a.world, lo, hi);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;

@@ -48,7 +48,9 @@ __device__ __forceinline__ int apply_winner(const TailArgs &a, int person, int o
     return -1;        // hole (:412)
 }
 
-template <class E>
+// STAMP = diagnostic build: wavefront 0 accumulates s_memtime deltas of the four segments of a round
+// (bid | barrier | resolve+assign+compact | barrier) into Ctl::dbg; never used for reported timings.
+template <class E, bool STAMP>
 __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
     __shared__ int sU[kTailMax];
     __shared__ unsigned long long sKey[kTailMax];
@@ -79,7 +81,17 @@ __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
     const double eps = (double)a.eps;
     unsigned long long edges = 0, bids = 0;
     int err = 0;
+    unsigned long long st[5] = {0, 0, 0, 0, 0}, t_prev = 0;
+    unsigned long long st2[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_prev2 = 0;
+    auto stamp = [&](int k) {
+        if (STAMP && wave == 0) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            st[k] += t - t_prev;
+            t_prev = t;
+        }
+    };
     __syncthreads();
+    if (STAMP) t_prev = __builtin_amdgcn_s_memtime();
 
     for (;;) {
         // ---- BID: one wavefront per bidder ---------------------------------------------------
@@ -88,7 +100,14 @@ __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
             const int s = a.row_ptr[i], e = a.row_ptr[i + 1];
             unsigned long long key;
             int obj;
-            wave_bid(ed, a.price, s, e, eps, key, obj, err);
+            if (STAMP) {
+                CycleStamp cs{st2, &t_prev2, wave == 0};
+                cs(15);  // (re)arm
+                cs(0);   // row pointers landed
+                wave_bid(ed, a.price, s, e, eps, key, obj, err, cs);
+            } else {
+                wave_bid(ed, a.price, s, e, eps, key, obj, err);
+            }
             if (lane == 0) {
                 sKey[n] = key;
                 sObj[n] = obj;
@@ -96,10 +115,16 @@ __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
                 // is only rewritten by this round's winner of obj, after every bid has been made.
                 sPrev[n] = __hip_atomic_load(&a.o2p[obj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
+            if (STAMP) {
+                CycleStamp cs{st2, &t_prev2, wave == 0};
+                cs(5);  // owner read + LDS writes
+            }
             edges += (unsigned long long)(e - s);
             bids += 1;
         }
+        stamp(0);
         __syncthreads();
+        stamp(1);
 
         if (K <= kWave) {
             // ---- fast path: the whole rest of the round in wavefront 0, no LDS atomics ------------
@@ -191,10 +216,17 @@ __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
             }
             if (t == 0) sK = Kn;
         }
+        stamp(2);
         __syncthreads();
+        stamp(3);
         K = sK;
         nits += 1;
         if (K == 0 || nits >= max_iter) break;
+    }
+    if (STAMP && t == 0) {
+        for (int k = 0; k < 4; ++k) atomicAdd(&ctl->dbg[k], st[k]);
+        for (int k = 0; k < 6; ++k) atomicAdd(&ctl->dbg[4 + k], st2[k]);
+        atomicAdd(&ctl->dbg[10], bids);  // bids made by wavefront 0
     }
 
     if (t < K0) a.U[t] = sU[t];

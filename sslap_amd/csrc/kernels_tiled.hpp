@@ -1,0 +1,460 @@
+// kernels_tiled.hpp -- the full-scan bid kernel with object prices tiled in LDS.
+//
+// Why: in the wave-per-row kernel (k_bid) every edge gathers an 8-byte price from a 1.6 MB table; the
+// table lives in L2 but every random 8-byte read moves a whole sector L2 -> L1, ~8x the bytes of the
+// edge stream, and that traffic -- not HBM -- bounds the kernel (measured: 259 us with the gather,
+// 106 us without, C3).  Here a workgroup owns one CU's LDS, loads a tile of kTileCols = 20096 prices
+// (157 KB) at a time and looks prices up with ds_read_b64.
+//
+// Second layout of the edges in HBM ("tile-major", built once at ingest, next to the row-major CSR; HBM
+// capacity is not a constraint): persons are cut into layout blocks of kTileRB = 128; inside a block
+// the edges are ordered by (column tile, person, stored order).  The segment of (person i, tile t) is
+// [S[idx], S[idx+1]) with idx = ((i / RB) * T + t) * RB + i % RB.  For a full scan consecutive 8-lane
+// groups read adjacent segments, so a wavefront streams ~1 KB of contiguous edges per step.  The layout
+// requires column tiles to be non-decreasing along every row (true for column-sorted rows: the
+// `mat=` entry and the generator); otherwise the solver keeps to k_bid.  The in-row tie rule ("last
+// stored index wins", auction_.pyx:351) is preserved because the tile-major position of an edge is
+// monotone in its stored index within a row.
+//
+// Work split: a 1024-thread workgroup = 128 groups of 8 lanes; a group owns up to kTileRows persons
+// and keeps, PER LANE, the running top-2 of the elements that lane has seen (registers, ascending
+// position => the reference's ">=" rule applies unchanged).  Lanes of a group are merged only once,
+// after the last tile, with three 3-step DPP all-reduces inside the 8 lanes.
+#pragma once
+#include "device_common.hpp"
+#include "kernels_round.hpp"
+
+namespace misslap {
+
+// prices per LDS tile (a multiple of 128 = one 1-KB LDS-DMA piece):
+constexpr int kTileColsBig = 157 * 128;   // 20096 -> 160768 B, one workgroup per CU owns (almost) all of its LDS
+constexpr int kTileColsHalf = 79 * 128;   // 10112 ->  80896 B, two workgroups per CU: one computes while the
+                                          //                     other waits for its tile fill
+constexpr int kTileRB = 128;      // persons per layout block
+// Launch shapes (template parameters of k_bid_tiled): THREADS per workgroup (one workgroup per CU: the
+// price tile takes 128 of the 160 KB of LDS), ROWS persons per 8-lane group (register-resident running
+// top-2 per lane), BATCH persons whose segment loads are in flight together.
+
+// index of segment (person, tile) in the pointer table; the host enables the tiled path only while the
+// table has < 2^31 entries, so 32-bit arithmetic is enough (and saves address registers in the kernel)
+__host__ __device__ __forceinline__ int tile_idx(int person, int t, int T) {
+    return ((person / kTileRB) * T + t) * kTileRB + (person % kTileRB);
+}
+
+// ---- ingest: tile-major copy of the edges ---------------------------------------------------------------
+// pass 1, one wavefront per person: L(i, t) = number of edges of row i with column < t * kTileCols
+// (binary search, one tile boundary per lane); cnt[idx(i,t)] = L(i,t+1) - L(i,t); also the
+// column-order check.
+__global__ __launch_bounds__(256) void k_tile_count(const int2 *edges, const int *row_ptr, int n_rows, int T,
+                                                    int kTileCols, int *cnt, int *lrel, int *unsorted) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int i = blockIdx.x * 4 + wave; i < n_rows; i += gridDim.x * 4) {
+        const int s = row_ptr[i], e = row_ptr[i + 1];
+        int bad = 0;
+        for (int g = s + 1 + lane; g < e; g += kWave) bad |= (edges[g].x < edges[g - 1].x);
+        if (__ballot(bad) && lane == 0) atomicOr(unsorted, 1);
+        for (int t0 = 0; t0 <= T; t0 += kWave) {
+            const int t = t0 + lane;
+            int lo = 0;
+            if (t <= T) {
+                if (t == T) {
+                    lo = e - s;
+                } else {
+                    const int bound = t * kTileCols;  // first position with col >= bound
+                    int hi = e - s;
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (edges[s + mid].x < bound) lo = mid + 1;
+                        else hi = mid;
+                    }
+                }
+            }
+            const int nxt = __shfl_down(lo, 1);
+            int next_lo = nxt;
+            if (lane == 63 && t < T) {  // boundary handled by the next 64-tile pass: recompute
+                const int bound = (t + 1) * kTileCols;
+                int l2 = 0, hi = e - s;
+                if (t + 1 == T) l2 = e - s;
+                else {
+                    while (l2 < hi) {
+                        const int mid = (l2 + hi) >> 1;
+                        if (edges[s + mid].x < bound) l2 = mid + 1;
+                        else hi = mid;
+                    }
+                }
+                next_lo = l2;
+            }
+            if (t < T) {
+                const int idx = tile_idx(i, t, T);
+                cnt[idx] = next_lo - lo;
+                lrel[idx] = lo;
+            }
+        }
+    }
+}
+
+// exclusive scan of a long int array in three launches (chunk sums, scan of the sums, rescan + offset)
+constexpr int kScanChunk = 4096;  // elements per 1024-thread block
+__global__ __launch_bounds__(1024) void k_scan_sums(const int *in, long long n, int *sums) {
+    __shared__ int s_w[16];
+    const long long base = (long long)blockIdx.x * kScanChunk;
+    int v = 0;
+    for (int q = 0; q < 4; ++q) {
+        const long long k = base + q * 1024 + threadIdx.x;
+        if (k < n) v += in[k];
+    }
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < 16; ++w) t += s_w[w];
+        sums[blockIdx.x] = t;
+    }
+}
+__global__ __launch_bounds__(1024) void k_scan_of_sums(int *sums, int nblocks) {  // in place, exclusive
+    __shared__ int s_w[16];
+    __shared__ int s_carry;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nblocks; base += 1024) {
+        const int i = base + t;
+        const int v = (i < nblocks) ? sums[i] : 0;
+        int x = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int y = __shfl_up(x, off);
+            if (lane >= off) x += y;
+        }
+        if (lane == 63) s_w[wave] = x;
+        __syncthreads();
+        int wpre = 0;
+        for (int w2 = 0; w2 < wave; ++w2) wpre += s_w[w2];
+        const int carry = s_carry;
+        if (i < nblocks) sums[i] = carry + wpre + x - v;
+        __syncthreads();
+        if (t == 1023) s_carry = carry + wpre + x;
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(1024) void k_scan_apply(const int *in, long long n, const int *sums, int *out,
+                                                     int total) {
+    __shared__ int s_w[16];
+    __shared__ int s_carry;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const long long base = (long long)blockIdx.x * kScanChunk;
+    if (t == 0) s_carry = sums[blockIdx.x];
+    __syncthreads();
+    for (int q = 0; q < 4; ++q) {
+        const long long k = base + q * 1024 + t;
+        const int v = (k < n) ? in[k] : 0;
+        int x = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int y = __shfl_up(x, off);
+            if (lane >= off) x += y;
+        }
+        if (lane == 63) s_w[wave] = x;
+        __syncthreads();
+        int wpre = 0;
+        for (int w2 = 0; w2 < wave; ++w2) wpre += s_w[w2];
+        const int carry = s_carry;
+        if (k < n) out[k] = carry + wpre + x - v;
+        __syncthreads();
+        if (t == 1023) s_carry = carry + wpre + x;
+        __syncthreads();
+    }
+    if (blockIdx.x == 0 && t == 0) out[n] = total;  // one-past-the-end entry
+}
+
+// pass 3: copy every edge to its tile-major position
+__global__ __launch_bounds__(256) void k_tile_scatter(const int2 *edges, const int *row_ptr, int n_rows, int T,
+                                                      int kTileCols, const int *seg, const int *lrel, int2 *tiled) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int i = blockIdx.x * 4 + wave; i < n_rows; i += gridDim.x * 4) {
+        const int s = row_ptr[i], e = row_ptr[i + 1];
+        for (int g = s + lane; g < e; g += kWave) {
+            const int2 x = edges[g];
+            const int t = x.x / kTileCols;
+            const int idx = tile_idx(i, t, T);
+            tiled[seg[idx] + (g - s - lrel[idx])] = x;
+        }
+    }
+}
+
+// ---- the kernel -------------------------------------------------------------------------------------------
+__device__ __forceinline__ double group8_max_f64(double v) {
+    {
+        const double o = dpp_f64<kDppXor1>(v);
+        v = o > v ? o : v;
+    }
+    {
+        const double o = dpp_f64<kDppXor2>(v);
+        v = o > v ? o : v;
+    }
+    {
+        const double o = dpp_f64<kDppHalfMirror>(v);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ int group8_max_i32(int v) {
+    {
+        const int o = dpp_i32<kDppXor1>(v);
+        v = o > v ? o : v;
+    }
+    {
+        const int o = dpp_i32<kDppXor2>(v);
+        v = o > v ? o : v;
+    }
+    {
+        const int o = dpp_i32<kDppHalfMirror>(v);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+struct TiledArgs {
+    const int2 *tiled;   // tile-major edges
+    const int *seg;      // segment pointers, (n_blocks * T * RB) + 1 entries
+    int T;               // number of column tiles
+    int min_K;           // the kernel runs only for K >= min_K (k_bid takes the smaller rounds)
+    int nnz;             // number of edges (loads of masked-off lanes are clamped to nnz - 1)
+};
+
+// All global loads of the tile loop are UNCONDITIONAL (masked-off lanes read a clamped, valid address and
+// their value is neutralised): a load inside an `if` makes hipcc wait for it (vmcnt(0)) before the branch
+// re-converges, which serialises every load of the kernel.  The price array is padded to a whole number
+// of tiles so that the LDS fill needs no bounds test either.
+//
+// LDS: two price tiles (double buffer).  While the workgroup looks prices up in tile t, LDS-DMA
+// (global_load_lds_dwordx4, no VGPRs) fills tile t+1 into the other buffer; one barrier per tile.  Slot
+// kTileCols of each buffer holds +inf: a masked-off element reads it, gets value -inf and changes nothing.
+//
+// Per element (auction_.pyx:350-358 without branches):  v = cost - price;
+//   w = max(w, min(v, best));  best' = max(best, v);  g = (v >= best) ? position : g
+// which is the reference's update (">=": a later equal value becomes the best and the old best the second).
+//
+// Template: THREADS per workgroup, ROWS persons per 8-lane group, BATCH persons whose loads are in flight
+// together, DEPTH unconditional 8-lane loads per segment (longer segments finish in a short loop),
+// TILE_COLS prices per LDS tile.  ABL (diagnostics only, results wrong): 1 = no LDS fill, 2 = no
+// per-element arithmetic, 3 = no edge loads.
+template <int kTileThreads, int kTileRows, int kTileBatch, int kTileDepth, int kTileCols, int kLoaders, int ABL = 0>
+__global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledArgs ta) {
+    constexpr int kTileGroups = (kTileThreads - kLoaders * kWave) / 8;  // the last kLoaders wavefronts only move tiles
+    constexpr int kBufDoubles = kTileCols + 2;  // + the +inf slot, keeps the second buffer 16-byte aligned
+    // kTileColsBig: ONE buffer (fill, barrier, look up, barrier); kTileColsHalf: two buffers, fill overlapped
+    constexpr bool kDouble = kTileCols != kTileColsBig;
+    static_assert(kDouble || kLoaders == 0, "the single-buffer variant has no loader wavefronts");
+    static_assert(kTileRows % kTileBatch == 0 && kTileRows / kTileBatch >= 2, "ROWS = BATCH * (>= 2 steps)");
+    extern __shared__ __attribute__((aligned(16))) double s_price[];  // 2 * kBufDoubles
+    const Ctl *ctl = a.ctl;
+    if (!round_live(ctl, a.thr) || ctl->K < ta.min_K) return;
+    int lo, hi;
+    shard_range(ctl->K, a.rank, a.world, lo, hi);
+    // this workgroup's slice of list positions
+    const int per_wg = (hi - lo + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int p0 = lo + (int)blockIdx.x * per_wg;
+    const int p1 = min(hi, p0 + per_wg);
+    if (p0 >= p1) return;  // uniform over the workgroup
+    const int t = threadIdx.x, lane = t & 63, gl = lane & 7;
+    const int group = t >> 3;
+    const double eps = (double)a.eps;
+    const double ninf = -__builtin_huge_val();
+    const int T = ta.T;
+    const int last = ta.nnz - 1;
+    // The LDS-DMA pieces of a tile and a wavefront's own loads share one in-order counter (vmcnt): data of a
+    // load issued AFTER a piece cannot be consumed before the piece has landed.  Two ways around it:
+    //   kLoaders > 0: the last kLoaders wavefronts do nothing but the fills (wavefront specialisation);
+    //   kLoaders = 0: every wavefront issues its share of the pieces right after the prefetch loads of the
+    //                 tile's first step, so that only loads of the tile's later steps queue behind them.
+    constexpr int kWaves = kTileThreads / kWave;
+    const int wave_u = __builtin_amdgcn_readfirstlane(t >> 6);
+    const bool loader = kLoaders > 0 && wave_u >= kWaves - kLoaders;
+
+    int person[kTileRows];
+    double sv[kTileRows], sw[kTileRows];
+    int sg[kTileRows];  // position of the lane's best element (its column / cost are re-read at the end)
+#pragma unroll
+    for (int j = 0; j < kTileRows; ++j) {
+        const int pos = p0 + j * kTileGroups + group;
+        const int u = a.U[min(pos, p1 - 1)];  // unconditional load (see the note above), masked afterwards
+        person[j] = (pos < p1 && !loader) ? u : -1;
+        sv[j] = ninf;
+        sw[j] = ninf;
+        sg[j] = -1;
+    }
+    if (t < (kDouble ? 2 : 1)) s_price[t * kBufDoubles + kTileCols] = __builtin_huge_val();
+
+    // pieces first, first + stride, ... of `tile` -> buffer tile & 1; one piece = 64 lanes x 16 B = 128 prices
+    auto dma_fill = [&](int tile, int first, int stride) {
+        constexpr int kPieces = kTileCols / 128;
+        const double *gsrc = a.price + (size_t)tile * kTileCols + 2 * lane;
+        double *dst = s_price + (kDouble ? (tile & 1) : 0) * kBufDoubles;
+#pragma unroll 4
+        for (int piece = first; piece < kPieces; piece += stride)
+            if (ABL != 1)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc + piece * 128),
+                                                 (__attribute__((address_space(3))) void *)(dst + piece * 128), 16, 0,
+                                                 0);
+    };
+    if (loader) {
+        const int me = wave_u - (kWaves - kLoaders);
+        dma_fill(0, me, kLoaders);
+        for (int tile = 0; tile < T; ++tile) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my pieces of tile `tile` have landed
+            __syncthreads();                                  // ... and tile - 1 is no longer read
+            if (tile + 1 < T) dma_fill(tile + 1, me, kLoaders);
+        }
+    }
+    // Software pipeline over steps = (tile, batch of kTileBatch persons): while step s is consumed, the edges
+    // of step s+1 and the segment pointers of step s+2 are in flight; they do not depend on LDS.
+    constexpr int kNB = kTileRows / kTileBatch;
+    struct Seg {
+        int s0[kTileBatch], s1[kTileBatch];
+    };
+    struct Edges {
+        int2 x[kTileBatch][kTileDepth];
+    };
+    auto load_seg = [&](int tile, int b, Seg &sg_) {
+        const int tl = min(tile, T - 1);
+#pragma unroll
+        for (int jj = 0; jj < kTileBatch; ++jj) {
+            const int pj = person[b * kTileBatch + jj];
+            const int idx = tile_idx(pj >= 0 ? pj : 0, tl, T);
+            sg_.s0[jj] = ta.seg[idx];
+            sg_.s1[jj] = ta.seg[idx + 1];
+        }
+    };
+    auto load_edges = [&](const Seg &sg_, Edges &e) {
+#pragma unroll
+        for (int jj = 0; jj < kTileBatch; ++jj)
+#pragma unroll
+            for (int d = 0; d < kTileDepth; ++d) {
+                if (ABL == 3) e.x[jj][d] = make_int2(sg_.s0[jj] & 1023, gl);
+                else e.x[jj][d] = ta.tiled[min(sg_.s0[jj] + gl + 8 * d, last)];
+            }
+    };
+    Seg seg_cur, seg_nxt, seg_nx2;
+    Edges e_cur, e_nxt;
+    load_seg(0, 0, seg_cur);
+    load_seg(0, 1, seg_nxt);
+    load_edges(seg_cur, e_cur);
+    if (kLoaders == 0 && kDouble) dma_fill(0, wave_u, kWaves);
+    for (int tile = 0; tile < (loader ? 0 : T); ++tile) {
+        if (!kDouble) {
+            __syncthreads();  // every lookup of the previous tile is done
+            dma_fill(tile, wave_u, kWaves);
+        }
+        if (kLoaders == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my pieces of this tile
+        __syncthreads();  // every piece of this tile has landed; the other buffer may be refilled
+        const int c0 = tile * kTileCols;
+        const double *buf = s_price + (kDouble ? (tile & 1) : 0) * kBufDoubles;
+#pragma unroll
+        for (int b = 0; b < kNB; ++b) {
+            // issue: edges of the next step, segment pointers of the step after it
+            const int n2t = (b + 2 < kNB) ? tile : tile + 1, n2b = (b + 2) % kNB;
+            load_edges(seg_nxt, e_nxt);
+            load_seg(n2t, n2b, seg_nx2);
+            if (kDouble && kLoaders == 0 && b == 0 && tile + 1 < T) dma_fill(tile + 1, wave_u, kWaves);
+            // consume step (tile, b)
+#pragma unroll
+            for (int jj = 0; jj < kTileBatch; ++jj) {
+                const int j = b * kTileBatch + jj;
+                const int s0 = seg_cur.s0[jj];
+                const int s1 = person[j] >= 0 ? seg_cur.s1[jj] : s0;  // empty segment for an absent person
+#pragma unroll
+                for (int d = 0; d < kTileDepth; ++d) {
+                    const int2 x = e_cur.x[jj][d];
+                    if (ABL == 2) {
+                        asm volatile("" ::"v"(x.x), "v"(x.y));  // keep the loads alive
+                        continue;
+                    }
+                    const int q = s0 + gl + 8 * d;
+                    const bool ok = q < s1;
+                    const double pr = buf[ok ? x.x - c0 : kTileCols];          // masked-off: +inf
+                    const double v = (double)__int_as_float(x.y) - pr;          // vi = cost - p[j]   (:350)
+                    const bool ge = ok && (v >= sv[j]);                          // :351
+                    sw[j] = __builtin_fmax(sw[j], __builtin_fmin(v, sv[j]));     // :353 / :357-358
+                    sv[j] = __builtin_fmax(sv[j], v);
+                    sg[j] = ge ? q : sg[j];
+                }
+                for (int q = s0 + gl + 8 * kTileDepth; q < s1 && ABL == 0; q += 8) {  // long segments
+                    const int2 y = ta.tiled[q];
+                    const double v = (double)__int_as_float(y.y) - buf[y.x - c0];
+                    if (v >= sv[j]) {
+                        sw[j] = sv[j];
+                        sv[j] = v;
+                        sg[j] = q;
+                    } else if (v > sw[j]) {
+                        sw[j] = v;
+                    }
+                }
+            }
+            seg_cur = seg_nxt;
+            seg_nxt = seg_nx2;
+            e_cur = e_nxt;
+        }
+    }
+    // merge the 8 lanes of each group, once per person (same three all-reduces as top2_wave_reduce)
+    unsigned long long edges = 0;
+    int nb = 0, err = 0;
+    int2 best[kTileRows];
+    int rlen[kTileRows];
+    double W[kTileRows];
+    bool mine[kTileRows];
+#pragma unroll
+    for (int j = 0; j < kTileRows; ++j) {
+        const double V = group8_max_f64(sv[j]);
+        const int G = group8_max_i32(sv[j] == V ? sg[j] : -1);
+        W[j] = group8_max_f64(sg[j] == G ? sw[j] : sv[j]);
+        mine[j] = person[j] >= 0 && sg[j] == G && G >= 0;  // exactly one lane of the group
+        const int pj = max(person[j], 0);
+        best[j] = ta.tiled[max(G, 0)];                     // unconditional loads, used under `mine`
+        rlen[j] = a.row_ptr[pj + 1] - a.row_ptr[pj];
+    }
+#pragma unroll
+    for (int j = 0; j < kTileRows; ++j) {
+        if (mine[j]) {
+            const double cost = (double)__int_as_float(best[j].y);
+            const double bid = (cost - W[j]) + eps;  // :360
+            if (!(bid >= 0.0)) err |= kErrNegativeBid;
+            const unsigned long long key = bid_to_key(bid);
+            const int pos = p0 + j * kTileGroups + group;
+            a.bid_key[pos] = key;
+            a.bid_obj[pos] = best[j].x;
+            atomicMax(&a.best_key[best[j].x], key);
+            edges += (unsigned long long)rlen[j];
+            nb += 1;
+        }
+    }
+    // statistics: one atomic per workgroup
+    __shared__ unsigned long long s_e[kTileThreads / kWave];
+    __shared__ int s_n[kTileThreads / kWave];
+    for (int off = 32; off >= 1; off >>= 1) {
+        edges += ((unsigned long long)__shfl_xor((unsigned)(edges >> 32), off) << 32) |
+                 (unsigned long long)__shfl_xor((unsigned)(edges & 0xffffffffull), off);
+        nb += __shfl_xor(nb, off);
+        err |= __shfl_xor(err, off);
+    }
+    if (lane == 0) {
+        s_e[t >> 6] = edges;
+        s_n[t >> 6] = nb;
+        if (err) atomicOr(&a.ctl->err, err);
+    }
+    __syncthreads();
+    if (t == 0) {
+        unsigned long long te = 0;
+        int tb = 0;
+        for (int w = 0; w < kTileThreads / kWave; ++w) {
+            te += s_e[w];
+            tb += s_n[w];
+        }
+        if (tb) {
+            atomicAdd(&a.ctl->edges, te);
+            atomicAdd(&a.ctl->bids, (unsigned long long)tb);
+            if (a.launch_edges) atomicAdd(&a.launch_edges[a.launch_idx], te);
+        }
+    }
+}
+
+}  // namespace misslap

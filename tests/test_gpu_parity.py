@@ -238,3 +238,49 @@ def test_sharded_driver_two_ranks_one_gpu(gpu_lib):
             sol, its, nred, obj = got[rank][k]
             assert sol == ref["sol"].tolist(), (rank, k)
             assert (its, nred, obj) == (ref["meta"]["its"], ref["meta"]["nreductions"], ref["extra"]["obj_f64"])
+
+
+@pytest.mark.parametrize("spec,prob", [
+    (dict(kind="sparse", n=6000, m=40000, density=0.001), "max"),          # 3 column tiles, rectangular
+    (dict(kind="sparse", n=5000, m=5000, density=0.01, ints=6), "max"),    # heavy ties, 1 tile
+    (dict(kind="sparse", n=4500, m=33000, density=0.0012, ints=3), "min"), # ties across tiles
+])
+def test_tiled_bid_kernel_round_by_round(spec, prob, gpu_lib):
+    """k_bid_tiled (prices tiled in LDS, tile-major edge copy) forced for every grid round
+    (tiled_min_k = 1, no tail kernel): full state vs the oracle after r rounds."""
+    loc, val = cases.synth_inputs(spec)
+    for r in [1, 2, 3, 5, 8, 13, 21, 40, 80, 200]:
+        o = orc.from_sparse(loc, val.copy(), problem=prob, max_iter=r, cardinality_check=False)
+        o.solve()
+        so = o.state()
+        g = from_sparse(loc, val.copy(), problem=prob, max_iter=r, cardinality_check=False, tail_threshold=0,
+                        tiled_min_k=1)
+        g.solve()
+        assert g.gpu["tiled_active"] == 1
+        sg = g.state()
+        assert sg["its"] == so["its"] and sg["K"] == so["K"], r
+        assert np.array_equal(sg["U"], so["U"]), r
+        assert np.array_equal(sg["p"].view(np.uint64), so["p"].view(np.uint64)), r
+        assert np.array_equal(sg["p2o"], so["p2o"]) and np.array_equal(sg["o2p"], so["o2p"]), r
+        assert g.gpu["edges_scanned"] == o.extra["edges_scanned"], r
+
+
+def test_tiled_and_gather_kernels_agree_end_to_end(gpu_lib):
+    loc, val = synth.gen_sparse(20000, 50000, 0.001, seed=4)
+    ref = orc.auction_solve(loc=loc, val=val.copy(), problem="max", cardinality_check=False, max_iter=10**8)
+    for tk in (1, 0, -1):  # always tiled, default threshold, never tiled
+        s = from_sparse(loc, val.copy(), problem="max", cardinality_check=False, max_iter=10**8, tiled_min_k=tk)
+        sol = s.solve()
+        assert s.gpu["tiled_active"] == (0 if tk < 0 else 1)
+        assert np.array_equal(sol, ref["sol"]) and s.meta["its"] == ref["meta"]["its"], tk
+        assert s.gpu["obj_f64"] == ref["extra"]["obj_f64"]
+
+
+def test_unsorted_rows_fall_back_to_gather_kernel(gpu_lib):
+    spec = dict(kind="shuffled", n=5000, m=20000, density=0.002)
+    loc, val = cases.synth_inputs(spec)
+    ref = orc.auction_solve(loc=loc, val=val.copy(), problem="max", cardinality_check=False)
+    s = from_sparse(loc, val.copy(), problem="max", cardinality_check=False, tiled_min_k=1)
+    sol = s.solve()
+    assert s.gpu["tiled_active"] == 0  # in-row order is the tie rule: no tile-major copy for unsorted rows
+    assert np.array_equal(sol, ref["sol"])

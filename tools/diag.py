@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Diagnostics on the GPU box: bid-kernel ablations and stamped tail kernel (not part of the product)."""
+import ctypes as C
+import json
+import sys
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from sslap_amd import AuctionSolver, synth, _lib
+
+cfg = sys.argv[1] if len(sys.argv) > 1 else "C3"
+loc, val = synth.gen_config(cfg)
+nnz = loc.shape[0]
+dl, dv = torch.from_numpy(loc).cuda(), torch.from_numpy(val).cuda()
+s = AuctionSolver.from_device_pointers(dl.data_ptr(), dv.data_ptr(), nnz, problem="max", max_iter=10**8)
+out = {"cfg": cfg, "nnz": int(nnz)}
+names = {0: "complete", 1: "no_gather", 2: "no_reduce", 3: "stream_only"}
+if "--tiled-ablate" in sys.argv:
+    s3 = AuctionSolver.from_device_pointers(dl.data_ptr(), dv.data_ptr(), nnz, problem="max", max_iter=10**8, tiled_shape=0)
+    for mode, nm in ((10, "complete"), (11, "no_fill"), (12, "no_arith"), (13, "no_edge_loads"), (10, "complete2")):
+        ms = C.c_float()
+        _lib.check(_lib.load().misslap_debug_time_bid(s3._h, mode, 20, C.byref(ms)))
+        out["tiled_" + nm + "_us"] = round(ms.value * 1e3, 1)
+    print(json.dumps(out, indent=1))
+    sys.exit(0)
+for mode in (0, 1, 2, 3, 0):
+    ms = C.c_float()
+    _lib.check(_lib.load().misslap_debug_time_bid(s._h, mode, 20, C.byref(ms)))
+    out["bid_" + names[mode] + "_us"] = round(ms.value * 1e3, 1)
+    out["bid_" + names[mode] + "_GBs"] = round(nnz * 8 / (ms.value * 1e-3) / 1e9, 1)
+# full-scan timing inside a real solve (HIP events), tiled vs gather kernel
+shapes = ["768x9x3x2h_L1", "768x9x3x3big", "1024x8x2x3big", "768x9x3x4big", "1024x8x2x2h_L2", "768x9x3x2h_L0", "1024x8x4x3big", "512x16x4x3big"]
+for tk, shape, name in [(0, k, "tiled_" + n) for k, n in enumerate(shapes)] + [(-1, 0, "gather_only")]:
+    st = AuctionSolver.from_device_pointers(dl.data_ptr(), dv.data_ptr(), nnz, problem="max", max_iter=10**8,
+                                            profile=1, tiled_min_k=tk, tiled_shape=shape)
+    st.solve()
+    g = st.gpu
+    out["solve_" + name] = dict(solve_ms=g["solve_ms"], setup_ms=g["setup_ms"], fullscan_us=1e3 * g["fullscan_ms"] / max(g["fullscan_launches"], 1),
+                                fullscan_GBs=g["fullscan_edges"] * 8 / max(g["fullscan_ms"], 1e-9) / 1e6,
+                                tiled_launches=g["tiled_launches"], tiled_ms=g["tiled_ms"], tiled_edges=g["tiled_edges"],
+                                bid_launches=g["bid_launches"], bid_ms=g["bid_ms"], bid_edges=g["bid_edges"], tail_ms=g["tail_ms"],
+                                grid_rounds=g["grid_rounds"], its=st.meta["its"])
+if "--tail" in sys.argv:
+    s2 = AuctionSolver.from_device_pointers(dl.data_ptr(), dv.data_ptr(), nnz, problem="max", max_iter=10**8, profile=2)
+    s2.solve()
+    g = s2.gpu
+    allc = g["tail_stamp_cycles"]
+    cyc = allc[:4]
+    tot = sum(cyc)
+    nb0 = max(allc[10], 1.0)
+    out["tail_bid_wave0_cycles_per_bid"] = dict(zip(
+        ["row_ptr", "edges", "prices", "top2+butterfly", "reread_edge", "owner+lds"], [round(c / nb0, 1) for c in allc[4:10]]))
+    out["tail_bids_by_wave0"] = nb0
+    out["tail"] = dict(rounds=g["tail_rounds"], tail_ms=g["tail_ms"], us_per_round=1e3 * g["tail_ms"] / g["tail_rounds"],
+                       cycles_per_round=tot / g["tail_rounds"],
+                       share=dict(zip(["bid", "barrier1", "resolve_apply_compact", "barrier2"], [round(c / tot, 3) for c in cyc])),
+                       bids=g["bids_made"], tail_edges=g["tail_edges"])
+print(json.dumps(out, indent=1))
