@@ -232,6 +232,89 @@ __device__ __forceinline__ void wave_bid(const E &ed, const double *price, int s
     obj = col;
 }
 
+// Per-object record used by the latency-bound tail kernel: one 16-byte gather brings the price AND the
+// current owner and the start of the owner's CSR row, so the next bidder of an eviction chain (the evicted
+// owner) and the address of its row are known without two further dependent loads (o2p, row_ptr).
+// `price[]` (plain fp64, used by the streaming kernels) and `rec[]` always hold the same prices.
+struct __attribute__((aligned(16))) PriceRec {
+    double price;
+    int owner;   // == o2p[j]
+    int ostart;  // row_ptr[owner] (undefined when owner == -1)
+};
+
+// wave_bid with the record gather.  (patch_col, patch): the record of one object may be overridden with a
+// value the caller holds in registers (the object it has just re-priced), so that the result never
+// depends on how fast the wavefront's own store becomes visible to its next loads.  `e_late` may arrive
+// after the edge loads have been issued: the first four 64-edge chunks are loaded unconditionally (the
+// edge arrays are padded) and masked with the row end afterwards.
+template <class E, class S = NoStamp>
+__device__ __forceinline__ void wave_bid_rec(const E &ed, const PriceRec *rec, int s, const int *e_ptr, double eps,
+                                             int patch_col, const PriceRec &patch, unsigned long long &key,
+                                             int &obj, int &prev, int &pstart, int &row_end, int &err,
+                                             const S &stamp = S()) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const double ninf = -__builtin_huge_val();
+    Top2 x;
+    x.v = ninf;
+    x.w = ninf;
+    x.g = -1;
+    int c1 = 0, o1 = -1, os1 = 0;
+    double a1 = 0.0;
+    int c[4];
+    double a[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ed.load(s + u * kWave + lane, c[u], a[u]);  // speculative: e not known yet
+    const int e = *e_ptr;
+    row_end = e;
+    for (int base = s; base < e; base += 4 * kWave) {
+        if (base != s) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ed.load(min(base + u * kWave + lane, e - 1), c[u], a[u]);
+        }
+        stamp(1);  // edges landed
+        PriceRec r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool ok = base + u * kWave + lane < e;
+            if (!ok) c[u] = -1;
+            r[u] = rec[ok ? c[u] : 0];
+        }
+        stamp(2);  // records landed
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (c[u] >= 0) {
+                if (c[u] == patch_col) r[u] = patch;
+                const double v = a[u] - r[u].price;  // vi = cost - p[j]   (:350)
+                if (v >= x.v) {                      // :351
+                    x.w = x.v;
+                    x.v = v;
+                    x.g = base + u * kWave + lane;
+                    c1 = c[u];
+                    a1 = a[u];
+                    o1 = r[u].owner;
+                    os1 = r[u].ostart;
+                } else if (v > x.w) {                // :357
+                    x.w = v;
+                }
+            }
+        }
+    }
+    const int g_mine = x.g;
+    x = top2_wave_reduce(x);
+    stamp(3);
+    const unsigned long long ownerm = __ballot(g_mine == x.g);
+    const int src = __ffsll((long long)ownerm) - 1;
+    const int col = __builtin_amdgcn_readlane(c1, src);
+    const double cost = readlane_f64(a1, src);
+    prev = __builtin_amdgcn_readlane(o1, src);
+    pstart = __builtin_amdgcn_readlane(os1, src);
+    stamp(4);
+    const double bid = (cost - x.w) + eps;  // bbest = costbest - wi + eps   (:360)
+    if (!(bid >= 0.0)) err |= kErrNegativeBid;
+    key = bid_to_key(bid);
+    obj = col;
+}
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
 __device__ __forceinline__ unsigned long long lanemask_lt() {
     return (1ull << lane_id()) - 1ull;

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void k_build_edges_f64(const int *loc, const d
     }
 }
 
-__global__ __launch_bounds__(256) void k_init_state(Ctl *ctl, double *price, int *p2o, int *o2p, int *U,
+__global__ __launch_bounds__(256) void k_init_state(Ctl *ctl, double *price, PriceRec *rec, int *p2o, int *o2p, int *U,
                                                     unsigned long long *best_key, int *best_pos, int n_rows,
                                                     int n_cols, long long max_iter) {
     const int stride = gridDim.x * blockDim.x;
@@ -99,6 +99,11 @@ __global__ __launch_bounds__(256) void k_init_state(Ctl *ctl, double *price, int
     }
     for (int j = t; j < n_cols; j += stride) {
         price[j] = 0.0;        // :220
+        PriceRec r;
+        r.price = 0.0;
+        r.owner = -1;
+        r.ostart = 0;
+        rec[j] = r;
         o2p[j] = -1;           // :232
         best_key[j] = 0ull;    // :255
         best_pos[j] = kPosNone;  // :256

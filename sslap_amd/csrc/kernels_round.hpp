@@ -17,6 +17,7 @@ struct RoundArgs {
     Ctl *ctl;
     const int *row_ptr;
     double *price;
+    PriceRec *rec;                // {price, owner, owner's row start} per object (tail kernel's gather)
     int *p2o;
     int *o2p;
     int *U;
@@ -115,7 +116,12 @@ __global__ __launch_bounds__(256) void k_apply(RoundArgs a) {
         const int n = a.best_pos[j];
         if (n != kPosNone) {
             const int i = a.U[n];
-            a.price[j] = key_to_bid(a.best_key[j]);  // p[j] = best_bids[j]   (:397)
+            PriceRec r;
+            r.price = key_to_bid(a.best_key[j]);     // p[j] = best_bids[j]   (:397)
+            r.owner = i;
+            r.ostart = a.row_ptr[i];
+            a.rec[j] = r;
+            a.price[j] = r.price;
             const int prev = a.o2p[j];               // :401
             if (prev != -1) {
                 a.p2o[prev] = -1;                    // :404
@@ -255,15 +261,18 @@ __global__ void k_round_end(RoundArgs a) {
 }
 
 // eps-phase restart (auction_.pyx:286-290): forget assignments, keep prices.
-__global__ __launch_bounds__(256) void k_reset_phase(Ctl *ctl, int *p2o, int *o2p, int *U, int n_rows,
-                                                     int n_cols) {
+__global__ __launch_bounds__(256) void k_reset_phase(Ctl *ctl, int *p2o, int *o2p, PriceRec *rec, int *U,
+                                                     int n_rows, int n_cols) {
     const int stride = gridDim.x * blockDim.x;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     for (int i = t; i < n_rows; i += stride) {
         p2o[i] = -1;
         U[i] = i;
     }
-    for (int j = t; j < n_cols; j += stride) o2p[j] = -1;
+    for (int j = t; j < n_cols; j += stride) {
+        o2p[j] = -1;
+        rec[j].owner = -1;  // the price stays
+    }
     if (t == 0) {
         ctl->K = n_rows;
         ctl->nholes = 0;

@@ -20,6 +20,7 @@ struct TailArgs {
     Ctl *ctl;
     const int *row_ptr;
     double *price;
+    PriceRec *rec;  // {price, owner, owner's row start} per object, see device_common.hpp
     int *p2o;
     int *o2p;
     int *U;
@@ -36,9 +37,14 @@ __device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v,
 }
 
 // assignment of one winner (auction_.pyx:396-418); returns the new content of its U slot
-__device__ __forceinline__ int apply_winner(const TailArgs &a, int person, int obj, int prev,
+__device__ __forceinline__ int apply_winner(const TailArgs &a, int person, int pstart, int obj, int prev,
                                             unsigned long long key) {
-    a.price[obj] = key_to_bid(key);
+    PriceRec r;
+    r.price = key_to_bid(key);
+    r.owner = person;
+    r.ostart = pstart;
+    a.rec[obj] = r;
+    a.price[obj] = r.price;
     a.o2p[obj] = person;
     a.p2o[person] = obj;
     if (prev != -1) {
@@ -56,12 +62,14 @@ __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
     __shared__ unsigned long long sKey[kTailMax];
     __shared__ int sObj[kTailMax];
     __shared__ int sPrev[kTailMax];
+    __shared__ int sStart[kTailMax];  // row_ptr of the bidder (for the record of the object it may win)
     __shared__ int sList[kTailMax];
     __shared__ int hObj[kHashSize];
     __shared__ unsigned long long hKey[kHashSize];
     __shared__ int hPos[kHashSize];
     __shared__ int sCnt[3][kTailMax / kWave];
     __shared__ int sK;
+    __shared__ long long sNits;
 
     Ctl *ctl = a.ctl;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -95,29 +103,102 @@ __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
 
     for (;;) {
         // ---- BID: one wavefront per bidder ---------------------------------------------------
+        if (K == 1) {
+            // ---- chain mode: one bidder per round until the phase ends (K never grows).  Wavefront 0 runs
+            // the rounds alone, without barriers and without LDS; the other wavefronts wait at the barrier
+            // below.  Round r+1's bidder is the owner evicted in round r, and its row start came with the
+            // price record, so the only dependent global accesses per round are: the row (edges), the
+            // price records of its columns, and row_ptr[i+1] in parallel with the edges.
+            if (wave == 0) {
+                int i = sU[0];
+                int s = a.row_ptr[i];
+                int patch_col = -1;
+                PriceRec patch;
+                patch.price = 0.0;
+                patch.owner = -1;
+                patch.ostart = 0;
+                for (;;) {
+                    unsigned long long key;
+                    int obj, prev, pstart, e;
+                    if (STAMP) {
+                        CycleStamp cs{st2, &t_prev2, true};
+                        cs(15);
+                        cs(0);
+                        wave_bid_rec(ed, a.rec, s, a.row_ptr + i + 1, eps, patch_col, patch, key, obj, prev, pstart, e,
+                                     err, cs);
+                    } else {
+                        wave_bid_rec(ed, a.rec, s, a.row_ptr + i + 1, eps, patch_col, patch, key, obj, prev, pstart, e,
+                                     err);
+                    }
+                    edges += (unsigned long long)(e - s);
+                    bids += 1;
+                    nits += 1;
+                    // ASSIGN (:396-418): the single bidder always wins
+                    patch.price = key_to_bid(key);
+                    patch.owner = i;
+                    patch.ostart = s;
+                    patch_col = obj;
+                    if (lane == 0) {
+                        a.rec[obj] = patch;
+                        a.price[obj] = patch.price;
+                        a.o2p[obj] = i;
+                        a.p2o[i] = obj;
+                        if (prev != -1) a.p2o[prev] = -1;
+                    }
+                    if (STAMP) {
+                        CycleStamp cs{st2, &t_prev2, true};
+                        cs(5);
+                    }
+                    if (prev == -1) {  // nobody evicted: everybody is assigned
+                        K = 0;
+                        if (lane == 0) sU[0] = -1;
+                        break;
+                    }
+                    i = prev;  // the evicted owner inherits the slot (:409) and bids next
+                    s = pstart;
+                    if (nits >= max_iter) {
+                        if (lane == 0) sU[0] = i;
+                        break;
+                    }
+                }
+                if (lane == 0) {
+                    sK = K;
+                    sNits = nits;
+                }
+            }
+            __syncthreads();
+            K = sK;
+            nits = sNits;
+            break;
+        }
         for (int n = wave; n < K; n += nwaves) {
             const int i = sU[n];
-            const int s = a.row_ptr[i], e = a.row_ptr[i + 1];
+            const int s = a.row_ptr[i];
             unsigned long long key;
-            int obj;
+            int obj, prev, pstart, e;
+            PriceRec nopatch;
+            nopatch.price = 0.0;
+            nopatch.owner = -1;
+            nopatch.ostart = 0;
             if (STAMP) {
                 CycleStamp cs{st2, &t_prev2, wave == 0};
                 cs(15);  // (re)arm
                 cs(0);   // row pointers landed
-                wave_bid(ed, a.price, s, e, eps, key, obj, err, cs);
+                wave_bid_rec(ed, a.rec, s, a.row_ptr + i + 1, eps, -1, nopatch, key, obj, prev, pstart, e, err, cs);
             } else {
-                wave_bid(ed, a.price, s, e, eps, key, obj, err);
+                wave_bid_rec(ed, a.rec, s, a.row_ptr + i + 1, eps, -1, nopatch, key, obj, prev, pstart, e, err);
             }
             if (lane == 0) {
                 sKey[n] = key;
                 sObj[n] = obj;
-                // owner at the start of the round == what the assignment phase reads (:401): o2p[obj]
-                // is only rewritten by this round's winner of obj, after every bid has been made.
-                sPrev[n] = __hip_atomic_load(&a.o2p[obj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                // owner at the start of the round == what the assignment phase reads (:401): the record of
+                // obj is only rewritten by this round's winner of obj, after every bid has been made.
+                sPrev[n] = prev;
+                sStart[n] = s;
             }
             if (STAMP) {
                 CycleStamp cs{st2, &t_prev2, wave == 0};
-                cs(5);  // owner read + LDS writes
+                cs(5);  // LDS writes
             }
             edges += (unsigned long long)(e - s);
             bids += 1;
@@ -139,7 +220,7 @@ __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
                     lose |= (om == obj) && (km > key || (km == key && m < lane));
                 }
                 int u = act ? sU[lane] : -1;
-                if (act && !lose) u = apply_winner(a, u, obj, sPrev[lane], key);
+                if (act && !lose) u = apply_winner(a, u, sStart[lane], obj, sPrev[lane], key);
                 // push_all_left with ballots
                 const unsigned long long kmask = (K >= 64) ? ~0ull : ((1ull << K) - 1ull);
                 const unsigned long long holes = __ballot(act && u == -1) & kmask;
@@ -186,7 +267,7 @@ __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
                 hPos[h] = kPosNone;
             }
             int u = act ? sU[t] : -1;
-            if (win) u = apply_winner(a, u, obj, sPrev[t], key);
+            if (win) u = apply_winner(a, u, sStart[t], obj, sPrev[t], key);
             const bool hole = act && u == -1;
             const unsigned long long bh = __ballot(hole);
             if (lane == 0) sCnt[0][wave] = __popcll(bh);

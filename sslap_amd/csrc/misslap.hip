@@ -98,6 +98,7 @@ struct misslap_solver {
     double *val64 = nullptr;
     int *row_ptr = nullptr;
     double *price = nullptr;
+    PriceRec *rec = nullptr;
     int *p2o = nullptr, *o2p = nullptr, *U = nullptr;
     unsigned long long *bid_key = nullptr;
     int *bid_obj = nullptr;
@@ -148,6 +149,7 @@ RoundArgs round_args(misslap_solver *h) {
     a.ctl = h->ctl;
     a.row_ptr = h->row_ptr;
     a.price = h->price;
+    a.rec = h->rec;
     a.p2o = h->p2o;
     a.o2p = h->o2p;
     a.U = h->U;
@@ -291,6 +293,7 @@ int launch_tail(misslap_solver *h) {
     a.ctl = h->ctl;
     a.row_ptr = h->row_ptr;
     a.price = h->price;
+    a.rec = h->rec;
     a.p2o = h->p2o;
     a.o2p = h->o2p;
     a.U = h->U;
@@ -347,7 +350,7 @@ void free_all(misslap_solver *h) {
     (void)hipSetDevice(h->device);
     void *ptrs[] = {h->edges32, h->col,     h->val64,     h->row_ptr,    h->price,   h->p2o,     h->o2p,
                     h->U,       h->bid_key, h->bid_obj,   h->best_key,   h->best_pos, h->cnt,    h->hole_list,
-                    h->mover_list, h->ctl,  h->contrib,   h->nmatch,     h->launch_edges, h->tiled, h->seg};
+                    h->mover_list, h->ctl,  h->contrib,   h->nmatch,     h->launch_edges, h->tiled, h->seg, h->rec};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_ctl) (void)hipHostFree(h->h_ctl);
@@ -394,12 +397,15 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
     h->f32 = !st.not_f32 && !opt->force_f64_values;
     const int flip = h->maximize ? 0 : 1;
     if (h->f32) {
-        if ((rc = dev_alloc(&h->edges32, (size_t)nnz))) return rc;
+        if ((rc = dev_alloc(&h->edges32, (size_t)nnz + 4 * kWave))) return rc;  // tail kernel reads up to 256 past a row start
+        HIP_TRY(hipMemsetAsync(h->edges32 + nnz, 0, sizeof(int2) * 4 * kWave, h->stream));
         hipLaunchKernelGGL(k_build_edges_f32, dim3(grid), dim3(256), 0, h->stream, d_loc, d_val, (long long)nnz,
                            flip, h->edges32);
     } else {
-        if ((rc = dev_alloc(&h->col, (size_t)nnz))) return rc;
-        if ((rc = dev_alloc(&h->val64, (size_t)nnz))) return rc;
+        if ((rc = dev_alloc(&h->col, (size_t)nnz + 4 * kWave))) return rc;
+        if ((rc = dev_alloc(&h->val64, (size_t)nnz + 4 * kWave))) return rc;
+        HIP_TRY(hipMemsetAsync(h->col + nnz, 0, sizeof(int) * 4 * kWave, h->stream));
+        HIP_TRY(hipMemsetAsync(h->val64 + nnz, 0, sizeof(double) * 4 * kWave, h->stream));
         hipLaunchKernelGGL(k_build_edges_f64, dim3(grid), dim3(256), 0, h->stream, d_loc, d_val, (long long)nnz,
                            flip, h->col, h->val64);
     }
@@ -460,6 +466,7 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
     const size_t Mpad = (size_t)h->T * kTileCols;  // whole tiles: the LDS fill of k_bid_tiled needs no bounds test
     if ((rc = dev_alloc(&h->price, Mpad))) return rc;
     HIP_TRY(hipMemsetAsync(h->price, 0, sizeof(double) * Mpad, h->stream));
+    if ((rc = dev_alloc(&h->rec, M))) return rc;
     if ((rc = dev_alloc(&h->p2o, N))) return rc;
     if ((rc = dev_alloc(&h->o2p, M))) return rc;
     if ((rc = dev_alloc(&h->U, N))) return rc;
@@ -481,7 +488,7 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
     }
     h->max_iter = opt->max_iter < 1 ? 1 : opt->max_iter;  // the loop body runs before the first test (:271-275)
     hipLaunchKernelGGL(k_init_state, dim3(blocks_for((long long)(N > M ? N : M), 256)), dim3(256), 0, h->stream,
-                       h->ctl, h->price, h->p2o, h->o2p, h->U, h->best_key, h->best_pos, h->n_rows, h->n_cols,
+                       h->ctl, h->price, h->rec, h->p2o, h->o2p, h->U, h->best_key, h->best_pos, h->n_rows, h->n_cols,
                        (long long)h->max_iter);
     HIP_TRY(hipGetLastError());
     // eps schedule, fp32 exactly as the generated C of the reference
@@ -748,7 +755,7 @@ MISSLAP_API int misslap_phase_end(misslap_solver *h, int32_t *finished) {
         } else {
             h->eps = h->eps * h->theta;  // :283 (fp32 product)
             hipLaunchKernelGGL(k_reset_phase, dim3(blocks_for(h->n_rows > h->n_cols ? h->n_rows : h->n_cols, 256)),
-                               dim3(256), 0, h->stream, h->ctl, h->p2o, h->o2p, h->U, h->n_rows, h->n_cols);
+                               dim3(256), 0, h->stream, h->ctl, h->p2o, h->o2p, h->rec, h->U, h->n_rows, h->n_cols);
             HIP_TRY(hipGetLastError());
             h->nreductions += 1;  // :292
             h->K_ub = h->n_rows;
