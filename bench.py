@@ -164,6 +164,14 @@ def main():
         rk_ms, rk_edges, rk_launches = (til_ms, til_edges, til_launches) if tiled else (bid_ms, bid_edges, bid_launches)
         achieved = rk_edges * bpe / (rk_ms * 1e-3) / 1e9 if rk_ms > 0 else 0.0
         fs_achieved = fs_edges * bpe / (fs_ms * 1e-3) / 1e9 if fs_ms > 0 else 0.0
+        # HBM traffic of the roofline kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+        # on this same command, summarised by tools/pmc_summary.py with the gfx950 corrections)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if tiled and os.path.exists(tpath):
+            tk = [v for k, v in json.load(open(tpath))["kernels"].items() if "k_bid_tiled" in k]
+            if tk:
+                traffic = round(tk[0]["read_avg"] + tk[0]["write_avg"])
         out = {
             "metric": "Medges/s (bid-phase CSR nnz/s) + solve ms, N=200k d=0.1% sparse LAP",
             "value": round(edges_all / dt / 1e6, 2),
@@ -205,7 +213,9 @@ def main():
                 "launches": rk_launches, "avg_launch_us": round(1e3 * rk_ms / max(rk_launches, 1), 3),
                 "algorithmic_bytes_per_edge": bpe,
                 "algorithmic_bytes_per_launch": round(rk_edges * bpe / max(rk_launches, 1)),
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 PMC, bytes per launch, FETCH_SIZE x2 "
+                                  "gfx950 correction calibrated on known-size kernels)" if traffic else None,
             },
             "device": name.value.decode(), "compute_units": int(cus.value),
         }

@@ -331,7 +331,7 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
 #pragma unroll
             for (int d = 0; d < kTileDepth; ++d) {
                 if (ABL == 3) e.x[jj][d] = make_int2(sg_.s0[jj] & 1023, gl);
-                else e.x[jj][d] = ta.tiled[min(sg_.s0[jj] + gl + 8 * d, last)];
+                else e.x[jj][d] = ta.tiled[min(sg_.s0[jj] + gl + 8 * d, last)];  // (non-temporal loads measured slower)
             }
     };
     Seg seg_cur, seg_nxt, seg_nx2;

@@ -129,6 +129,7 @@ struct misslap_solver {
     bool profile = false;
     bool stamp = false;  // profile == 2: stamped (diagnostic) tail kernel
     int K_ub = 0;  // host-side upper bound of K (K never grows inside a phase)
+    bool K_exact = false;  // K_ub was read from the device and no round has been enqueued since
     bool phase_fresh = true;  // no round of the current eps-phase has been enqueued yet
     std::vector<ProfRec> prof;
     size_t prof_used = 0;
@@ -196,6 +197,7 @@ int read_ctl(misslap_solver *h) {
     HIP_TRY(hipMemcpyAsync(h->h_ctl, h->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->K_ub = h->h_ctl->K;
+    h->K_exact = true;
     if (h->h_ctl->err)
         return fail(MISSLAP_ERR_STATE, "device-side invariant violated (error bits 0x%x)", h->h_ctl->err);
     return MISSLAP_OK;
@@ -240,7 +242,13 @@ int launch_bid(misslap_solver *h) {
     if (h->tiled_ok && h->K_ub >= h->tiled_min_K) {
         int rc = launch_bid_tiled(h);  // no-op on the device when K has dropped below tiled_min_K
         if (rc) return rc;
+        if (h->K_exact) {  // the host has just read K: k_bid would be a no-op
+            h->phase_fresh = false;
+            h->K_exact = false;
+            return MISSLAP_OK;
+        }
     }
+    h->K_exact = false;
     RoundArgs a = round_args(h);
     const long long share = ((long long)h->K_ub + h->world - 1) / h->world;
     const int grid = blocks_for(share, kBidBlock / kWave);
@@ -276,6 +284,7 @@ int launch_tiebreak(misslap_solver *h) {
 }
 
 int launch_apply(misslap_solver *h) {
+    h->K_exact = false;
     RoundArgs a = round_args(h);
     hipLaunchKernelGGL(k_apply, dim3(blocks_for(h->n_cols, 256)), dim3(256), 0, h->stream, a);
     const int cb = blocks_for(h->K_ub, kChunk);
@@ -504,6 +513,7 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
     if (opt->eps_start > 0) h->eps = opt->eps_start;  // :251-252
     h->start_eps = h->eps;
     h->K_ub = h->n_rows;
+    h->K_exact = true;
     h->phase_fresh = true;
     HIP_TRY(hipStreamSynchronize(h->stream));
     return MISSLAP_OK;
@@ -759,6 +769,7 @@ MISSLAP_API int misslap_phase_end(misslap_solver *h, int32_t *finished) {
             HIP_TRY(hipGetLastError());
             h->nreductions += 1;  // :292
             h->K_ub = h->n_rows;
+            h->K_exact = true;  // k_reset_phase sets K = n_rows
             h->phase_fresh = true;
         }
     }
@@ -868,7 +879,10 @@ MISSLAP_API int misslap_solve(misslap_solver *h, int32_t *person_to_object_out, 
             const Ctl &c = *h->h_ctl;
             if (c.K == 0 || c.nits >= h->max_iter) break;
             if (c.K > h->thr) {
-                for (int r = 0; r < h->rounds_per_sync; ++r) {
+                // rounds big enough for the tiled kernel are few (a handful per phase): enqueue them one at
+                // a time so that neither bid kernel is launched for a round the other one takes
+                const int batch = (h->tiled_ok && c.K >= h->tiled_min_K) ? 1 : h->rounds_per_sync;
+                for (int r = 0; r < batch; ++r) {
                     if ((rc = launch_bid(h))) return rc;
                     if ((rc = launch_tiebreak(h))) return rc;
                     if ((rc = launch_apply(h))) return rc;
