@@ -56,6 +56,13 @@ struct EdgesF32 {  // 8 B / edge
         col = x.x;
         val = (double)__int_as_float(x.y);  // exact widening
     }
+    // streaming variant for the tail kernel: rows are read once and must not evict the price records from L2
+    __device__ __forceinline__ void load_nt(int g, int &col, double &val) const {
+        typedef int v2i_t __attribute__((ext_vector_type(2)));
+        const v2i_t x = __builtin_nontemporal_load(reinterpret_cast<const v2i_t *>(e) + g);
+        col = x.x;
+        val = (double)__int_as_float(x.y);
+    }
 };
 struct EdgesF64 {  // 12 B / edge
     const int *col;
@@ -63,6 +70,10 @@ struct EdgesF64 {  // 12 B / edge
     __device__ __forceinline__ void load(int g, int &c, double &v) const {
         c = col[g];
         v = val[g];
+    }
+    __device__ __forceinline__ void load_nt(int g, int &c, double &v) const {
+        c = __builtin_nontemporal_load(col + g);
+        v = __builtin_nontemporal_load(val + g);
     }
 };
 
@@ -138,13 +149,13 @@ __device__ __forceinline__ int wave_max_i32(int v) {
     MISSLAP_WAVE_MAX_STEP(int, (dpp_i32<kDppBcast31, 0xC>(v)))
     return __builtin_amdgcn_readlane(v, 63);
 }
-__device__ __forceinline__ double wave_max_f64(double v) {  // no NaNs on this path
-    MISSLAP_WAVE_MAX_STEP(double, dpp_f64<kDppXor1>(v))
-    MISSLAP_WAVE_MAX_STEP(double, dpp_f64<kDppXor2>(v))
-    MISSLAP_WAVE_MAX_STEP(double, dpp_f64<kDppHalfMirror>(v))
-    MISSLAP_WAVE_MAX_STEP(double, dpp_f64<kDppMirror>(v))
-    MISSLAP_WAVE_MAX_STEP(double, (dpp_f64<kDppBcast15, 0xA>(v)))
-    MISSLAP_WAVE_MAX_STEP(double, (dpp_f64<kDppBcast31, 0xC>(v)))
+__device__ __forceinline__ double wave_max_f64(double v) {  // no NaNs on this path: v_max_f64 is exact
+    v = __builtin_fmax(v, dpp_f64<kDppXor1>(v));
+    v = __builtin_fmax(v, dpp_f64<kDppXor2>(v));
+    v = __builtin_fmax(v, dpp_f64<kDppHalfMirror>(v));
+    v = __builtin_fmax(v, dpp_f64<kDppMirror>(v));
+    v = __builtin_fmax(v, (dpp_f64<kDppBcast15, 0xA>(v)));
+    v = __builtin_fmax(v, (dpp_f64<kDppBcast31, 0xC>(v)));
     return readlane_f64(v, 63);
 }
 #undef MISSLAP_WAVE_MAX_STEP
@@ -263,13 +274,13 @@ __device__ __forceinline__ void wave_bid_rec(const E &ed, const PriceRec *rec, i
     int c[4];
     double a[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) ed.load(s + u * kWave + lane, c[u], a[u]);  // speculative: e not known yet
+    for (int u = 0; u < 4; ++u) ed.load_nt(s + u * kWave + lane, c[u], a[u]);  // speculative: e not known yet
     const int e = *e_ptr;
     row_end = e;
     for (int base = s; base < e; base += 4 * kWave) {
         if (base != s) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) ed.load(min(base + u * kWave + lane, e - 1), c[u], a[u]);
+            for (int u = 0; u < 4; ++u) ed.load_nt(min(base + u * kWave + lane, e - 1), c[u], a[u]);
         }
         stamp(1);  // edges landed
         PriceRec r[4];

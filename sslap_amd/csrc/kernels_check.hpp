@@ -23,20 +23,25 @@ __global__ __launch_bounds__(256) void k_ece(Ctl *ctl, E ed, const int *row_ptr,
         const int j = p2o[i];
         double vmax = ninf;
         int gsel = -1;
-        for (int g = s + lane; g < e; g += kWave) {
-            int c;
-            double cost;
-            ed.load(g, c, cost);
-            const double v = cost - price[c];
-            vmax = v > vmax ? v : vmax;
-            if (c == j) gsel = g;  // ascending g per lane: keeps the last match
+        for (int base = s; base < e; base += 4 * kWave) {  // four 64-edge chunks in flight, like wave_bid
+            int c[4];
+            double a[4], pr[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ed.load(min(base + u * kWave + lane, e - 1), c[u], a[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) pr[u] = price[c[u]];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int g = base + u * kWave + lane;
+                if (g < e) {
+                    const double v = a[u] - pr[u];
+                    vmax = v > vmax ? v : vmax;
+                    if (c[u] == j) gsel = g;  // ascending g per lane: keeps the last match
+                }
+            }
         }
-        for (int off = 32; off >= 1; off >>= 1) {
-            const double v2 = shfl_xor_f64(vmax, off);
-            const int g2 = __shfl_xor(gsel, off);
-            vmax = v2 > vmax ? v2 : vmax;
-            gsel = g2 > gsel ? g2 : gsel;
-        }
+        vmax = wave_max_f64(vmax);
+        gsel = wave_max_i32(gsel);
         if (lane == 0) {
             bool bad = true;  // an assigned column that is not in the row cannot happen
             if (gsel >= 0) {
@@ -99,11 +104,26 @@ __global__ __launch_bounds__(256) void k_obj_rows(Ctl *ctl, E ed, const int *row
 template <class E>
 __global__ void k_obj_sum(Ctl *ctl, E ed, const int *row_ptr, const int *p2o, int n_rows, int maximize,
                           const double *contrib, const int *nmatch) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (blockIdx.x != 0 || threadIdx.x >= kWave) return;  // one wavefront
+    const int lane = threadIdx.x;
     double obj = 0.0;
     if (ctl->dup_rows == 0) {
-        for (int i = 0; i < n_rows; ++i) obj += contrib[i];  // adding +0.0 for skipped rows is exact
-    } else {
+        // 64 contributions per coalesced load, then added one by one in person order (v_readlane): the
+        // additions stay sequential, only the loads are parallel
+        double nxt = (lane < n_rows) ? contrib[lane] : 0.0;
+        for (int base = 0; base < n_rows; base += kWave) {
+            const double cur = nxt;
+            const int k = base + kWave + lane;
+            nxt = (k < n_rows) ? contrib[k] : 0.0;
+            const int cnt = min(kWave, n_rows - base);
+            if (cnt == kWave) {
+#pragma unroll
+                for (int l = 0; l < kWave; ++l) obj += readlane_f64(cur, l);  // adding +0.0 for skipped rows is exact
+            } else {
+                for (int l = 0; l < cnt; ++l) obj += readlane_f64(cur, l);
+            }
+        }
+    } else if (lane == 0) {
         for (int i = 0; i < n_rows; ++i) {
             if (nmatch[i] <= 1) {
                 obj += contrib[i];
@@ -118,6 +138,7 @@ __global__ void k_obj_sum(Ctl *ctl, E ed, const int *row_ptr, const int *p2o, in
             }
         }
     }
+    if (lane != 0) return;
     ctl->obj = obj;
 }
 

@@ -108,7 +108,7 @@ def test_forced_f64_layout_matches(golden_small, gpu_lib):
     assert s.meta["its"] == manifest["cases"]["sq1000_max"]["meta"]["its"]
 
 
-@pytest.mark.parametrize("name", ["C1", "C1_min", "C4", "C2", "C3"])
+@pytest.mark.parametrize("name", ["C1", "C1_min", "C4", "C2", "C3", "C5"])
 def test_baseline_configs_match_reference_hashes(name, golden_large, gpu_lib):
     g = golden_large["cases"].get(name)
     if g is None:
