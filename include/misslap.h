@@ -49,7 +49,8 @@ typedef struct misslap_options {
     int32_t shard_world;     /* number of shards (1 = single GPU) */
     int32_t rounds_per_sync; /* grid rounds enqueued between host status reads; <= 0 = default */
     int32_t reserved[8];     /* [0]: LDS-tiled bid kernel: 0 = default threshold, < 0 = never, > 0 = minimum K;
-                                [1]: its launch shape (tuning knob, 0..5; see misslap.hip:kShapes) */
+                                [1]: launch shape of k_bid_tiled (tuning knob, see misslap.hip:kTiledShapes);
+                                [2]: full-scan engine: 0 / 1 k_bid_tiled (default), 2 k_scan2d + k_merge2d (experimental) */
 } misslap_options;
 
 /* Result block of misslap_finish: the reference's `meta` dict (auction_.pyx:264,:297-304)
@@ -88,8 +89,11 @@ typedef struct misslap_meta {
     int64_t tiled_launches;      /* launches of the LDS-tiled bid kernel (k_bid_tiled), no-ops included */
     double tiled_ms;
     uint64_t tiled_edges;
-    int32_t tiled_active;        /* the tile-major edge copy exists and big rounds use k_bid_tiled */
+    int32_t tiled_active;        /* full-scan engine for big rounds: 0 none (k_bid only), 1 k_bid_tiled,
+                                    2 k_scan2d + k_merge2d (the tiled_* counters then refer to k_scan2d) */
     int32_t tiled_min_K;         /* rounds with K >= this use it */
+    int64_t merge_launches;      /* k_merge2d */
+    double merge_ms;
     double reserved_d[12];       /* diagnostic cycle counters of the stamped tail build */
 } misslap_meta;
 

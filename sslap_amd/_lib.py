@@ -33,6 +33,7 @@ class Meta(C.Structure):
         ("tail_launches", C.c_int64), ("tail_ms", C.c_double), ("tail_edges", C.c_uint64),
         ("tiled_launches", C.c_int64), ("tiled_ms", C.c_double), ("tiled_edges", C.c_uint64),
         ("tiled_active", C.c_int32), ("tiled_min_K", C.c_int32),
+        ("merge_launches", C.c_int64), ("merge_ms", C.c_double),
         ("reserved_d", C.c_double * 12),
     ]
 

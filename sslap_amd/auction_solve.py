@@ -26,7 +26,8 @@ _ENV_TILED = "MISSLAP_TILED_MIN_K"  # 0 default, < 0 never use the LDS-tiled bid
 
 
 def _options(problem, eps_start, max_iter, device=None, tail_threshold=None, profile=None, force_f64=False,
-             input_on_device=False, shard=None, rounds_per_sync=None, tiled_min_k=None, tiled_shape=None):
+             input_on_device=False, shard=None, rounds_per_sync=None, tiled_min_k=None, tiled_shape=None,
+             engine=None):
     if problem not in ("min", "max"):
         # the reference treats every string other than 'min' as 'max' (auction_.pyx:236, :502)
         problem = "max" if problem != "min" else "min"
@@ -45,6 +46,7 @@ def _options(problem, eps_start, max_iter, device=None, tail_threshold=None, pro
         o.shard_rank, o.shard_world = int(shard[0]), int(shard[1])
     o.reserved[0] = int(os.environ.get(_ENV_TILED, 0)) if tiled_min_k is None else int(tiled_min_k)
     o.reserved[1] = int(os.environ.get("MISSLAP_TILED_SHAPE", 0)) if tiled_shape is None else int(tiled_shape)
+    o.reserved[2] = int(os.environ.get("MISSLAP_ENGINE", 0)) if engine is None else int(engine)
     return o
 
 
@@ -170,7 +172,8 @@ class AuctionSolver:
                      fullscan_launches=int(m.fullscan_launches), fullscan_ms=float(m.fullscan_ms),
                      fullscan_edges=int(m.fullscan_edges), tail_launches=int(m.tail_launches),
                      tail_ms=float(m.tail_ms), tiled_launches=int(m.tiled_launches), tiled_ms=float(m.tiled_ms),
-                     tiled_edges=int(m.tiled_edges))
+                     tiled_edges=int(m.tiled_edges), merge_launches=int(m.merge_launches),
+                     merge_ms=float(m.merge_ms))
         self.gpu = g
         self.meta["gpu"] = g
 

@@ -37,8 +37,8 @@ constexpr int kTileRB = 128;      // persons per layout block
 
 // index of segment (person, tile) in the pointer table; the host enables the tiled path only while the
 // table has < 2^31 entries, so 32-bit arithmetic is enough (and saves address registers in the kernel)
-__host__ __device__ __forceinline__ int tile_idx(int person, int t, int T) {
-    return ((person / kTileRB) * T + t) * kTileRB + (person % kTileRB);
+__host__ __device__ __forceinline__ int tile_idx(int person, int t, int T, int rb = kTileRB) {
+    return ((person / rb) * T + t) * rb + (person % rb);
 }
 
 // ---- ingest: tile-major copy of the edges ---------------------------------------------------------------
@@ -46,7 +46,7 @@ __host__ __device__ __forceinline__ int tile_idx(int person, int t, int T) {
 // (binary search, one tile boundary per lane); cnt[idx(i,t)] = L(i,t+1) - L(i,t); also the
 // column-order check.
 __global__ __launch_bounds__(256) void k_tile_count(const int2 *edges, const int *row_ptr, int n_rows, int T,
-                                                    int kTileCols, int *cnt, int *lrel, int *unsorted) {
+                                                    int kTileCols, int rb, int *cnt, int *lrel, int *unsorted) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int i = blockIdx.x * 4 + wave; i < n_rows; i += gridDim.x * 4) {
         const int s = row_ptr[i], e = row_ptr[i + 1];
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void k_tile_count(const int2 *edges, const int
                 next_lo = l2;
             }
             if (t < T) {
-                const int idx = tile_idx(i, t, T);
+                const int idx = tile_idx(i, t, T, rb);
                 cnt[idx] = next_lo - lo;
                 lrel[idx] = lo;
             }
@@ -168,14 +168,15 @@ __global__ __launch_bounds__(1024) void k_scan_apply(const int *in, long long n,
 
 // pass 3: copy every edge to its tile-major position
 __global__ __launch_bounds__(256) void k_tile_scatter(const int2 *edges, const int *row_ptr, int n_rows, int T,
-                                                      int kTileCols, const int *seg, const int *lrel, int2 *tiled) {
+                                                      int kTileCols, int rb, const int *seg, const int *lrel,
+                                                      int2 *tiled) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int i = blockIdx.x * 4 + wave; i < n_rows; i += gridDim.x * 4) {
         const int s = row_ptr[i], e = row_ptr[i + 1];
         for (int g = s + lane; g < e; g += kWave) {
             const int2 x = edges[g];
             const int t = x.x / kTileCols;
-            const int idx = tile_idx(i, t, T);
+            const int idx = tile_idx(i, t, T, rb);
             tiled[seg[idx] + (g - s - lrel[idx])] = x;
         }
     }
@@ -378,15 +379,35 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
                     sv[j] = __builtin_fmax(sv[j], v);
                     sg[j] = ge ? q : sg[j];
                 }
-                for (int q = s0 + gl + 8 * kTileDepth; q < s1 && ABL == 0; q += 8) {  // long segments
-                    const int2 y = ta.tiled[q];
-                    const double v = (double)__int_as_float(y.y) - buf[y.x - c0];
-                    if (v >= sv[j]) {
-                        sw[j] = sv[j];
-                        sv[j] = v;
-                        sg[j] = q;
-                    } else if (v > sw[j]) {
-                        sw[j] = v;
+            }
+            // segments longer than 8 * kTileDepth edges: wave-uniform loop with the loads of the whole batch
+            // issued together (a per-segment `for` with a load inside costs one HBM latency per segment)
+            if (ABL == 0) {
+                int qx[kTileBatch], s1x[kTileBatch];
+                bool more = false;
+#pragma unroll
+                for (int jj = 0; jj < kTileBatch; ++jj) {
+                    qx[jj] = seg_cur.s0[jj] + gl + 8 * kTileDepth;
+                    s1x[jj] = person[b * kTileBatch + jj] >= 0 ? seg_cur.s1[jj] : seg_cur.s0[jj];
+                    more |= qx[jj] < s1x[jj];
+                }
+                while (__any(more)) {
+                    int2 y[kTileBatch];
+#pragma unroll
+                    for (int jj = 0; jj < kTileBatch; ++jj) y[jj] = ta.tiled[min(qx[jj], last)];
+                    more = false;
+#pragma unroll
+                    for (int jj = 0; jj < kTileBatch; ++jj) {
+                        const int j = b * kTileBatch + jj;
+                        const bool ok = qx[jj] < s1x[jj];
+                        const double pr = buf[ok ? y[jj].x - c0 : kTileCols];
+                        const double v = (double)__int_as_float(y[jj].y) - pr;
+                        const bool ge = ok && (v >= sv[j]);
+                        sw[j] = __builtin_fmax(sw[j], __builtin_fmin(v, sv[j]));
+                        sv[j] = __builtin_fmax(sv[j], v);
+                        sg[j] = ge ? qx[jj] : sg[j];
+                        qx[jj] += 8;
+                        more |= qx[jj] < s1x[jj];
                     }
                 }
             }

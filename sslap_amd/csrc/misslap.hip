@@ -25,6 +25,7 @@
 #include "kernels_round.hpp"
 #include "kernels_tail.hpp"
 #include "kernels_tiled.hpp"
+#include "kernels_scan2d.hpp"
 
 using namespace misslap;
 
@@ -77,7 +78,7 @@ inline size_t tiled_lds_bytes(int tile_cols) {
 
 struct ProfRec {
     hipEvent_t start, stop;
-    int kind;        // 0 = k_bid, 1 = k_tail, 2 = k_bid_tiled
+    int kind;        // 0 = k_bid, 1 = k_tail, 2 = k_bid_tiled / k_scan2d, 3 = k_merge2d
     int fullscan;    // bid launch with K == n_rows
     int launch_idx;  // index into launch_edges (kind 0)
 };
@@ -117,6 +118,11 @@ struct misslap_solver {
     bool tiled_ok = false;
     int tiled_min_K = 0;
     int tiled_shape = 0;  // index into kShapes of launch_bid_tiled
+    // 2-D full-scan engine (kernels_scan2d.hpp): row blocks x column slices, partial top-2s merged per bidder
+    bool scan2d = false;
+    int s2_C = 0, s2_R = 0, s2_rb = 0, s2_cols = 0;
+    double *part_v = nullptr, *part_w = nullptr;
+    int *part_g = nullptr;
     Ctl *h_ctl = nullptr;  // pinned mirror
     // scalar solver state (auction_.pyx:180-187)
     float eps = 0, target_eps = 0, theta = 0, start_eps = 0;
@@ -238,9 +244,38 @@ int launch_bid_tiled(misslap_solver *h) {
     return MISSLAP_OK;
 }
 
+int launch_bid_scan2d(misslap_solver *h) {
+    RoundArgs a = round_args(h);
+    Scan2dArgs sa{h->tiled, h->seg, h->s2_C, h->s2_rb, h->s2_cols, h->tiled_min_K, (int)h->nnz,
+                  h->part_v, h->part_w, h->part_g};
+    ProfRec *pr = nullptr, *pm = nullptr;
+    if (h->profile) {
+        if (h->launch_idx >= h->launch_edges_cap)
+            return fail(MISSLAP_ERR_STATE, "profile buffer exhausted (%d bid launches)", h->launch_idx);
+        pr = prof_next(h, 2);
+        if (!pr) return fail(MISSLAP_ERR_HIP, "hipEventCreate failed");
+        pr->fullscan = h->phase_fresh;
+        pr->launch_idx = a.launch_idx = h->launch_idx++;
+        HIP_TRY(hipEventRecord(pr->start, h->stream));
+    }
+    const size_t lds = (size_t)(h->s2_cols + 2) * sizeof(double);
+    hipLaunchKernelGGL((k_scan2d<1024, 3, 4>), dim3((unsigned)(h->s2_R * h->s2_C)), dim3(1024), lds, h->stream, a, sa);
+    if (pr) HIP_TRY(hipEventRecord(pr->stop, h->stream));
+    if (h->profile) {
+        pm = prof_next(h, 3);
+        if (!pm) return fail(MISSLAP_ERR_HIP, "hipEventCreate failed");
+        pm->launch_idx = a.launch_idx;
+        HIP_TRY(hipEventRecord(pm->start, h->stream));
+    }
+    hipLaunchKernelGGL(k_merge2d, dim3(blocks_for(h->K_ub, 256)), dim3(256), 0, h->stream, a, sa);
+    if (pm) HIP_TRY(hipEventRecord(pm->stop, h->stream));
+    HIP_TRY(hipGetLastError());
+    return MISSLAP_OK;
+}
+
 int launch_bid(misslap_solver *h) {
     if (h->tiled_ok && h->K_ub >= h->tiled_min_K) {
-        int rc = launch_bid_tiled(h);  // no-op on the device when K has dropped below tiled_min_K
+        int rc = h->scan2d ? launch_bid_scan2d(h) : launch_bid_tiled(h);  // no-op on the device when K < tiled_min_K
         if (rc) return rc;
         if (h->K_exact) {  // the host has just read K: k_bid would be a no-op
             h->phase_fresh = false;
@@ -359,7 +394,7 @@ void free_all(misslap_solver *h) {
     (void)hipSetDevice(h->device);
     void *ptrs[] = {h->edges32, h->col,     h->val64,     h->row_ptr,    h->price,   h->p2o,     h->o2p,
                     h->U,       h->bid_key, h->bid_obj,   h->best_key,   h->best_pos, h->cnt,    h->hole_list,
-                    h->mover_list, h->ctl,  h->contrib,   h->nmatch,     h->launch_edges, h->tiled, h->seg, h->rec};
+                    h->mover_list, h->ctl,  h->contrib,   h->nmatch,     h->launch_edges, h->tiled, h->seg, h->rec, h->part_v, h->part_w, h->part_g};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_ctl) (void)hipHostFree(h->h_ctl);
@@ -419,60 +454,88 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
                            flip, h->col, h->val64);
     }
     const size_t N = (size_t)h->n_rows, M = (size_t)h->n_cols;
-    // second, tile-major copy of the edges for the LDS-tiled bid kernel (8 B/edge layout, big rounds only)
+    // second, tile-major copy of the edges for the full-scan bid engines (8 B/edge layout, big rounds only)
     h->tiled_shape = (opt->reserved[1] >= 0 && opt->reserved[1] < kNumTiledShapes) ? opt->reserved[1] : 0;
-    const int kTileCols = kTiledShapes[h->tiled_shape][4];
-    h->T = (int)((M + kTileCols - 1) / kTileCols);
-    const int tiled_opt = opt->reserved[0];  // 0 default, < 0 never, > 0 minimum K for the tiled kernel
-    const long long nblk = ((long long)N + kTileRB - 1) / kTileRB;
-    const long long L = nblk * h->T * kTileRB;
-    if (h->f32 && tiled_opt >= 0 && N >= 4096 && (double)nnz / ((double)N * h->T) >= 4.0 && L < 0x7fffffffLL) {
-        const int nchunks = (int)((L + kScanChunk - 1) / kScanChunk);
-        int *cnt = nullptr, *lrel = nullptr, *sums = nullptr, *flag = nullptr;
-        if ((rc = dev_alloc(&cnt, (size_t)L))) return rc;
-        if ((rc = dev_alloc(&lrel, (size_t)L))) return rc;
-        if ((rc = dev_alloc(&sums, (size_t)nchunks + 1))) return rc;
-        if ((rc = dev_alloc(&flag, 1))) return rc;
-        if ((rc = dev_alloc(&h->seg, (size_t)L + 1))) return rc;
-        HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)L, h->stream));
-        HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), h->stream));
-        hipLaunchKernelGGL(k_tile_count, dim3(blocks_for((long long)N, 4)), dim3(256), 0, h->stream, h->edges32,
-                           h->row_ptr, h->n_rows, h->T, kTileCols, cnt, lrel, flag);
-        hipLaunchKernelGGL(k_scan_sums, dim3(nchunks), dim3(1024), 0, h->stream, cnt, L, sums);
-        hipLaunchKernelGGL(k_scan_of_sums, dim3(1), dim3(1024), 0, h->stream, sums, nchunks);
-        hipLaunchKernelGGL(k_scan_apply, dim3(nchunks), dim3(1024), 0, h->stream, cnt, L, sums, h->seg, (int)nnz);
-        int unsorted = 0;
-        HIP_TRY(hipMemcpyAsync(&unsorted, flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
-        if (!unsorted) {
-            if ((rc = dev_alloc(&h->tiled, (size_t)nnz))) return rc;
-            hipLaunchKernelGGL(k_tile_scatter, dim3(blocks_for((long long)N, 4)), dim3(256), 0, h->stream, h->edges32,
-                               h->row_ptr, h->n_rows, h->T, kTileCols, h->seg, lrel, h->tiled);
-            HIP_TRY(hipGetLastError());
+    const int tiled_opt = opt->reserved[0];  // 0 default, < 0 never, > 0 minimum K for the full-scan engines
+    const int engine = opt->reserved[2];     // 0 auto (2-D scan when applicable), 1 tiled kernel, 2 2-D scan
+    size_t Mpad = M;
+    if (h->f32 && tiled_opt >= 0 && N >= 4096) {
+        // 2-D engine: C column slices that fit the LDS, R row blocks, R * C ~ 256 workgroups
+        const int C2 = (int)std::max<size_t>(16, (M + kTileColsBig - 1) / kTileColsBig);
+        const int R2 = std::max(1, 256 / C2);
+        const int cols2 = (int)(((M + C2 - 1) / C2 + 127) / 128 * 128);
+        const int rb2 = (int)((N + R2 - 1) / R2);
+        const bool forced = engine != 0 && tiled_opt > 0;  // tests / tuning: skip the density heuristics
+        // the 2-D engine is correct but measured slower than k_bid_tiled at C3 (175 vs 135 us per full scan: one
+        // cross-lane reduction per (person, slice) segment costs more issue slots than the tile loop's refills),
+        // so it is opt-in (engine 2)
+        const bool want2d = engine == 2 && h->world == 1 && (forced || (double)nnz / ((double)N * C2) >= 4.0);
+        const int tcols = want2d ? cols2 : kTiledShapes[h->tiled_shape][4];
+        const int T = want2d ? C2 : (int)((M + tcols - 1) / tcols);
+        const int rb = want2d ? rb2 : kTileRB;
+        const long long nblk = ((long long)N + rb - 1) / rb;
+        const long long L = nblk * T * rb;
+        if ((forced || (double)nnz / ((double)N * T) >= 4.0) && L < 0x7fffffffLL) {
+            h->T = T;
+            const int nchunks = (int)((L + kScanChunk - 1) / kScanChunk);
+            int *cnt = nullptr, *lrel = nullptr, *sums = nullptr, *flag = nullptr;
+            if ((rc = dev_alloc(&cnt, (size_t)L))) return rc;
+            if ((rc = dev_alloc(&lrel, (size_t)L))) return rc;
+            if ((rc = dev_alloc(&sums, (size_t)nchunks + 1))) return rc;
+            if ((rc = dev_alloc(&flag, 1))) return rc;
+            if ((rc = dev_alloc(&h->seg, (size_t)L + 1))) return rc;
+            HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)L, h->stream));
+            HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), h->stream));
+            hipLaunchKernelGGL(k_tile_count, dim3(blocks_for((long long)N, 4)), dim3(256), 0, h->stream, h->edges32,
+                               h->row_ptr, h->n_rows, T, tcols, rb, cnt, lrel, flag);
+            hipLaunchKernelGGL(k_scan_sums, dim3(nchunks), dim3(1024), 0, h->stream, cnt, L, sums);
+            hipLaunchKernelGGL(k_scan_of_sums, dim3(1), dim3(1024), 0, h->stream, sums, nchunks);
+            hipLaunchKernelGGL(k_scan_apply, dim3(nchunks), dim3(1024), 0, h->stream, cnt, L, sums, h->seg, (int)nnz);
+            int unsorted = 0;
+            HIP_TRY(hipMemcpyAsync(&unsorted, flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(hipStreamSynchronize(h->stream));
-            h->tiled_ok = true;
-            // break-even against k_bid (cost ~ K) measured at C3: the tiled kernel has a fixed cost (tile fills,
-            // one barrier per tile) of about a fifth of a full k_bid scan
-            h->tiled_min_K = tiled_opt > 0 ? tiled_opt : (int)std::max<size_t>((N * 3) / 10, 8192);
-            static bool attr_set = false;
-            if (!attr_set) {
+            if (!unsorted) {
+                if ((rc = dev_alloc(&h->tiled, (size_t)nnz))) return rc;
+                hipLaunchKernelGGL(k_tile_scatter, dim3(blocks_for((long long)N, 4)), dim3(256), 0, h->stream,
+                                   h->edges32, h->row_ptr, h->n_rows, T, tcols, rb, h->seg, lrel, h->tiled);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipStreamSynchronize(h->stream));
+                h->tiled_ok = true;
+                // break-even against k_bid (cost ~ K) measured at C3: the full-scan engines have a fixed cost
+                // (price fills, barriers / the merge pass) of about a fifth of a full k_bid scan
+                h->tiled_min_K = tiled_opt > 0 ? tiled_opt : (int)std::max<size_t>((N * 3) / 10, 8192);
+                Mpad = (size_t)T * tcols;  // whole tiles: the LDS fills need no bounds test
                 const hipFuncAttribute at = hipFuncAttributeMaxDynamicSharedMemorySize;
+                if (want2d) {
+                    h->scan2d = true;
+                    h->s2_C = C2;
+                    h->s2_R = R2;
+                    h->s2_rb = rb2;
+                    h->s2_cols = cols2;
+                    if ((rc = dev_alloc(&h->part_v, (size_t)C2 * N))) return rc;
+                    if ((rc = dev_alloc(&h->part_w, (size_t)C2 * N))) return rc;
+                    if ((rc = dev_alloc(&h->part_g, (size_t)C2 * N))) return rc;
+                    HIP_TRY(hipFuncSetAttribute((const void *)k_scan2d<1024, 3, 4>, at, (cols2 + 2) * (int)sizeof(double)));
+                } else {
+                    static bool attr_set = false;
+                    if (!attr_set) {
 #define X(I, TH, R, B, D, TC, LD) \
     HIP_TRY(hipFuncSetAttribute((const void *)k_bid_tiled<TH, R, B, D, TC, LD>, at, (int)tiled_lds_bytes(TC)));
-                MISSLAP_FOR_TILED_SHAPES(X)
+                        MISSLAP_FOR_TILED_SHAPES(X)
 #undef X
-                attr_set = true;
+                        attr_set = true;
+                    }
+                }
+            } else {
+                (void)hipFree(h->seg);
+                h->seg = nullptr;
             }
-        } else {
-            (void)hipFree(h->seg);
-            h->seg = nullptr;
+            (void)hipFree(cnt);
+            (void)hipFree(lrel);
+            (void)hipFree(sums);
+            (void)hipFree(flag);
         }
-        (void)hipFree(cnt);
-        (void)hipFree(lrel);
-        (void)hipFree(sums);
-        (void)hipFree(flag);
     }
-    const size_t Mpad = (size_t)h->T * kTileCols;  // whole tiles: the LDS fill of k_bid_tiled needs no bounds test
     if ((rc = dev_alloc(&h->price, Mpad))) return rc;
     HIP_TRY(hipMemsetAsync(h->price, 0, sizeof(double) * Mpad, h->stream));
     if ((rc = dev_alloc(&h->rec, M))) return rc;
@@ -829,7 +892,7 @@ MISSLAP_API int misslap_finish(misslap_solver *h, int32_t *person_to_object_out,
     meta->tail_edges = c.tail_edges;
     meta->bytes_per_edge = h->f32 ? 8 : 12;
     meta->profiled = h->profile ? 1 : 0;
-    meta->tiled_active = h->tiled_ok ? 1 : 0;
+    meta->tiled_active = h->tiled_ok ? (h->scan2d ? 2 : 1) : 0;
     meta->tiled_min_K = h->tiled_min_K;
     for (int k = 0; k < 12; ++k) meta->reserved_d[k] = (double)c.dbg[k];  // stamped tail build only
     if (h->profile && h->prof_used) {
@@ -857,6 +920,9 @@ MISSLAP_API int misslap_finish(misslap_solver *h, int32_t *person_to_object_out,
                     meta->fullscan_ms += ms;
                     meta->fullscan_edges += e;
                 }
+            } else if (r.kind == 3) {
+                meta->merge_launches += 1;
+                meta->merge_ms += ms;
             } else {
                 meta->tail_launches += 1;
                 meta->tail_ms += ms;

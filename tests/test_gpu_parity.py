@@ -245,8 +245,10 @@ def test_sharded_driver_two_ranks_one_gpu(gpu_lib):
     (dict(kind="sparse", n=5000, m=5000, density=0.01, ints=6), "max"),    # heavy ties, 1 tile
     (dict(kind="sparse", n=4500, m=33000, density=0.0012, ints=3), "min"), # ties across tiles
 ])
-def test_tiled_bid_kernel_round_by_round(spec, prob, gpu_lib):
-    """k_bid_tiled (prices tiled in LDS, tile-major edge copy) forced for every grid round
+@pytest.mark.parametrize("engine", [1, 2])
+def test_tiled_bid_kernel_round_by_round(spec, prob, engine, gpu_lib):
+    """The full-scan engines -- k_bid_tiled (engine 1: prices tiled in LDS, tile loop) and k_scan2d +
+    k_merge2d (engine 2: row block x column slice, partial top-2s) -- forced for every grid round
     (tiled_min_k = 1, no tail kernel): full state vs the oracle after r rounds."""
     loc, val = cases.synth_inputs(spec)
     for r in [1, 2, 3, 5, 8, 13, 21, 40, 80, 200]:
@@ -254,9 +256,9 @@ def test_tiled_bid_kernel_round_by_round(spec, prob, gpu_lib):
         o.solve()
         so = o.state()
         g = from_sparse(loc, val.copy(), problem=prob, max_iter=r, cardinality_check=False, tail_threshold=0,
-                        tiled_min_k=1)
+                        tiled_min_k=1, engine=engine)
         g.solve()
-        assert g.gpu["tiled_active"] == 1
+        assert g.gpu["tiled_active"] == engine
         sg = g.state()
         assert sg["its"] == so["its"] and sg["K"] == so["K"], r
         assert np.array_equal(sg["U"], so["U"]), r
@@ -268,10 +270,11 @@ def test_tiled_bid_kernel_round_by_round(spec, prob, gpu_lib):
 def test_tiled_and_gather_kernels_agree_end_to_end(gpu_lib):
     loc, val = synth.gen_sparse(20000, 50000, 0.001, seed=4)
     ref = orc.auction_solve(loc=loc, val=val.copy(), problem="max", cardinality_check=False, max_iter=10**8)
-    for tk in (1, 0, -1):  # always tiled, default threshold, never tiled
-        s = from_sparse(loc, val.copy(), problem="max", cardinality_check=False, max_iter=10**8, tiled_min_k=tk)
+    for tk, eng in ((1, 1), (1, 2), (0, 0), (-1, 0)):  # always tiled / always 2-D / default / gather only
+        s = from_sparse(loc, val.copy(), problem="max", cardinality_check=False, max_iter=10**8, tiled_min_k=tk,
+                        engine=eng)
         sol = s.solve()
-        assert s.gpu["tiled_active"] == (0 if tk < 0 else 1)
+        assert s.gpu["tiled_active"] == (0 if tk < 0 else (eng or 1))
         assert np.array_equal(sol, ref["sol"]) and s.meta["its"] == ref["meta"]["its"], tk
         assert s.gpu["obj_f64"] == ref["extra"]["obj_f64"]
 

@@ -29,15 +29,15 @@ for mode in (0, 1, 2, 3, 0):
     out["bid_" + names[mode] + "_us"] = round(ms.value * 1e3, 1)
     out["bid_" + names[mode] + "_GBs"] = round(nnz * 8 / (ms.value * 1e-3) / 1e9, 1)
 # full-scan timing inside a real solve (HIP events), tiled vs gather kernel
-shapes = ["768x9x3x2h_L1", "768x9x3x3big", "1024x8x2x3big", "768x9x3x4big", "1024x8x2x2h_L2", "768x9x3x2h_L0", "1024x8x4x3big", "512x16x4x3big"]
-for tk, shape, name in [(0, k, "tiled_" + n) for k, n in enumerate(shapes)] + [(-1, 0, "gather_only")]:
+for tk, shape, eng, name in ((0, 0, 1, "tiled_768x9x3x2h_L1"), (0, 0, 2, "scan2d"), (-1, 0, 0, "gather_only")):
     st = AuctionSolver.from_device_pointers(dl.data_ptr(), dv.data_ptr(), nnz, problem="max", max_iter=10**8,
-                                            profile=1, tiled_min_k=tk, tiled_shape=shape)
+                                            profile=1, tiled_min_k=tk, tiled_shape=shape, engine=eng)
     st.solve()
     g = st.gpu
     out["solve_" + name] = dict(solve_ms=g["solve_ms"], setup_ms=g["setup_ms"], fullscan_us=1e3 * g["fullscan_ms"] / max(g["fullscan_launches"], 1),
                                 fullscan_GBs=g["fullscan_edges"] * 8 / max(g["fullscan_ms"], 1e-9) / 1e6,
                                 tiled_launches=g["tiled_launches"], tiled_ms=g["tiled_ms"], tiled_edges=g["tiled_edges"],
+                                merge_ms=g["merge_ms"], merge_launches=g["merge_launches"],
                                 bid_launches=g["bid_launches"], bid_ms=g["bid_ms"], bid_edges=g["bid_edges"], tail_ms=g["tail_ms"],
                                 grid_rounds=g["grid_rounds"], its=st.meta["its"])
 if "--tail" in sys.argv:
