@@ -25,7 +25,7 @@ namespace misslap {
 
 struct Scan2dArgs {
     const int2 *tiled;  // tile-major edges, blocks of `rb` persons x C slices
-    const int *seg;     // segment pointers
+    const int2 *seg;    // {start, real length} per segment
     int C;              // column slices
     int rb;             // persons per row block
     int slice_cols;     // prices per slice (multiple of 128)
@@ -83,8 +83,9 @@ __global__ __launch_bounds__(kThreads) void k_scan2d(RoundArgs a, Scan2dArgs sa)
             const int i = ibase + b * kGroups;
             const int ic = min(i, i1 - 1);
             const int idx = tile_idx(ic, c, C, sa.rb);
-            sg_.s0[b] = sa.seg[idx];
-            sg_.s1[b] = sa.seg[idx + 1];
+            const int2 sp = sa.seg[idx];
+            sg_.s0[b] = sp.x;
+            sg_.s1[b] = sp.x + sp.y;
             sg_.bidder[b] = (i < i1) && (a.p2o[ic] == -1);  // unassigned persons bid (auction_.pyx:339-340)
         }
         return sg_;

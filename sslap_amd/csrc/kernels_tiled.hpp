@@ -45,8 +45,11 @@ __host__ __device__ __forceinline__ int tile_idx(int person, int t, int T, int r
 // pass 1, one wavefront per person: L(i, t) = number of edges of row i with column < t * kTileCols
 // (binary search, one tile boundary per lane); cnt[idx(i,t)] = L(i,t+1) - L(i,t); also the
 // column-order check.
+// cnt = the count rounded up to an even number (every segment starts 16-byte aligned, so that a lane can
+// take two edges with one dwordx4 load); len = the real count.
 __global__ __launch_bounds__(256) void k_tile_count(const int2 *edges, const int *row_ptr, int n_rows, int T,
-                                                    int kTileCols, int rb, int *cnt, int *lrel, int *unsorted) {
+                                                    int kTileCols, int rb, int *cnt, int *len, int *lrel,
+                                                    int *unsorted) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int i = blockIdx.x * 4 + wave; i < n_rows; i += gridDim.x * 4) {
         const int s = row_ptr[i], e = row_ptr[i + 1];
@@ -86,7 +89,8 @@ __global__ __launch_bounds__(256) void k_tile_count(const int2 *edges, const int
             }
             if (t < T) {
                 const int idx = tile_idx(i, t, T, rb);
-                cnt[idx] = next_lo - lo;
+                cnt[idx] = (next_lo - lo + 1) & ~1;
+                len[idx] = next_lo - lo;
                 lrel[idx] = lo;
             }
         }
@@ -137,8 +141,7 @@ __global__ __launch_bounds__(1024) void k_scan_of_sums(int *sums, int nblocks) {
         __syncthreads();
     }
 }
-__global__ __launch_bounds__(1024) void k_scan_apply(const int *in, long long n, const int *sums, int *out,
-                                                     int total) {
+__global__ __launch_bounds__(1024) void k_scan_apply(const int *in, long long n, const int *sums, int *out) {
     __shared__ int s_w[16];
     __shared__ int s_carry;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -159,16 +162,23 @@ __global__ __launch_bounds__(1024) void k_scan_apply(const int *in, long long n,
         for (int w2 = 0; w2 < wave; ++w2) wpre += s_w[w2];
         const int carry = s_carry;
         if (k < n) out[k] = carry + wpre + x - v;
+        if (k == n - 1) out[n] = carry + wpre + x;  // one-past-the-end entry = grand total
         __syncthreads();
         if (t == 1023) s_carry = carry + wpre + x;
         __syncthreads();
     }
-    if (blockIdx.x == 0 && t == 0) out[n] = total;  // one-past-the-end entry
+}
+
+// segment table entry = {start (even), real length}
+__global__ __launch_bounds__(256) void k_pack_seg(const int *start, const int *len, long long n, int2 *seg) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride)
+        seg[k] = make_int2(start[k], len[k]);
 }
 
 // pass 3: copy every edge to its tile-major position
 __global__ __launch_bounds__(256) void k_tile_scatter(const int2 *edges, const int *row_ptr, int n_rows, int T,
-                                                      int kTileCols, int rb, const int *seg, const int *lrel,
+                                                      int kTileCols, int rb, const int *start, const int *lrel,
                                                       int2 *tiled) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int i = blockIdx.x * 4 + wave; i < n_rows; i += gridDim.x * 4) {
@@ -177,7 +187,7 @@ __global__ __launch_bounds__(256) void k_tile_scatter(const int2 *edges, const i
             const int2 x = edges[g];
             const int t = x.x / kTileCols;
             const int idx = tile_idx(i, t, T, rb);
-            tiled[seg[idx] + (g - s - lrel[idx])] = x;
+            tiled[start[idx] + (g - s - lrel[idx])] = x;
         }
     }
 }
@@ -214,12 +224,29 @@ __device__ __forceinline__ int group8_max_i32(int v) {
     return v;
 }
 
+__device__ __forceinline__ double group4_max_f64(double v) {
+    v = __builtin_fmax(v, dpp_f64<kDppXor1>(v));
+    v = __builtin_fmax(v, dpp_f64<kDppXor2>(v));
+    return v;
+}
+__device__ __forceinline__ int group4_max_i32(int v) {
+    {
+        const int o = dpp_i32<kDppXor1>(v);
+        v = o > v ? o : v;
+    }
+    {
+        const int o = dpp_i32<kDppXor2>(v);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
 struct TiledArgs {
-    const int2 *tiled;   // tile-major edges
-    const int *seg;      // segment pointers, (n_blocks * T * RB) + 1 entries
+    const int2 *tiled;   // tile-major edges, every segment starts at an even position (16-byte aligned)
+    const int2 *seg;     // {start, real length} per (person block, tile, person), n_blocks * T * RB entries
     int T;               // number of column tiles
     int min_K;           // the kernel runs only for K >= min_K (k_bid takes the smaller rounds)
-    int nnz;             // number of edges (loads of masked-off lanes are clamped to nnz - 1)
+    int nnz;             // entries of `tiled` incl. padding (loads of masked-off lanes are clamped below it)
 };
 
 // All global loads of the tile loop are UNCONDITIONAL (masked-off lanes read a clamped, valid address and
@@ -241,7 +268,7 @@ struct TiledArgs {
 // per-element arithmetic, 3 = no edge loads.
 template <int kTileThreads, int kTileRows, int kTileBatch, int kTileDepth, int kTileCols, int kLoaders, int ABL = 0>
 __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledArgs ta) {
-    constexpr int kTileGroups = (kTileThreads - kLoaders * kWave) / 8;  // the last kLoaders wavefronts only move tiles
+    constexpr int kTileGroups = (kTileThreads - kLoaders * kWave) / 4;  // 4-lane groups; loader wavefronts own none
     constexpr int kBufDoubles = kTileCols + 2;  // + the +inf slot, keeps the second buffer 16-byte aligned
     // kTileColsBig: ONE buffer (fill, barrier, look up, barrier); kTileColsHalf: two buffers, fill overlapped
     constexpr bool kDouble = kTileCols != kTileColsBig;
@@ -257,8 +284,8 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
     const int p0 = lo + (int)blockIdx.x * per_wg;
     const int p1 = min(hi, p0 + per_wg);
     if (p0 >= p1) return;  // uniform over the workgroup
-    const int t = threadIdx.x, lane = t & 63, gl = lane & 7;
-    const int group = t >> 3;
+    const int t = threadIdx.x, lane = t & 63, gl = lane & 3;
+    const int group = t >> 2;
     const double eps = (double)a.eps;
     const double ninf = -__builtin_huge_val();
     const int T = ta.T;
@@ -314,7 +341,7 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
         int s0[kTileBatch], s1[kTileBatch];
     };
     struct Edges {
-        int2 x[kTileBatch][kTileDepth];
+        int4 x[kTileBatch][kTileDepth];  // two consecutive edges per lane and load (dwordx4)
     };
     auto load_seg = [&](int tile, int b, Seg &sg_) {
         const int tl = min(tile, T - 1);
@@ -322,8 +349,9 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
         for (int jj = 0; jj < kTileBatch; ++jj) {
             const int pj = person[b * kTileBatch + jj];
             const int idx = tile_idx(pj >= 0 ? pj : 0, tl, T);
-            sg_.s0[jj] = ta.seg[idx];
-            sg_.s1[jj] = ta.seg[idx + 1];
+            const int2 sp = ta.seg[idx];
+            sg_.s0[jj] = sp.x;
+            sg_.s1[jj] = sp.x + sp.y;
         }
     };
     auto load_edges = [&](const Seg &sg_, Edges &e) {
@@ -331,8 +359,9 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
         for (int jj = 0; jj < kTileBatch; ++jj)
 #pragma unroll
             for (int d = 0; d < kTileDepth; ++d) {
-                if (ABL == 3) e.x[jj][d] = make_int2(sg_.s0[jj] & 1023, gl);
-                else e.x[jj][d] = ta.tiled[min(sg_.s0[jj] + gl + 8 * d, last)];  // (non-temporal loads measured slower)
+                if (ABL == 3) e.x[jj][d] = make_int4(sg_.s0[jj] & 1023, gl, sg_.s0[jj] & 1023, gl);
+                else  // s0 is even: 16-byte aligned; a group of 4 lanes covers 8 consecutive edges per load
+                    e.x[jj][d] = reinterpret_cast<const int4 *>(ta.tiled)[min((sg_.s0[jj] >> 1) + gl + 4 * d, last >> 1)];
             }
     };
     Seg seg_cur, seg_nxt, seg_nx2;
@@ -354,7 +383,7 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
         for (int b = 0; b < kNB; ++b) {
             // issue: edges of the next step, segment pointers of the step after it
             const int n2t = (b + 2 < kNB) ? tile : tile + 1, n2b = (b + 2) % kNB;
-            load_edges(seg_nxt, e_nxt);
+            load_edges(seg_nxt, e_nxt);  // (a prefetch distance of two steps measured no faster)
             load_seg(n2t, n2b, seg_nx2);
             if (kDouble && kLoaders == 0 && b == 0 && tile + 1 < T) dma_fill(tile + 1, wave_u, kWaves);
             // consume step (tile, b)
@@ -365,19 +394,23 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
                 const int s1 = person[j] >= 0 ? seg_cur.s1[jj] : s0;  // empty segment for an absent person
 #pragma unroll
                 for (int d = 0; d < kTileDepth; ++d) {
-                    const int2 x = e_cur.x[jj][d];
+                    const int4 x = e_cur.x[jj][d];
                     if (ABL == 2) {
-                        asm volatile("" ::"v"(x.x), "v"(x.y));  // keep the loads alive
+                        asm volatile("" ::"v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w));  // keep the loads alive
                         continue;
                     }
-                    const int q = s0 + gl + 8 * d;
-                    const bool ok = q < s1;
-                    const double pr = buf[ok ? x.x - c0 : kTileCols];          // masked-off: +inf
-                    const double v = (double)__int_as_float(x.y) - pr;          // vi = cost - p[j]   (:350)
-                    const bool ge = ok && (v >= sv[j]);                          // :351
-                    sw[j] = __builtin_fmax(sw[j], __builtin_fmin(v, sv[j]));     // :353 / :357-358
-                    sv[j] = __builtin_fmax(sv[j], v);
-                    sg[j] = ge ? q : sg[j];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int col = h ? x.z : x.x, vb = h ? x.w : x.y;
+                        const int q = s0 + 2 * gl + 8 * d + h;
+                        const bool ok = q < s1;
+                        const double pr = buf[ok ? col - c0 : kTileCols];            // masked-off: +inf
+                        const double v = (double)__int_as_float(vb) - pr;             // vi = cost - p[j]   (:350)
+                        const bool ge = ok && (v >= sv[j]);                           // :351
+                        sw[j] = __builtin_fmax(sw[j], __builtin_fmin(v, sv[j]));      // :353 / :357-358
+                        sv[j] = __builtin_fmax(sv[j], v);
+                        sg[j] = ge ? q : sg[j];
+                    }
                 }
             }
             // segments longer than 8 * kTileDepth edges: wave-uniform loop with the loads of the whole batch
@@ -387,7 +420,7 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
                 bool more = false;
 #pragma unroll
                 for (int jj = 0; jj < kTileBatch; ++jj) {
-                    qx[jj] = seg_cur.s0[jj] + gl + 8 * kTileDepth;
+                    qx[jj] = seg_cur.s0[jj] + gl + 8 * kTileDepth;  // one edge per lane and pass from here on
                     s1x[jj] = person[b * kTileBatch + jj] >= 0 ? seg_cur.s1[jj] : seg_cur.s0[jj];
                     more |= qx[jj] < s1x[jj];
                 }
@@ -406,7 +439,7 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
                         sw[j] = __builtin_fmax(sw[j], __builtin_fmin(v, sv[j]));
                         sv[j] = __builtin_fmax(sv[j], v);
                         sg[j] = ge ? qx[jj] : sg[j];
-                        qx[jj] += 8;
+                        qx[jj] += 4;
                         more |= qx[jj] < s1x[jj];
                     }
                 }
@@ -425,9 +458,9 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
     bool mine[kTileRows];
 #pragma unroll
     for (int j = 0; j < kTileRows; ++j) {
-        const double V = group8_max_f64(sv[j]);
-        const int G = group8_max_i32(sv[j] == V ? sg[j] : -1);
-        W[j] = group8_max_f64(sg[j] == G ? sw[j] : sv[j]);
+        const double V = group4_max_f64(sv[j]);
+        const int G = group4_max_i32(sv[j] == V ? sg[j] : -1);
+        W[j] = group4_max_f64(sg[j] == G ? sw[j] : sv[j]);
         mine[j] = person[j] >= 0 && sg[j] == G && G >= 0;  // exactly one lane of the group
         const int pj = max(person[j], 0);
         best[j] = ta.tiled[max(G, 0)];                     // unconditional loads, used under `mine`

@@ -65,13 +65,13 @@ constexpr int kNumTiledShapes = 8;
 // launch shapes of k_bid_tiled: {threads, persons per 8-lane group, persons in flight, loads per segment,
 // prices per LDS tile}; see kernels_tiled.hpp
 const int kTiledShapes[kNumTiledShapes][6] = {
-    {768, 9, 3, 2, kTileColsHalf, 1},  {768, 9, 3, 3, kTileColsBig, 0},  {1024, 8, 2, 3, kTileColsBig, 0},
-    {768, 9, 3, 4, kTileColsBig, 0},   {1024, 8, 2, 2, kTileColsHalf, 2}, {768, 9, 3, 2, kTileColsHalf, 0},
-    {1024, 8, 4, 3, kTileColsBig, 0},  {512, 16, 4, 3, kTileColsBig, 0}};
-#define MISSLAP_FOR_TILED_SHAPES(X)                                                                                \
-    X(0, 768, 9, 3, 2, kTileColsHalf, 1) X(1, 768, 9, 3, 3, kTileColsBig, 0) X(2, 1024, 8, 2, 3, kTileColsBig, 0)   \
-    X(3, 768, 9, 3, 4, kTileColsBig, 0) X(4, 1024, 8, 2, 2, kTileColsHalf, 2) X(5, 768, 9, 3, 2, kTileColsHalf, 0)  \
-    X(6, 1024, 8, 4, 3, kTileColsBig, 0) X(7, 512, 16, 4, 3, kTileColsBig, 0)
+    {1024, 4, 2, 2, kTileColsHalf, 1}, {1024, 4, 2, 2, kTileColsHalf, 0}, {1024, 4, 2, 3, kTileColsBig, 0},
+    {768, 5, 1, 2, kTileColsHalf, 1},  {768, 6, 3, 2, kTileColsHalf, 1},  {1024, 4, 1, 2, kTileColsHalf, 1},
+    {1024, 4, 2, 3, kTileColsHalf, 1}, {512, 8, 4, 2, kTileColsHalf, 1}};
+#define MISSLAP_FOR_TILED_SHAPES(X)                                                                                  \
+    X(0, 1024, 4, 2, 2, kTileColsHalf, 1) X(1, 1024, 4, 2, 2, kTileColsHalf, 0) X(2, 1024, 4, 2, 3, kTileColsBig, 0)  \
+    X(3, 768, 5, 1, 2, kTileColsHalf, 1) X(4, 768, 6, 3, 2, kTileColsHalf, 1) X(5, 1024, 4, 1, 2, kTileColsHalf, 1)    \
+    X(6, 1024, 4, 2, 3, kTileColsHalf, 1) X(7, 512, 8, 4, 2, kTileColsHalf, 1)
 inline size_t tiled_lds_bytes(int tile_cols) {
     return (tile_cols == kTileColsBig ? 1 : 2) * (size_t)(tile_cols + 2) * sizeof(double);
 }
@@ -113,7 +113,8 @@ struct misslap_solver {
     int launch_edges_cap = 0;
     // tile-major second copy of the edges for k_bid_tiled (kernels_tiled.hpp)
     int2 *tiled = nullptr;
-    int *seg = nullptr;
+    int2 *seg = nullptr;
+    int n_tiled = 0;  // entries of `tiled` including the padding entries
     int T = 0;
     bool tiled_ok = false;
     int tiled_min_K = 0;
@@ -213,13 +214,13 @@ int launch_bid_tiled(misslap_solver *h) {
     RoundArgs a = round_args(h);
     const long long share = ((long long)h->K_ub + h->world - 1) / h->world;
     const int *shp = kTiledShapes[h->tiled_shape];
-    const int groups = (shp[0] - 64 * shp[5]) / 8;  // loader wavefronts own no persons
+    const int groups = (shp[0] - 64 * shp[5]) / 4;  // 4-lane groups; loader wavefronts own no persons
     const int per_wg_max = groups * shp[1];
     long long grid = (share + per_wg_max - 1) / per_wg_max;
     const long long resident = 256;  // one workgroup per CU: its two price tiles take the whole LDS
     const long long spread = std::min<long long>(resident, (share + groups - 1) / groups);
     if (grid < spread) grid = spread;
-    TiledArgs ta{h->tiled, h->seg, h->T, h->tiled_min_K, (int)h->nnz};
+    TiledArgs ta{h->tiled, h->seg, h->T, h->tiled_min_K, h->n_tiled};
     ProfRec *pr = nullptr;
     if (h->profile) {
         if (h->launch_idx >= h->launch_edges_cap)
@@ -246,7 +247,7 @@ int launch_bid_tiled(misslap_solver *h) {
 
 int launch_bid_scan2d(misslap_solver *h) {
     RoundArgs a = round_args(h);
-    Scan2dArgs sa{h->tiled, h->seg, h->s2_C, h->s2_rb, h->s2_cols, h->tiled_min_K, (int)h->nnz,
+    Scan2dArgs sa{h->tiled, h->seg, h->s2_C, h->s2_rb, h->s2_cols, h->tiled_min_K, h->n_tiled,
                   h->part_v, h->part_w, h->part_g};
     ProfRec *pr = nullptr, *pm = nullptr;
     if (h->profile) {
@@ -478,26 +479,33 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
         if ((forced || (double)nnz / ((double)N * T) >= 4.0) && L < 0x7fffffffLL) {
             h->T = T;
             const int nchunks = (int)((L + kScanChunk - 1) / kScanChunk);
-            int *cnt = nullptr, *lrel = nullptr, *sums = nullptr, *flag = nullptr;
+            int *cnt = nullptr, *len = nullptr, *lrel = nullptr, *start = nullptr, *sums = nullptr, *flag = nullptr;
             if ((rc = dev_alloc(&cnt, (size_t)L))) return rc;
+            if ((rc = dev_alloc(&len, (size_t)L))) return rc;
             if ((rc = dev_alloc(&lrel, (size_t)L))) return rc;
+            if ((rc = dev_alloc(&start, (size_t)L + 1))) return rc;
             if ((rc = dev_alloc(&sums, (size_t)nchunks + 1))) return rc;
             if ((rc = dev_alloc(&flag, 1))) return rc;
-            if ((rc = dev_alloc(&h->seg, (size_t)L + 1))) return rc;
             HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)L, h->stream));
+            HIP_TRY(hipMemsetAsync(len, 0, sizeof(int) * (size_t)L, h->stream));
             HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), h->stream));
             hipLaunchKernelGGL(k_tile_count, dim3(blocks_for((long long)N, 4)), dim3(256), 0, h->stream, h->edges32,
-                               h->row_ptr, h->n_rows, T, tcols, rb, cnt, lrel, flag);
+                               h->row_ptr, h->n_rows, T, tcols, rb, cnt, len, lrel, flag);
             hipLaunchKernelGGL(k_scan_sums, dim3(nchunks), dim3(1024), 0, h->stream, cnt, L, sums);
             hipLaunchKernelGGL(k_scan_of_sums, dim3(1), dim3(1024), 0, h->stream, sums, nchunks);
-            hipLaunchKernelGGL(k_scan_apply, dim3(nchunks), dim3(1024), 0, h->stream, cnt, L, sums, h->seg, (int)nnz);
-            int unsorted = 0;
+            hipLaunchKernelGGL(k_scan_apply, dim3(nchunks), dim3(1024), 0, h->stream, cnt, L, sums, start);
+            int unsorted = 0, total = 0;
             HIP_TRY(hipMemcpyAsync(&unsorted, flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipMemcpyAsync(&total, start + L, sizeof(int), hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(hipStreamSynchronize(h->stream));
-            if (!unsorted) {
-                if ((rc = dev_alloc(&h->tiled, (size_t)nnz))) return rc;
+            if (!unsorted && total > 0) {
+                h->n_tiled = total;
+                if ((rc = dev_alloc(&h->tiled, (size_t)total + 16))) return rc;
+                if ((rc = dev_alloc(&h->seg, (size_t)L))) return rc;
+                HIP_TRY(hipMemsetAsync(h->tiled, 0, sizeof(int2) * ((size_t)total + 16), h->stream));
                 hipLaunchKernelGGL(k_tile_scatter, dim3(blocks_for((long long)N, 4)), dim3(256), 0, h->stream,
-                                   h->edges32, h->row_ptr, h->n_rows, T, tcols, rb, h->seg, lrel, h->tiled);
+                                   h->edges32, h->row_ptr, h->n_rows, T, tcols, rb, start, lrel, h->tiled);
+                hipLaunchKernelGGL(k_pack_seg, dim3(blocks_for(L, 256)), dim3(256), 0, h->stream, start, len, L, h->seg);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipStreamSynchronize(h->stream));
                 h->tiled_ok = true;
@@ -526,12 +534,11 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
                         attr_set = true;
                     }
                 }
-            } else {
-                (void)hipFree(h->seg);
-                h->seg = nullptr;
             }
             (void)hipFree(cnt);
+            (void)hipFree(len);
             (void)hipFree(lrel);
+            (void)hipFree(start);
             (void)hipFree(sums);
             (void)hipFree(flag);
         }
@@ -990,22 +997,22 @@ MISSLAP_API int misslap_debug_time_bid(misslap_solver *h, int32_t mode, int32_t 
         if (!h->tiled_ok || h->tiled_shape != 0) return fail(MISSLAP_ERR_STATE, "tiled ablations need tiled_shape 0");
         const hipFuncAttribute at = hipFuncAttributeMaxDynamicSharedMemorySize;
         const int ldsb = (int)tiled_lds_bytes(kTileColsHalf);
-        HIP_TRY(hipFuncSetAttribute((const void *)k_bid_tiled<768, 9, 3, 2, kTileColsHalf, 1, 1>, at, ldsb));
-        HIP_TRY(hipFuncSetAttribute((const void *)k_bid_tiled<768, 9, 3, 2, kTileColsHalf, 1, 2>, at, ldsb));
-        HIP_TRY(hipFuncSetAttribute((const void *)k_bid_tiled<768, 9, 3, 2, kTileColsHalf, 1, 3>, at, ldsb));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 1, 1>, at, ldsb));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 1, 2>, at, ldsb));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 1, 3>, at, ldsb));
         RoundArgs a = round_args(h);
         a.launch_edges = nullptr;
-        TiledArgs ta{h->tiled, h->seg, h->T, 1, (int)h->nnz};
+        TiledArgs ta{h->tiled, h->seg, h->T, 1, h->n_tiled};
         hipEvent_t t0, t1;
         HIP_TRY(hipEventCreate(&t0));
         HIP_TRY(hipEventCreate(&t1));
         auto launch_t = [&]() {
-            const dim3 g(256), b(768);
+            const dim3 g(256), b(1024);
             switch (mode) {
-                case 10: hipLaunchKernelGGL((k_bid_tiled<768, 9, 3, 2, kTileColsHalf, 1, 0>), g, b, ldsb, h->stream, a, ta); break;
-                case 11: hipLaunchKernelGGL((k_bid_tiled<768, 9, 3, 2, kTileColsHalf, 1, 1>), g, b, ldsb, h->stream, a, ta); break;
-                case 12: hipLaunchKernelGGL((k_bid_tiled<768, 9, 3, 2, kTileColsHalf, 1, 2>), g, b, ldsb, h->stream, a, ta); break;
-                default: hipLaunchKernelGGL((k_bid_tiled<768, 9, 3, 2, kTileColsHalf, 1, 3>), g, b, ldsb, h->stream, a, ta); break;
+                case 10: hipLaunchKernelGGL((k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 1, 0>), g, b, ldsb, h->stream, a, ta); break;
+                case 11: hipLaunchKernelGGL((k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 1, 1>), g, b, ldsb, h->stream, a, ta); break;
+                case 12: hipLaunchKernelGGL((k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 1, 2>), g, b, ldsb, h->stream, a, ta); break;
+                default: hipLaunchKernelGGL((k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 1, 3>), g, b, ldsb, h->stream, a, ta); break;
             }
         };
         launch_t();
