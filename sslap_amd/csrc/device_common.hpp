@@ -292,35 +292,45 @@ __device__ __forceinline__ void wave_bid_rec(const E &ed, const PriceRec *rec, i
         }
         stamp(2);  // records landed
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (c[u] >= 0) {
-                if (c[u] == patch_col) r[u] = patch;
-                const double v = a[u] - r[u].price;  // vi = cost - p[j]   (:350)
-                if (v >= x.v) {                      // :351
-                    x.w = x.v;
-                    x.v = v;
-                    x.g = base + u * kWave + lane;
-                    c1 = c[u];
-                    a1 = a[u];
-                    o1 = r[u].owner;
-                    os1 = r[u].ostart;
-                } else if (v > x.w) {                // :357
-                    x.w = v;
-                }
-            }
+        for (int u = 0; u < 4; ++u) {  // branch-free: a masked-off element has value -inf and changes nothing
+            const bool ok = c[u] >= 0;
+            if (c[u] == patch_col) r[u] = patch;
+            const double v = ok ? a[u] - r[u].price : ninf;  // vi = cost - p[j]   (:350)
+            const bool ge = ok && (v >= x.v);                 // :351
+            x.w = __builtin_fmax(x.w, __builtin_fmin(v, x.v));  // :353 / :357-358
+            x.v = __builtin_fmax(x.v, v);
+            x.g = ge ? base + u * kWave + lane : x.g;
+            c1 = ge ? c[u] : c1;
+            a1 = ge ? a[u] : a1;
+            o1 = ge ? r[u].owner : o1;
+            os1 = ge ? r[u].ostart : os1;
         }
     }
-    const int g_mine = x.g;
-    x = top2_wave_reduce(x);
+    // Winner first: if exactly one lane holds the largest HIGH WORD of the per-lane best values, that lane
+    // holds the row's best element (no tie is possible), so one 32-bit wave maximum replaces the 64-bit value
+    // and index passes; only the second-best value still needs a 64-bit reduction.
+    const int hi = __double2hiint(x.v);
+    const int k = hi ^ ((hi >> 31) & 0x7fffffff);  // signed order of k == order of the doubles' high words
+    const int kmax = wave_max_i32(k);
+    const unsigned long long cand = __ballot(k == kmax);
+    int src;
+    double W;
+    if (__popcll(cand) == 1) {  // wave-uniform
+        src = __ffsll((long long)cand) - 1;
+        W = wave_max_f64(lane == src ? x.w : x.v);
+    } else {
+        const int g_mine = x.g;
+        const Top2 t2 = top2_wave_reduce(x);
+        src = __ffsll((long long)__ballot(g_mine == t2.g)) - 1;
+        W = t2.w;
+    }
     stamp(3);
-    const unsigned long long ownerm = __ballot(g_mine == x.g);
-    const int src = __ffsll((long long)ownerm) - 1;
     const int col = __builtin_amdgcn_readlane(c1, src);
     const double cost = readlane_f64(a1, src);
     prev = __builtin_amdgcn_readlane(o1, src);
     pstart = __builtin_amdgcn_readlane(os1, src);
     stamp(4);
-    const double bid = (cost - x.w) + eps;  // bbest = costbest - wi + eps   (:360)
+    const double bid = (cost - W) + eps;  // bbest = costbest - wi + eps   (:360)
     if (!(bid >= 0.0)) err |= kErrNegativeBid;
     key = bid_to_key(bid);
     obj = col;

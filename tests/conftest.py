@@ -47,5 +47,8 @@ def golden_large():
 @pytest.fixture(scope="session")
 def gpu_lib():
     """The loaded HIP library; fails (not skips) when it is missing -- gpu tests must run native code."""
-    from sslap_amd import _lib
+    from sslap_amd import _lib, build
+    import shutil
+    if build.stale() and (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        build.build()  # in-tree build of the product library (never a fallback: without it the tests fail)
     return _lib.load()
