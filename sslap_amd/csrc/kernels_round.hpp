@@ -250,6 +250,70 @@ __global__ __launch_bounds__(256) void k_compact_fill(RoundArgs a) {
         a.U[a.hole_list[k]] = a.mover_list[k];  // data[left_track] = i   (:158)
 }
 
+// push_all_left + round end in ONE launch for moderate K: a single 1024-thread workgroup walks U[0,K) in
+// chunks (block scan with a running carry), writes the two lists, fills, and closes the round.  Replaces four
+// launches (count, scatter, fill, round_end) -- most grid rounds have K of a few hundred to a few thousand
+// and are bound by launch boundaries, not by work.  The host uses it while K_ub <= kCompactSmallMax.
+constexpr int kCompactSmallMax = 32768;
+__global__ __launch_bounds__(1024) void k_compact_small(RoundArgs a) {
+    Ctl *ctl = a.ctl;
+    if (!round_live(ctl, a.thr)) return;
+    const int K = ctl->K, nholes = ctl->nholes, Kn = K - nholes;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    __shared__ int s_wl[16], s_wm[16];
+    __shared__ int s_cl, s_cm;
+    if (nholes > 0) {
+        if (t == 0) {
+            s_cl = 0;
+            s_cm = 0;
+        }
+        __syncthreads();
+        for (int base = 0; base < K; base += 1024) {
+            const int n = base + t;
+            int u = -1;
+            if (n < K) u = a.U[n];
+            const bool isl = (n < Kn) && (u == -1);
+            const bool ism = (n >= Kn) && (n < K) && (u != -1);
+            const unsigned long long bl = __ballot(isl), bm = __ballot(ism);
+            if (lane == 0) {
+                s_wl[wave] = __popcll(bl);
+                s_wm[wave] = __popcll(bm);
+            }
+            __syncthreads();
+            int wl = 0, wm = 0, tl = 0, tm = 0;
+            for (int w2 = 0; w2 < 16; ++w2) {
+                if (w2 < wave) {
+                    wl += s_wl[w2];
+                    wm += s_wm[w2];
+                }
+                tl += s_wl[w2];
+                tm += s_wm[w2];
+            }
+            const int cl = s_cl, cm = s_cm;
+            if (isl) a.hole_list[cl + wl + __popcll(bl & lanemask_lt())] = n;
+            if (ism) {
+                a.mover_list[cm + wm + __popcll(bm & lanemask_lt())] = u;
+                a.U[n] = -1;  // data[right_track] = -1   (:159)
+            }
+            __syncthreads();
+            if (t == 0) {
+                s_cl = cl + tl;
+                s_cm = cm + tm;
+            }
+            __syncthreads();
+        }
+        const int nl = s_cl;  // left holes == movers
+        for (int k = t; k < nl; k += 1024) a.U[a.hole_list[k]] = a.mover_list[k];  // data[left_track] = i   (:158)
+    }
+    if (t == 0) {
+        ctl->K = Kn;  // :429
+        ctl->nholes = 0;
+        ctl->nleft = 0;
+        ctl->nits += 1;  // :273
+        ctl->grid_rounds += 1;
+    }
+}
+
 __global__ void k_round_end(RoundArgs a) {
     Ctl *ctl = a.ctl;
     if (!round_live(ctl, a.thr)) return;

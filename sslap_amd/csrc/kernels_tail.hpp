@@ -62,7 +62,9 @@ __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
     __shared__ unsigned long long sKey[kTailMax];
     __shared__ int sObj[kTailMax];
     __shared__ int sPrev[kTailMax];
-    __shared__ int sStart[kTailMax];  // row_ptr of the bidder (for the record of the object it may win)
+    __shared__ int sStart[kTailMax];  // row start of the person in slot n, kept next to sU: evicted owners bring
+                                      // theirs with the price record, so no row_ptr load precedes a row fetch
+    __shared__ int sPst[kTailMax];    // row start of the owner of the object slot n bid on
     __shared__ int sList[kTailMax];
     __shared__ int hObj[kHashSize];
     __shared__ unsigned long long hKey[kHashSize];
@@ -81,6 +83,7 @@ __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
     const int K0 = K;
     const long long nits0 = nits;
     sU[t] = (t < K) ? a.U[t] : -1;
+    sStart[t] = (t < K) ? a.row_ptr[sU[t]] : 0;
     for (int h = t; h < kHashSize; h += kTailMax) {
         hObj[h] = -1;
         hKey[h] = 0ull;
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
             // price records of its columns, and row_ptr[i+1] in parallel with the edges.
             if (wave == 0) {
                 int i = sU[0];
-                int s = a.row_ptr[i];
+                int s = sStart[0];
                 int patch_col = -1;
                 PriceRec patch;
                 patch.price = 0.0;
@@ -157,7 +160,10 @@ __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
                     i = prev;  // the evicted owner inherits the slot (:409) and bids next
                     s = pstart;
                     if (nits >= max_iter) {
-                        if (lane == 0) sU[0] = i;
+                        if (lane == 0) {
+                            sU[0] = i;
+                            sStart[0] = s;
+                        }
                         break;
                     }
                 }
@@ -173,7 +179,7 @@ __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
         }
         for (int n = wave; n < K; n += nwaves) {
             const int i = sU[n];
-            const int s = a.row_ptr[i];
+            const int s = sStart[n];
             unsigned long long key;
             int obj, prev, pstart, e;
             PriceRec nopatch;
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
                 // owner at the start of the round == what the assignment phase reads (:401): the record of
                 // obj is only rewritten by this round's winner of obj, after every bid has been made.
                 sPrev[n] = prev;
-                sStart[n] = s;
+                sPst[n] = pstart;
             }
             if (STAMP) {
                 CycleStamp cs{st2, &t_prev2, wave == 0};
@@ -215,28 +221,49 @@ __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
                 const int obj = act ? sObj[lane] : (-2 - lane);
                 bool lose = false;
                 for (int m = 0; m < K; ++m) {  // RESOLVE (:375-385): K <= 64 all-pairs via readlane
-                    const unsigned long long km = readlane_u64(key, m);
                     const int om = __builtin_amdgcn_readlane(obj, m);
-                    lose |= (om == obj) && (km > key || (km == key && m < lane));
+                    const bool same = (om == obj) && (m != lane);
+                    if (__any(same)) {  // wave-uniform; two bidders on one object are the exception
+                        const unsigned long long km = readlane_u64(key, m);
+                        lose |= same && (km > key || (km == key && m < lane));
+                    }
                 }
                 int u = act ? sU[lane] : -1;
-                if (act && !lose) u = apply_winner(a, u, sStart[lane], obj, sPrev[lane], key);
+                int st = act ? sStart[lane] : 0;  // row start travelling with the slot's person
+                if (act && !lose) {
+                    u = apply_winner(a, u, st, obj, sPrev[lane], key);
+                    st = sPst[lane];
+                }
                 // push_all_left with ballots
                 const unsigned long long kmask = (K >= 64) ? ~0ull : ((1ull << K) - 1ull);
                 const unsigned long long holes = __ballot(act && u == -1) & kmask;
                 const int Kn = K - __popcll(holes);
                 const unsigned long long lmask = (Kn >= 64) ? ~0ull : ((1ull << Kn) - 1ull);
                 const unsigned long long hl = holes & lmask;            // empty slots left of K'
-                const unsigned long long mv = ~holes & ~lmask & kmask;  // persons right of K'
-                const bool is_hl = (hl >> lane) & 1ull, is_mv = (mv >> lane) & 1ull;
-                if (is_hl) sList[__popcll(hl & lanemask_lt())] = lane;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (is_mv) sU[sList[__popcll(mv & lanemask_lt())]] = u;
-                if (act) {
-                    if (lane >= Kn) sU[lane] = -1;
-                    else if (!is_hl) sU[lane] = u;
+                if (hl == 0ull) {  // wave-uniform: nothing to move (no hole, or only holes at the end)
+                    if (act) {
+                        sU[lane] = (lane < Kn) ? u : -1;
+                        sStart[lane] = st;
+                    }
+                } else {
+                    const unsigned long long mv = ~holes & ~lmask & kmask;  // persons right of K'
+                    const bool is_hl = (hl >> lane) & 1ull, is_mv = (mv >> lane) & 1ull;
+                    if (is_hl) sList[__popcll(hl & lanemask_lt())] = lane;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (is_mv) {
+                        const int dst = sList[__popcll(mv & lanemask_lt())];
+                        sU[dst] = u;
+                        sStart[dst] = st;
+                    }
+                    if (act) {
+                        if (lane >= Kn) sU[lane] = -1;
+                        else if (!is_hl) {
+                            sU[lane] = u;
+                            sStart[lane] = st;
+                        }
+                    }
                 }
                 if (lane == 0) sK = Kn;
             }
@@ -267,7 +294,11 @@ __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
                 hPos[h] = kPosNone;
             }
             int u = act ? sU[t] : -1;
-            if (win) u = apply_winner(a, u, sStart[t], obj, sPrev[t], key);
+            int st = act ? sStart[t] : 0;
+            if (win) {
+                u = apply_winner(a, u, st, obj, sPrev[t], key);
+                st = sPst[t];
+            }
             const bool hole = act && u == -1;
             const unsigned long long bh = __ballot(hole);
             if (lane == 0) sCnt[0][wave] = __popcll(bh);
@@ -290,10 +321,16 @@ __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
             }
             if (is_hl) sList[pl] = t;
             __syncthreads();
-            if (is_mv) sU[sList[pm]] = u;
+            if (is_mv) {
+                sU[sList[pm]] = u;
+                sStart[sList[pm]] = st;
+            }
             if (act) {
                 if (t >= Kn) sU[t] = -1;
-                else if (!is_hl) sU[t] = u;
+                else if (!is_hl) {
+                    sU[t] = u;
+                    sStart[t] = st;
+                }
             }
             if (t == 0) sK = Kn;
         }

@@ -323,11 +323,15 @@ int launch_apply(misslap_solver *h) {
     h->K_exact = false;
     RoundArgs a = round_args(h);
     hipLaunchKernelGGL(k_apply, dim3(blocks_for(h->n_cols, 256)), dim3(256), 0, h->stream, a);
-    const int cb = blocks_for(h->K_ub, kChunk);
-    hipLaunchKernelGGL(k_compact_count, dim3(cb), dim3(256), 0, h->stream, a);
-    hipLaunchKernelGGL(k_compact_scatter, dim3(cb), dim3(256), 0, h->stream, a);
-    hipLaunchKernelGGL(k_compact_fill, dim3(blocks_for(h->K_ub, 256)), dim3(256), 0, h->stream, a);
-    hipLaunchKernelGGL(k_round_end, dim3(1), dim3(1), 0, h->stream, a);
+    if (h->K_ub <= kCompactSmallMax) {
+        hipLaunchKernelGGL(k_compact_small, dim3(1), dim3(1024), 0, h->stream, a);
+    } else {
+        const int cb = blocks_for(h->K_ub, kChunk);
+        hipLaunchKernelGGL(k_compact_count, dim3(cb), dim3(256), 0, h->stream, a);
+        hipLaunchKernelGGL(k_compact_scatter, dim3(cb), dim3(256), 0, h->stream, a);
+        hipLaunchKernelGGL(k_compact_fill, dim3(blocks_for(h->K_ub, 256)), dim3(256), 0, h->stream, a);
+        hipLaunchKernelGGL(k_round_end, dim3(1), dim3(1), 0, h->stream, a);
+    }
     HIP_TRY(hipGetLastError());
     return MISSLAP_OK;
 }
