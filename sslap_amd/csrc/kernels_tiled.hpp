@@ -24,6 +24,10 @@
 #include "device_common.hpp"
 #include "kernels_round.hpp"
 
+#ifndef MISSLAP_TILED_NT
+#define MISSLAP_TILED_NT 0
+#endif
+
 namespace misslap {
 
 // prices per LDS tile (a multiple of 128 = one 1-KB LDS-DMA piece):
@@ -272,6 +276,7 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
     constexpr int kBufDoubles = kTileCols + 2;  // + the +inf slot, keeps the second buffer 16-byte aligned
     // kTileColsBig: ONE buffer (fill, barrier, look up, barrier); kTileColsHalf: two buffers, fill overlapped
     constexpr bool kDouble = kTileCols != kTileColsBig;
+    constexpr bool kNT = MISSLAP_TILED_NT;  // edge loads non-temporal (keeps the price tiles in L2?)
     static_assert(kDouble || kLoaders == 0, "the single-buffer variant has no loader wavefronts");
     static_assert(kTileRows % kTileBatch == 0 && kTileRows / kTileBatch >= 2, "ROWS = BATCH * (>= 2 steps)");
     extern __shared__ __attribute__((aligned(16))) double s_price[];  // 2 * kBufDoubles
@@ -361,7 +366,13 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
             for (int d = 0; d < kTileDepth; ++d) {
                 if (ABL == 3) e.x[jj][d] = make_int4(sg_.s0[jj] & 1023, gl, sg_.s0[jj] & 1023, gl);
                 else  // s0 is even: 16-byte aligned; a group of 4 lanes covers 8 consecutive edges per load
-                    e.x[jj][d] = reinterpret_cast<const int4 *>(ta.tiled)[min((sg_.s0[jj] >> 1) + gl + 4 * d, last >> 1)];
+                {
+                    typedef int v4i_t __attribute__((ext_vector_type(4)));
+                    const v4i_t y = kNT ? __builtin_nontemporal_load(reinterpret_cast<const v4i_t *>(ta.tiled) +
+                                                                     min((sg_.s0[jj] >> 1) + gl + 4 * d, last >> 1))
+                                        : reinterpret_cast<const v4i_t *>(ta.tiled)[min((sg_.s0[jj] >> 1) + gl + 4 * d, last >> 1)];
+                    e.x[jj][d] = make_int4(y.x, y.y, y.z, y.w);
+                }
             }
     };
     Seg seg_cur, seg_nxt, seg_nx2;
