@@ -201,43 +201,45 @@ __device__ __forceinline__ void wave_bid(const E &ed, const double *price, int s
         int c[4];
         double a[4], pr[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int g = base + u * kWave + lane;
-            c[u] = -1;
-            a[u] = 0.0;
-            if (g < e) ed.load(g, c[u], a[u]);
-        }
+        for (int u = 0; u < 4; ++u) ed.load(min(base + u * kWave + lane, e - 1), c[u], a[u]);  // unconditional
         stamp(1);  // edges landed
 #pragma unroll
-        for (int u = 0; u < 4; ++u) pr[u] = (c[u] >= 0) ? price[c[u]] : 0.0;
+        for (int u = 0; u < 4; ++u) pr[u] = price[c[u]];
         stamp(2);  // prices landed
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (c[u] >= 0) {
-                const double v = a[u] - pr[u];  // vi = cost - p[j]   (:350)
-                if (v >= x.v) {                 // :351
-                    x.w = x.v;
-                    x.v = v;
-                    x.g = base + u * kWave + lane;
-                    c1 = c[u];
-                    a1 = a[u];
-                } else if (v > x.w) {           // :357
-                    x.w = v;
-                }
-            }
+        for (int u = 0; u < 4; ++u) {  // branch-free: a masked-off element has value -inf and changes nothing
+            const int g = base + u * kWave + lane;
+            const bool ok = g < e;
+            const double v = ok ? a[u] - pr[u] : ninf;           // vi = cost - p[j]   (:350)
+            const bool ge = ok && (v >= x.v);                     // :351
+            x.w = __builtin_fmax(x.w, __builtin_fmin(v, x.v));    // :353 / :357-358
+            x.v = __builtin_fmax(x.v, v);
+            x.g = ge ? g : x.g;
+            c1 = ge ? c[u] : c1;
+            a1 = ge ? a[u] : a1;
         }
     }
-    const int g_mine = x.g;
-    x = top2_wave_reduce(x);
+    // winner first (see wave_bid_rec): a single lane holding the largest high word holds the row's best
+    const int hi = __double2hiint(x.v);
+    const int k = hi ^ ((hi >> 31) & 0x7fffffff);
+    const int kmax = wave_max_i32(k);
+    const unsigned long long cand = __ballot(k == kmax);
+    int src;
+    double W;
+    if (__popcll(cand) == 1) {  // wave-uniform
+        src = __ffsll((long long)cand) - 1;
+        W = wave_max_f64(lane == src ? x.w : x.v);
+    } else {
+        const int g_mine = x.g;
+        const Top2 t2 = top2_wave_reduce(x);
+        src = __ffsll((long long)__ballot(g_mine == t2.g)) - 1;
+        W = t2.w;
+    }
     stamp(3);  // reduction done
-    // the lane whose own best element is the row's best holds its column and cost (every row has
-    // at least one entry, so exactly one lane matches)
-    const unsigned long long owner = __ballot(g_mine == x.g);
-    const int src = __ffsll((long long)owner) - 1;
     const int col = __builtin_amdgcn_readlane(c1, src);
     const double cost = readlane_f64(a1, src);
     stamp(4);
-    const double bid = (cost - x.w) + eps;  // bbest = costbest - wi + eps   (:360)
+    const double bid = (cost - W) + eps;  // bbest = costbest - wi + eps   (:360)
     if (!(bid >= 0.0)) err |= kErrNegativeBid;
     key = bid_to_key(bid);
     obj = col;
