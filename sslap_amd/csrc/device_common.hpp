@@ -255,16 +255,16 @@ struct __attribute__((aligned(16))) PriceRec {
     int ostart;  // row_ptr[owner] (undefined when owner == -1)
 };
 
-// wave_bid with the record gather.  (patch_col, patch): the record of one object may be overridden with a
-// value the caller holds in registers (the object it has just re-priced), so that the result never
-// depends on how fast the wavefront's own store becomes visible to its next loads.  `e_late` may arrive
-// after the edge loads have been issued: the first four 64-edge chunks are loaded unconditionally (the
-// edge arrays are padded) and masked with the row end afterwards.
+// wave_bid with the record gather.  The row end (*e_ptr) may arrive after the edge loads have been issued:
+// the first four 64-edge chunks are loaded unconditionally (the edge arrays are padded) and masked with the
+// row end afterwards.  Ordering against the caller's own stores of the previous round (chain mode): the
+// records are gathered only after the edge loads have returned, the edge loads were issued after those
+// stores, and a wavefront's vector memory operations complete in issue order -- so the stores have been
+// written before any record is read (the same CU-level coherence the barrier-separated rounds rely on).
 template <class E, class S = NoStamp>
 __device__ __forceinline__ void wave_bid_rec(const E &ed, const PriceRec *rec, int s, const int *e_ptr, double eps,
-                                             int patch_col, const PriceRec &patch, unsigned long long &key,
-                                             int &obj, int &prev, int &pstart, int &row_end, int &err,
-                                             const S &stamp = S()) {
+                                             unsigned long long &key, int &obj, int &prev, int &pstart,
+                                             int &row_end, int &err, const S &stamp = S()) {
     const int lane = threadIdx.x & (kWave - 1);
     const double ninf = -__builtin_huge_val();
     Top2 x;
@@ -296,7 +296,6 @@ __device__ __forceinline__ void wave_bid_rec(const E &ed, const PriceRec *rec, i
 #pragma unroll
         for (int u = 0; u < 4; ++u) {  // branch-free: a masked-off element has value -inf and changes nothing
             const bool ok = c[u] >= 0;
-            if (c[u] == patch_col) r[u] = patch;
             const double v = ok ? a[u] - r[u].price : ninf;  // vi = cost - p[j]   (:350)
             const bool ge = ok && (v >= x.v);                 // :351
             x.w = __builtin_fmax(x.w, __builtin_fmin(v, x.v));  // :353 / :357-358

@@ -115,11 +115,6 @@ __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
             if (wave == 0) {
                 int i = sU[0];
                 int s = sStart[0];
-                int patch_col = -1;
-                PriceRec patch;
-                patch.price = 0.0;
-                patch.owner = -1;
-                patch.ostart = 0;
                 for (;;) {
                     unsigned long long key;
                     int obj, prev, pstart, e;
@@ -127,27 +122,15 @@ __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
                         CycleStamp cs{st2, &t_prev2, true};
                         cs(15);
                         cs(0);
-                        wave_bid_rec(ed, a.rec, s, a.row_ptr + i + 1, eps, patch_col, patch, key, obj, prev, pstart, e,
-                                     err, cs);
+                        wave_bid_rec(ed, a.rec, s, a.row_ptr + i + 1, eps, key, obj, prev, pstart, e, err, cs);
                     } else {
-                        wave_bid_rec(ed, a.rec, s, a.row_ptr + i + 1, eps, patch_col, patch, key, obj, prev, pstart, e,
-                                     err);
+                        wave_bid_rec(ed, a.rec, s, a.row_ptr + i + 1, eps, key, obj, prev, pstart, e, err);
                     }
                     edges += (unsigned long long)(e - s);
                     bids += 1;
                     nits += 1;
                     // ASSIGN (:396-418): the single bidder always wins
-                    patch.price = key_to_bid(key);
-                    patch.owner = i;
-                    patch.ostart = s;
-                    patch_col = obj;
-                    if (lane == 0) {
-                        a.rec[obj] = patch;
-                        a.price[obj] = patch.price;
-                        a.o2p[obj] = i;
-                        a.p2o[i] = obj;
-                        if (prev != -1) a.p2o[prev] = -1;
-                    }
+                    if (lane == 0) apply_winner(a, i, s, obj, prev, key);
                     if (STAMP) {
                         CycleStamp cs{st2, &t_prev2, true};
                         cs(5);
@@ -182,17 +165,13 @@ __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
             const int s = sStart[n];
             unsigned long long key;
             int obj, prev, pstart, e;
-            PriceRec nopatch;
-            nopatch.price = 0.0;
-            nopatch.owner = -1;
-            nopatch.ostart = 0;
             if (STAMP) {
                 CycleStamp cs{st2, &t_prev2, wave == 0};
                 cs(15);  // (re)arm
                 cs(0);   // row pointers landed
-                wave_bid_rec(ed, a.rec, s, a.row_ptr + i + 1, eps, -1, nopatch, key, obj, prev, pstart, e, err, cs);
+                wave_bid_rec(ed, a.rec, s, a.row_ptr + i + 1, eps, key, obj, prev, pstart, e, err, cs);
             } else {
-                wave_bid_rec(ed, a.rec, s, a.row_ptr + i + 1, eps, -1, nopatch, key, obj, prev, pstart, e, err);
+                wave_bid_rec(ed, a.rec, s, a.row_ptr + i + 1, eps, key, obj, prev, pstart, e, err);
             }
             if (lane == 0) {
                 sKey[n] = key;
