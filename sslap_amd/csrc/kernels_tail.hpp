@@ -36,7 +36,10 @@ __device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v,
     return ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo;
 }
 
-// assignment of one winner (auction_.pyx:396-418); returns the new content of its U slot
+// assignment of one winner (auction_.pyx:396-418); returns the new content of its U slot.  Inside the tail
+// kernel the price record is the ONLY copy that is kept current: one 16-byte store per winner instead of
+// five scattered ones, and price[] / o2p[] / p2o[] lines stay out of the CU's L2 working set.  k_sync_price /
+// k_sync_p2o rebuild the three plain arrays from the records when the kernel has finished.
 __device__ __forceinline__ int apply_winner(const TailArgs &a, int person, int pstart, int obj, int prev,
                                             unsigned long long key) {
     PriceRec r;
@@ -44,14 +47,21 @@ __device__ __forceinline__ int apply_winner(const TailArgs &a, int person, int p
     r.owner = person;
     r.ostart = pstart;
     a.rec[obj] = r;
-    a.price[obj] = r.price;
-    a.o2p[obj] = person;
-    a.p2o[person] = obj;
-    if (prev != -1) {
-        a.p2o[prev] = -1;
-        return prev;  // evicted owner inherits the slot (:409)
+    return prev;  // evicted owner inherits the slot (:409); -1 = hole (:412)
+}
+
+// After the tail kernel: price[j], o2p[j] from the records; p2o rebuilt as the inverse of o2p.
+__global__ __launch_bounds__(256) void k_sync_clear_p2o(int *p2o, int n_rows) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_rows; i += gridDim.x * blockDim.x) p2o[i] = -1;
+}
+__global__ __launch_bounds__(256) void k_sync_from_rec(const PriceRec *rec, double *price, int *o2p, int *p2o,
+                                                       int n_cols) {
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n_cols; j += gridDim.x * blockDim.x) {
+        const PriceRec r = rec[j];
+        price[j] = r.price;
+        o2p[j] = r.owner;
+        if (r.owner >= 0) p2o[r.owner] = j;
     }
-    return -1;        // hole (:412)
 }
 
 // STAMP = diagnostic build: wavefront 0 accumulates s_memtime deltas of the four segments of a round

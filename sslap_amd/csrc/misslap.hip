@@ -364,6 +364,10 @@ int launch_tail(misslap_solver *h) {
         else hipLaunchKernelGGL((k_tail<EdgesF64, false>), dim3(1), dim3(kTailMax), 0, h->stream, a, ed);
     }
     if (pr) HIP_TRY(hipEventRecord(pr->stop, h->stream));
+    // the tail keeps only the price records current: rebuild price / o2p / p2o from them
+    hipLaunchKernelGGL(k_sync_clear_p2o, dim3(blocks_for(h->n_rows, 256)), dim3(256), 0, h->stream, h->p2o, h->n_rows);
+    hipLaunchKernelGGL(k_sync_from_rec, dim3(blocks_for(h->n_cols, 256)), dim3(256), 0, h->stream, h->rec, h->price,
+                       h->o2p, h->p2o, h->n_cols);
     HIP_TRY(hipGetLastError());
     h->phase_fresh = false;
     return MISSLAP_OK;
