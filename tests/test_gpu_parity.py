@@ -287,3 +287,25 @@ def test_unsorted_rows_fall_back_to_gather_kernel(gpu_lib):
     sol = s.solve()
     assert s.gpu["tiled_active"] == 0  # in-row order is the tie rule: no tile-major copy for unsorted rows
     assert np.array_equal(sol, ref["sol"])
+
+
+def test_integration_md_binding_stub_works(gpu_lib):
+    """The reference-side ctypes binding printed in INTEGRATION.md (what a maintainer of the reference would
+    add) is executed verbatim against the built library."""
+    import os
+    import re
+    from sslap_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(# sslap/misslap_binding.py.*?)```", text, re.S).group(1)
+    code = code.replace('C.CDLL("libmisslap.so")', f'C.CDLL({_lib.LIB_PATH!r})')
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    loc, val = synth.gen_sparse(800, 800, 0.03, seed=9)
+    for prob in ("max", "min"):
+        solver = ns["_from_sparse"](loc, val.copy(), problem=prob, cardinality_check=False)
+        sol = solver.solve()
+        ref = orc.auction_solve(loc=loc, val=val.copy(), problem=prob, cardinality_check=False)
+        assert np.array_equal(sol, ref["sol"])
+        for k in ("its", "nreductions", "eCE", "soln_found", "n_assigned", "obj", "final_eps", "start_eps"):
+            assert solver.meta[k] == ref["meta"][k], k
