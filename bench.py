@@ -82,10 +82,14 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # one rank per GPU; MISSLAP_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsal of the
+    # multi-rank path on a single-GPU box; RCCL needs a GPU per rank)
+    backend = os.environ.get("MISSLAP_DIST_BACKEND", "nccl")
+    local_rank = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
 
     def barrier():
         if world > 1:

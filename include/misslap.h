@@ -108,6 +108,8 @@ typedef struct misslap_status {
     int32_t error_bits;   /* device-side invariant violations (0 = none) */
     int32_t tail_threshold;   /* effective value (library default resolved) */
     int32_t rounds_per_sync;  /* effective value */
+    int32_t shard_min_K;      /* multi-GPU: rounds with K >= this are sharded + exchanged, smaller ones replicated */
+    int32_t reserved;
 } misslap_status;
 
 /* ---- construction: replaces AuctionSolver.__init__ (auction_.pyx:202-265) as reached through
@@ -140,7 +142,9 @@ int misslap_solve(misslap_solver *h, int32_t *person_to_object_out, misslap_meta
 
 /* ---- stepwise interface (multi-GPU driver, round-level parity tests).  One grid round is
  *   misslap_round_bid      bid phase (auction_.pyx:339-365) over this shard's bidders + per-object
- *                          maximum of the shard's bids (first half of :375-385)
+ *                          maximum of the shard's bids (first half of :375-385).  Only rounds with
+ *                          K >= status.shard_min_K are sharded (and need the two exchanges); in smaller
+ *                          rounds every rank bids for every list position and no exchange is needed.
  *   [exchange: all-reduce MAX over the best-key buffer, see misslap_exchange_buffers]
  *   misslap_round_tiebreak earliest bidder in list order wins equal bids (strict '>' of :379)
  *   [exchange: all-reduce MIN over the best-position buffer]

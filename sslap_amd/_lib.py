@@ -43,6 +43,7 @@ class Status(C.Structure):
         ("its", C.c_int64), ("K", C.c_int32), ("nreductions", C.c_int32), ("eps", C.c_float),
         ("target_eps", C.c_float), ("finished", C.c_int32), ("error_bits", C.c_int32),
         ("tail_threshold", C.c_int32), ("rounds_per_sync", C.c_int32),
+        ("shard_min_K", C.c_int32), ("reserved", C.c_int32),
     ]
 
 

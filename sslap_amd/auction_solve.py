@@ -129,6 +129,7 @@ class AuctionSolver:
         self.num_rows, self.num_cols, self.nnz = n.value, m.value, z.value
         st = self.status()
         self.tail_threshold, self.rounds_per_sync = int(st.tail_threshold), int(st.rounds_per_sync)
+        self.shard_min_K = int(st.shard_min_K)
         self.meta = {"start_eps": round(float(st.eps), 3)}  # auction_.pyx:264
         self.gpu = {}
 

@@ -32,6 +32,7 @@ struct RoundArgs {
     int n_rows, n_cols;
     int thr;                      // tail threshold
     int rank, world;              // bidder shard
+    int shard_min_K;              // shard only rounds with K >= this (multi-GPU), see shard_range
     float eps;
     int launch_idx;
     int gather_max_K;             // k_bid runs only for K < gather_max_K (k_bid_tiled takes the rest); 0 = no limit
@@ -40,7 +41,15 @@ struct RoundArgs {
 __device__ __forceinline__ bool round_live(const Ctl *c, int thr) {
     return c->K > thr && c->K > 0 && c->nits < c->max_iter;
 }
-__device__ __forceinline__ void shard_range(int K, int rank, int world, int &lo, int &hi) {
+// Bidders of a round are sharded over the ranks only while K >= shard_min_K (the few big rounds where the
+// bid phase is bandwidth-bound); below that every rank bids for everybody -- the replicas stay identical
+// without any exchange, and a per-round all-reduce would cost more than the round.
+__device__ __forceinline__ void shard_range(int K, int rank, int world, int shard_min_K, int &lo, int &hi) {
+    if (K < shard_min_K) {
+        lo = 0;
+        hi = K;
+        return;
+    }
     lo = (int)(((long long)K * rank) / world);
     hi = (int)(((long long)K * (rank + 1)) / world);
 }
@@ -52,7 +61,7 @@ __global__ __launch_bounds__(kBidBlock) void k_bid(RoundArgs a, E ed) {
     if (!round_live(ctl, a.thr)) return;
     if (a.gather_max_K > 0 && ctl->K >= a.gather_max_K) return;
     int lo, hi;
-    shard_range(ctl->K, a.rank, a.world, lo, hi);
+    shard_range(ctl->K, a.rank, a.world, a.shard_min_K, lo, hi);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wpb = kBidBlock / kWave;
     const double eps = (double)a.eps;  // float promoted to double, auction_.pyx:360
@@ -99,7 +108,7 @@ __global__ __launch_bounds__(256) void k_tiebreak(RoundArgs a) {
     const Ctl *ctl = a.ctl;
     if (!round_live(ctl, a.thr)) return;
     int lo, hi;
-    shard_range(ctl->K, a.rank, a.world, lo, hi);
+    shard_range(ctl->K, a.rank, a.world, a.shard_min_K, lo, hi);
     for (int n = lo + blockIdx.x * blockDim.x + threadIdx.x; n < hi; n += gridDim.x * blockDim.x) {
         const int j = a.bid_obj[n];
         if (a.bid_key[n] == a.best_key[j]) atomicMin(&a.best_pos[j], n);

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void k_merge2d(RoundArgs a, Scan2dArgs sa) {
     const Ctl *ctl = a.ctl;
     if (!round_live(ctl, a.thr) || ctl->K < sa.min_K) return;
     int lo, hi;
-    shard_range(ctl->K, a.rank, a.world, lo, hi);
+    shard_range(ctl->K, a.rank, a.world, a.shard_min_K, lo, hi);
     const double eps = (double)a.eps;
     const double ninf = -__builtin_huge_val();
     unsigned long long edges = 0;

@@ -283,7 +283,7 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
     const Ctl *ctl = a.ctl;
     if (!round_live(ctl, a.thr) || ctl->K < ta.min_K) return;
     int lo, hi;
-    shard_range(ctl->K, a.rank, a.world, lo, hi);
+    shard_range(ctl->K, a.rank, a.world, a.shard_min_K, lo, hi);
     // this workgroup's slice of list positions
     const int per_wg = (hi - lo + (int)gridDim.x - 1) / (int)gridDim.x;
     const int p0 = lo + (int)blockIdx.x * per_wg;

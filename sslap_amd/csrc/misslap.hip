@@ -133,6 +133,7 @@ struct misslap_solver {
     int thr = kDefaultTailThreshold;
     int rounds_per_sync = kDefaultRoundsPerSync;
     int rank = 0, world = 1;
+    int shard_min_K = 0;  // multi-GPU: only rounds with K >= this are sharded and exchanged
     bool profile = false;
     bool stamp = false;  // profile == 2: stamped (diagnostic) tail kernel
     int K_ub = 0;  // host-side upper bound of K (K never grows inside a phase)
@@ -174,6 +175,7 @@ RoundArgs round_args(misslap_solver *h) {
     a.thr = h->thr;
     a.rank = h->rank;
     a.world = h->world;
+    a.shard_min_K = h->world > 1 ? h->shard_min_K : 0;
     a.eps = h->eps;
     a.launch_idx = 0;
     a.gather_max_K = h->tiled_ok ? h->tiled_min_K : 0;
@@ -286,7 +288,7 @@ int launch_bid(misslap_solver *h) {
     }
     h->K_exact = false;
     RoundArgs a = round_args(h);
-    const long long share = ((long long)h->K_ub + h->world - 1) / h->world;
+    const long long share = h->K_ub;  // upper bound: unsharded rounds bid for every list position
     const int grid = blocks_for(share, kBidBlock / kWave);
     ProfRec *pr = nullptr;
     if (h->profile) {
@@ -313,7 +315,7 @@ int launch_bid(misslap_solver *h) {
 
 int launch_tiebreak(misslap_solver *h) {
     RoundArgs a = round_args(h);
-    const long long share = ((long long)h->K_ub + h->world - 1) / h->world;
+    const long long share = h->K_ub;
     hipLaunchKernelGGL(k_tiebreak, dim3(blocks_for(share, 256)), dim3(256), 0, h->stream, a);
     HIP_TRY(hipGetLastError());
     return MISSLAP_OK;
@@ -573,6 +575,7 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
         if ((rc = dev_alloc(&h->launch_edges, (size_t)h->launch_edges_cap))) return rc;
         HIP_TRY(hipMemsetAsync(h->launch_edges, 0, sizeof(unsigned long long) * h->launch_edges_cap, h->stream));
     }
+    h->shard_min_K = h->tiled_ok ? h->tiled_min_K : (int)std::max<size_t>((N * 3) / 10, 8192);
     h->max_iter = opt->max_iter < 1 ? 1 : opt->max_iter;  // the loop body runs before the first test (:271-275)
     hipLaunchKernelGGL(k_init_state, dim3(blocks_for((long long)(N > M ? N : M), 256)), dim3(256), 0, h->stream,
                        h->ctl, h->price, h->rec, h->p2o, h->o2p, h->U, h->best_key, h->best_pos, h->n_rows, h->n_cols,
@@ -812,6 +815,7 @@ MISSLAP_API int misslap_get_status(misslap_solver *h, misslap_status *st) {
     st->finished = h->finished ? 1 : 0;
     st->tail_threshold = h->thr;
     st->rounds_per_sync = h->rounds_per_sync;
+    st->shard_min_K = h->shard_min_K;
     return rc;
 }
 

@@ -12,9 +12,11 @@ the only exchange step of a round is the per-object arg-max of the bids (auction
     round_apply     assignment + list compaction, run redundantly -- and deterministically -- by every
                     rank, which is what keeps the replicas identical (this *is* the price broadcast)
 
-Rounds with few bidders (K <= tail threshold; > 98 % of all rounds) run inside the persistent tail kernel
-on every rank redundantly, with no communication: a dense all-reduce per tiny round would cost far more
-than the round.  The driver is written against a small backend interface so that its control flow and
+Only the big rounds (K >= shard_min_K = 0.3 N: a handful per eps-phase, where the bid phase is a
+bandwidth-bound CSR scan) are sharded and exchanged.  All smaller rounds are replicated: every rank bids for
+every list position (grid kernels) or runs the persistent tail kernel (K <= tail threshold; > 98 % of all
+rounds), with no communication -- a dense all-reduce per small round would cost far more than the round, and
+the replicas stay bit-identical because every step is deterministic.  The driver is written against a small backend interface so that its control flow and
 collective sequence are covered by world_size-2 `gloo` tests on CPU tensors (tests/test_dist_gloo.py).
 """
 import torch
@@ -34,6 +36,7 @@ class GpuBackend:
         solver.set_stream(torch.cuda.current_stream().cuda_stream)
         self.thr = solver.tail_threshold
         self.rounds_per_sync = solver.rounds_per_sync
+        self.shard_min_K = solver.shard_min_K
 
     def status(self):
         st = self.s.status()
@@ -88,14 +91,22 @@ def solve_sharded(solver_or_backend, group=None):
             K, its = b.status()
             if K == 0 or its >= b.max_iter:
                 break
-            if K > b.thr:
+            if K >= b.shard_min_K and K > b.thr:
+                # a big round: bidders sharded over the ranks, per-object arg-max exchanged (K is exact here,
+                # so the device-side decision "K >= shard_min_K" is the same on every rank)
+                b.round_bid()
+                if multi:
+                    dist.all_reduce(b.best_key, op=dist.ReduceOp.MAX, group=group)
+                b.round_tiebreak()
+                if multi:
+                    dist.all_reduce(b.best_pos, op=dist.ReduceOp.MIN, group=group)
+                b.round_apply()
+            elif K > b.thr:
+                # K never grows inside a phase: from here on every rank bids for everybody (replicated,
+                # deterministic), no exchange; several rounds per status read
                 for _ in range(b.rounds_per_sync):
                     b.round_bid()
-                    if multi:
-                        dist.all_reduce(b.best_key, op=dist.ReduceOp.MAX, group=group)
                     b.round_tiebreak()
-                    if multi:
-                        dist.all_reduce(b.best_pos, op=dist.ReduceOp.MIN, group=group)
                     b.round_apply()
             else:
                 b.run_tail()

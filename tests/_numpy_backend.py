@@ -9,7 +9,8 @@ POS_NONE = np.int32(0x7FFFFFFF)
 
 
 class NumpyBackend:
-    def __init__(self, loc, val, problem, rank, world, max_iter=10**8, eps_start=0.0, thr=0, rounds_per_sync=2):
+    def __init__(self, loc, val, problem, rank, world, max_iter=10**8, eps_start=0.0, thr=0, rounds_per_sync=2,
+                 shard_min_K=0):
         loc = loc.astype(np.int32)
         self.N, self.M = int(loc[:, 0].max()) + 1, int(loc[:, 1].max()) + 1
         self.row_ptr = np.searchsorted(loc[:, 0], np.arange(self.N + 1)).astype(np.int64)
@@ -29,6 +30,7 @@ class NumpyBackend:
         self.K, self.its, self.nreductions = self.N, 0, 0
         self.max_iter = max(1, int(max_iter))
         self.rank, self.world, self.thr, self.rounds_per_sync = rank, world, thr, rounds_per_sync
+        self.shard_min_K = shard_min_K
         self.best_key = torch.zeros(self.M, dtype=torch.int64)
         self.best_pos = torch.full((self.M,), int(POS_NONE), dtype=torch.int32)
         self._bk, self._bp = self.best_key.numpy(), self.best_pos.numpy()  # shared memory views
@@ -41,6 +43,8 @@ class NumpyBackend:
         return self.K, self.its
 
     def _shard(self):
+        if self.K < self.shard_min_K:  # small rounds are replicated, not sharded
+            return 0, self.K
         return (self.K * self.rank) // self.world, (self.K * (self.rank + 1)) // self.world
 
     def round_bid(self):

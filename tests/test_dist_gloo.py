@@ -19,7 +19,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, spec, prob, max_iter, out):
+def _worker(rank, world, port, spec, prob, max_iter, shard_min_K, out):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
@@ -31,26 +31,28 @@ def _worker(rank, world, port, spec, prob, max_iter, out):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     loc, val = cases.synth_inputs(spec)
-    b = NumpyBackend(loc, val, prob, rank, world, max_iter=max_iter)
+    b = NumpyBackend(loc, val, prob, rank, world, max_iter=max_iter, shard_min_K=shard_min_K)
     sol = solve_sharded(b)
     out.put((rank, sol.tolist(), b.its, b.nreductions, b.p.tobytes()))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("spec,prob,max_iter", [
-    (dict(kind="sparse", n=64, m=64, density=0.1), "max", 10**8),
-    (dict(kind="sparse", n=60, m=60, density=0.15, ints=3), "max", 10**8),   # cross-rank equal bids
-    (dict(kind="sparse", n=40, m=60, density=0.2), "min", 10**8),            # rectangular
-    (dict(kind="sparse", n=64, m=64, density=0.1), "max", 7),                # stops at max_iter
+@pytest.mark.parametrize("spec,prob,max_iter,shard_min_K", [
+    (dict(kind="sparse", n=64, m=64, density=0.1), "max", 10**8, 0),            # every round exchanged
+    (dict(kind="sparse", n=60, m=60, density=0.15, ints=3), "max", 10**8, 0),   # cross-rank equal bids
+    (dict(kind="sparse", n=40, m=60, density=0.2), "min", 10**8, 0),            # rectangular
+    (dict(kind="sparse", n=64, m=64, density=0.1), "max", 7, 0),                # stops at max_iter
+    (dict(kind="sparse", n=64, m=64, density=0.1), "max", 10**8, 20),           # big rounds sharded, rest replicated
+    (dict(kind="sparse", n=60, m=60, density=0.15, ints=3), "min", 10**8, 30),
 ])
-def test_sharded_driver_world2_matches_oracle(spec, prob, max_iter):
+def test_sharded_driver_world2_matches_oracle(spec, prob, max_iter, shard_min_K):
     import cases
     from oracle import oracle as orc
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, spec, prob, max_iter, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, spec, prob, max_iter, shard_min_K, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=240) for _ in procs)
