@@ -134,12 +134,14 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        # a rank counts the bids of its own shard in exchanged rounds plus the (replicated) tail rounds:
-        # unique work = sum over ranks of the sharded part + the tail once
-        tail_e = sum(g["tail_edges"] for _, g in runs)
-        e = torch.tensor([sum(g["edges_scanned"] for _, g in runs) - tail_e], dtype=torch.int64, device="cuda")
+        # a rank counts the bids of its own shard in the exchanged (sharded) rounds plus all bids of the
+        # replicated rounds, which every rank repeats: unique work = sum over ranks of the sharded part + the
+        # replicated part ONCE (redundant scans are not throughput)
+        sh = sum(g["shard_edges"] for _, g in runs)
+        repl = sum(g["edges_scanned"] for _, g in runs) - sh
+        e = torch.tensor([sh], dtype=torch.int64, device="cuda")
         dist.all_reduce(e, op=dist.ReduceOp.SUM)
-        edges_all = int(e.item()) + tail_e
+        edges_all = int(e.item()) + repl
     else:
         edges_all = sum(g["edges_scanned"] for _, g in runs)
 

@@ -50,7 +50,9 @@ typedef struct misslap_options {
     int32_t rounds_per_sync; /* grid rounds enqueued between host status reads; <= 0 = default */
     int32_t reserved[8];     /* [0]: LDS-tiled bid kernel: 0 = default threshold, < 0 = never, > 0 = minimum K;
                                 [1]: launch shape of k_bid_tiled (tuning knob, see misslap.hip:kTiledShapes);
-                                [2]: full-scan engine: 0 / 1 k_bid_tiled (default), 2 k_scan2d + k_merge2d (experimental) */
+                                [2]: full-scan engine: 0 / 1 k_bid_tiled (default), 2 k_scan2d + k_merge2d (experimental);
+                                [3]: multi-GPU shard threshold: 0 = default (the full-scan threshold, 0.3 N), > 0 = minimum K
+                                     of a sharded round, < 0 = shard every grid round */
 } misslap_options;
 
 /* Result block of misslap_finish: the reference's `meta` dict (auction_.pyx:264,:297-304)
@@ -94,7 +96,9 @@ typedef struct misslap_meta {
     int32_t tiled_min_K;         /* rounds with K >= this use it */
     int64_t merge_launches;      /* k_merge2d */
     double merge_ms;
-    double reserved_d[12];       /* diagnostic cycle counters of the stamped tail build */
+    uint64_t shard_edges;        /* multi-GPU: edges scanned in sharded rounds (this rank's share); the rest of
+                                    edges_scanned is replicated work, identical on every rank */
+    double reserved_d[11];       /* diagnostic cycle counters of the stamped tail build */
 } misslap_meta;
 
 /* Snapshot of the round state (tests / multi-GPU driver). */

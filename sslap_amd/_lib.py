@@ -34,7 +34,7 @@ class Meta(C.Structure):
         ("tiled_launches", C.c_int64), ("tiled_ms", C.c_double), ("tiled_edges", C.c_uint64),
         ("tiled_active", C.c_int32), ("tiled_min_K", C.c_int32),
         ("merge_launches", C.c_int64), ("merge_ms", C.c_double),
-        ("reserved_d", C.c_double * 12),
+        ("shard_edges", C.c_uint64), ("reserved_d", C.c_double * 11),
     ]
 
 

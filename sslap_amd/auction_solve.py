@@ -26,7 +26,7 @@ _ENV_TILED = "MISSLAP_TILED_MIN_K"  # 0 default, < 0 never use the LDS-tiled bid
 
 
 def _options(problem, eps_start, max_iter, device=None, tail_threshold=None, profile=None, force_f64=False,
-             input_on_device=False, shard=None, rounds_per_sync=None, tiled_min_k=None, tiled_shape=None,
+             input_on_device=False, shard=None, rounds_per_sync=None, tiled_min_k=None, tiled_shape=None, shard_min_k=None,
              engine=None):
     if problem not in ("min", "max"):
         # the reference treats every string other than 'min' as 'max' (auction_.pyx:236, :502)
@@ -47,6 +47,7 @@ def _options(problem, eps_start, max_iter, device=None, tail_threshold=None, pro
     o.reserved[0] = int(os.environ.get(_ENV_TILED, 0)) if tiled_min_k is None else int(tiled_min_k)
     o.reserved[1] = int(os.environ.get("MISSLAP_TILED_SHAPE", 0)) if tiled_shape is None else int(tiled_shape)
     o.reserved[2] = int(os.environ.get("MISSLAP_ENGINE", 0)) if engine is None else int(engine)
+    o.reserved[3] = int(os.environ.get("MISSLAP_SHARD_MIN_K", 0)) if shard_min_k is None else int(shard_min_k)
     return o
 
 
@@ -165,7 +166,7 @@ class AuctionSolver:
         g = dict(obj_f64=float(m.obj_f64), edges_scanned=int(m.edges_scanned), bids_made=int(m.bids_made),
                  grid_rounds=int(m.grid_rounds), tail_rounds=int(m.tail_rounds), bytes_per_edge=int(m.bytes_per_edge),
                  setup_ms=float(m.setup_ms), solve_ms=float(m.solve_ms), final_eps_f32=float(m.final_eps),
-                 start_eps_f32=float(m.start_eps), tail_edges=int(m.tail_edges),
+                 start_eps_f32=float(m.start_eps), tail_edges=int(m.tail_edges), shard_edges=int(m.shard_edges),
                  tiled_active=int(m.tiled_active), tiled_min_K=int(m.tiled_min_K))
         if m.profiled:
             g["tail_stamp_cycles"] = [float(x) for x in m.reserved_d]

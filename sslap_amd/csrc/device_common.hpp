@@ -44,6 +44,7 @@ struct Ctl {
     long long grid_rounds;
     long long tail_rounds;
     unsigned long long tail_edges;
+    unsigned long long shard_edges;  // edges scanned in sharded rounds (multi-GPU: this rank's share only)
     double obj;            // objective accumulator (auction_.pyx:491)
     unsigned long long dbg[16]; // diagnostic cycle counters of the stamped tail build (profile == 2)
 };

@@ -98,6 +98,7 @@ __global__ __launch_bounds__(kBidBlock) void k_bid(RoundArgs a, E ed) {
         }
         if (tb) {
             atomicAdd(&a.ctl->edges, te);
+            if (a.world > 1 && a.ctl->K >= a.shard_min_K) atomicAdd(&a.ctl->shard_edges, te);
             atomicAdd(&a.ctl->bids, (unsigned long long)tb);
             if (a.launch_edges) atomicAdd(&a.launch_edges[a.launch_idx], te);
         }

@@ -233,6 +233,7 @@ __global__ __launch_bounds__(256) void k_merge2d(RoundArgs a, Scan2dArgs sa) {
         const int tb = s_n[0] + s_n[1] + s_n[2] + s_n[3];
         if (tb) {
             atomicAdd(&a.ctl->edges, te);
+            if (a.world > 1 && a.ctl->K >= a.shard_min_K) atomicAdd(&a.ctl->shard_edges, te);
             atomicAdd(&a.ctl->bids, (unsigned long long)tb);
             if (a.launch_edges) atomicAdd(&a.launch_edges[a.launch_idx], te);
         }

@@ -516,6 +516,7 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
         }
         if (tb) {
             atomicAdd(&a.ctl->edges, te);
+            if (a.world > 1 && a.ctl->K >= a.shard_min_K) atomicAdd(&a.ctl->shard_edges, te);
             atomicAdd(&a.ctl->bids, (unsigned long long)tb);
             if (a.launch_edges) atomicAdd(&a.launch_edges[a.launch_idx], te);
         }

@@ -214,7 +214,10 @@ int read_ctl(misslap_solver *h) {
 
 int launch_bid_tiled(misslap_solver *h) {
     RoundArgs a = round_args(h);
-    const long long share = ((long long)h->K_ub + h->world - 1) / h->world;
+    // K_ub is only an upper bound unless the host has just read K: the device decides sharded / replicated from
+    // the exact K, so the smaller sharded grid is used only when the host knows the same K
+    const bool sharded = h->world > 1 && h->K_exact && h->K_ub >= h->shard_min_K;
+    const long long share = sharded ? ((long long)h->K_ub + h->world - 1) / h->world : h->K_ub;
     const int *shp = kTiledShapes[h->tiled_shape];
     const int groups = (shp[0] - 64 * shp[5]) / 4;  // 4-lane groups; loader wavefronts own no persons
     const int per_wg_max = groups * shp[1];
@@ -576,6 +579,8 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
         HIP_TRY(hipMemsetAsync(h->launch_edges, 0, sizeof(unsigned long long) * h->launch_edges_cap, h->stream));
     }
     h->shard_min_K = h->tiled_ok ? h->tiled_min_K : (int)std::max<size_t>((N * 3) / 10, 8192);
+    if (opt->reserved[3] > 0) h->shard_min_K = opt->reserved[3];
+    if (opt->reserved[3] < 0) h->shard_min_K = 0;  // every grid round sharded + exchanged
     h->max_iter = opt->max_iter < 1 ? 1 : opt->max_iter;  // the loop body runs before the first test (:271-275)
     hipLaunchKernelGGL(k_init_state, dim3(blocks_for((long long)(N > M ? N : M), 256)), dim3(256), 0, h->stream,
                        h->ctl, h->price, h->rec, h->p2o, h->o2p, h->U, h->best_key, h->best_pos, h->n_rows, h->n_cols,
@@ -913,7 +918,8 @@ MISSLAP_API int misslap_finish(misslap_solver *h, int32_t *person_to_object_out,
     meta->profiled = h->profile ? 1 : 0;
     meta->tiled_active = h->tiled_ok ? (h->scan2d ? 2 : 1) : 0;
     meta->tiled_min_K = h->tiled_min_K;
-    for (int k = 0; k < 12; ++k) meta->reserved_d[k] = (double)c.dbg[k];  // stamped tail build only
+    meta->shard_edges = c.shard_edges;
+    for (int k = 0; k < 11; ++k) meta->reserved_d[k] = (double)c.dbg[k];  // stamped tail build only
     if (h->profile && h->prof_used) {
         std::vector<unsigned long long> le((size_t)h->launch_idx);
         if (h->launch_idx)

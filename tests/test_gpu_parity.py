@@ -187,6 +187,12 @@ def test_device_resident_input(gpu_lib):
     assert torch.equal(dv.cpu(), torch.from_numpy(val))  # device input untouched
 
 
+# (n, density, seed, integer values, tail threshold, shard_min_k): every grid round sharded / a mix of sharded
+# and replicated rounds / library default (nothing sharded at this size) / the LDS-tiled kernel sharded
+_DIST_GPU_CASES = ((1500, 0.02, 1, 0, 0, -1), (1500, 0.02, 2, 4, 8, 300), (1500, 0.02, 3, 0, None, None),
+                   (30000, 0.002, 4, 0, None, None))
+
+
 def _dist_gpu_worker(rank, world, port, out):
     import os
     import sys
@@ -201,12 +207,13 @@ def _dist_gpu_worker(rank, world, port, out):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     res = []
-    for seed, ints, thr in ((1, 0, 0), (2, 4, 8), (3, 0, None)):
-        loc, val = synth.gen_sparse(1500, 1500, 0.02, seed=seed, integer_values=ints)
+    for n, dens, seed, ints, thr, smk in _DIST_GPU_CASES:
+        loc, val = synth.gen_sparse(n, n, dens, seed=seed, integer_values=ints)
         s = from_sparse(loc, val, problem="max", cardinality_check=False, shard=(rank, world), tail_threshold=thr,
-                        max_iter=10**8)
+                        max_iter=10**8, shard_min_k=smk)
         sol = solve_sharded(s)
-        res.append((sol.tolist(), s.meta["its"], s.meta["nreductions"], s.gpu["obj_f64"]))
+        res.append((sol.tolist(), s.meta["its"], s.meta["nreductions"], s.gpu["obj_f64"],
+                    s.gpu["edges_scanned"], s.gpu["shard_edges"]))
     out.put((rank, res))
     dist.barrier()
     dist.destroy_process_group()
@@ -231,13 +238,23 @@ def test_sharded_driver_two_ranks_one_gpu(gpu_lib):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for k, (seed, ints) in enumerate(((1, 0), (2, 4), (3, 0))):
-        loc, val = synth.gen_sparse(1500, 1500, 0.02, seed=seed, integer_values=ints)
+    for k, (n, dens, seed, ints, thr, smk) in enumerate(_DIST_GPU_CASES):
+        loc, val = synth.gen_sparse(n, n, dens, seed=seed, integer_values=ints)
         ref = orc.auction_solve(loc=loc, val=val.copy(), problem="max", cardinality_check=False, max_iter=10**8)
+        one = from_sparse(loc, val.copy(), problem="max", cardinality_check=False, max_iter=10**8, tail_threshold=thr)
+        one.solve()
         for rank in (0, 1):
-            sol, its, nred, obj = got[rank][k]
+            sol, its, nred, obj, edges, sh = got[rank][k]
             assert sol == ref["sol"].tolist(), (rank, k)
             assert (its, nred, obj) == (ref["meta"]["its"], ref["meta"]["nreductions"], ref["extra"]["obj_f64"])
+        # unique work: the sharded parts of the two ranks add up, the replicated part is the same on both
+        (e0, s0), (e1, s1) = got[0][k][4:], got[1][k][4:]
+        assert e0 - s0 == e1 - s1
+        assert s0 + s1 + (e0 - s0) == one.gpu["edges_scanned"]
+        if smk is not None or n >= 30000:
+            assert s0 > 0 and s1 > 0
+        else:
+            assert s0 == 0 and s1 == 0
 
 
 @pytest.mark.parametrize("spec,prob", [
