@@ -212,7 +212,7 @@ __device__ __forceinline__ void wave_bid(const E &ed, const double *price, int s
             const int g = base + u * kWave + lane;
             const bool ok = g < e;
             const double v = ok ? a[u] - pr[u] : ninf;           // vi = cost - p[j]   (:350)
-            const bool ge = ok && (v >= x.v);                     // :351
+            const bool ge = ok & (v >= x.v);                     // :351
             x.w = __builtin_fmax(x.w, __builtin_fmin(v, x.v));    // :353 / :357-358
             x.v = __builtin_fmax(x.v, v);
             x.g = ge ? g : x.g;
@@ -298,7 +298,7 @@ __device__ __forceinline__ void wave_bid_rec(const E &ed, const PriceRec *rec, i
         for (int u = 0; u < 4; ++u) {  // branch-free: a masked-off element has value -inf and changes nothing
             const bool ok = c[u] >= 0;
             const double v = ok ? a[u] - r[u].price : ninf;  // vi = cost - p[j]   (:350)
-            const bool ge = ok && (v >= x.v);                 // :351
+            const bool ge = ok & (v >= x.v);                 // :351
             x.w = __builtin_fmax(x.w, __builtin_fmin(v, x.v));  // :353 / :357-358
             x.v = __builtin_fmax(x.v, v);
             x.g = ge ? base + u * kWave + lane : x.g;

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(kThreads) void k_scan2d(RoundArgs a, Scan2dArgs sa)
                 const bool ok = q < s1[b];
                 const double pr = s_price[ok ? x.x - c0 : sa.slice_cols];  // masked-off: +inf
                 const double v = (double)__int_as_float(x.y) - pr;
-                const bool ge = ok && (v >= v1[b]);
+                const bool ge = ok & (v >= v1[b]);
                 w[b] = __builtin_fmax(w[b], __builtin_fmin(v, v1[b]));
                 v1[b] = __builtin_fmax(v1[b], v);
                 g1[b] = ge ? q : g1[b];
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(kThreads) void k_scan2d(RoundArgs a, Scan2dArgs sa)
                 const bool ok = qx[b] < s1[b];
                 const double pr = s_price[ok ? y[b].x - c0 : sa.slice_cols];
                 const double v = (double)__int_as_float(y[b].y) - pr;
-                const bool ge = ok && (v >= v1[b]);
+                const bool ge = ok & (v >= v1[b]);
                 w[b] = __builtin_fmax(w[b], __builtin_fmin(v, v1[b]));
                 v1[b] = __builtin_fmax(v1[b], v);
                 g1[b] = ge ? qx[b] : g1[b];

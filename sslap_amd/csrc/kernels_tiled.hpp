@@ -397,12 +397,24 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
             load_edges(seg_nxt, e_nxt);  // (a prefetch distance of two steps measured no faster)
             load_seg(n2t, n2b, seg_nx2);
             if (kDouble && kLoaders == 0 && b == 0 && tile + 1 < T) dma_fill(tile + 1, wave_u, kWaves);
-            // consume step (tile, b)
+            // consume step (tile, b): first ALL price look-ups of the step (independent ds_reads, one wait),
+            // then the arithmetic -- a look-up followed by its use costs one LDS latency per element
+            double prs[kTileBatch][kTileDepth][2];
+            int rem[kTileBatch];  // real elements of the segment from this lane's first one on
+#pragma unroll
+            for (int jj = 0; jj < kTileBatch; ++jj) {
+                rem[jj] = (person[b * kTileBatch + jj] >= 0 ? seg_cur.s1[jj] - seg_cur.s0[jj] : 0) - 2 * gl;
+#pragma unroll
+                for (int d = 0; d < kTileDepth; ++d) {
+                    const int4 x = e_cur.x[jj][d];
+                    prs[jj][d][0] = buf[(8 * d < rem[jj]) ? x.x - c0 : kTileCols];      // masked-off: +inf
+                    prs[jj][d][1] = buf[(8 * d + 1 < rem[jj]) ? x.z - c0 : kTileCols];
+                }
+            }
 #pragma unroll
             for (int jj = 0; jj < kTileBatch; ++jj) {
                 const int j = b * kTileBatch + jj;
-                const int s0 = seg_cur.s0[jj];
-                const int s1 = person[j] >= 0 ? seg_cur.s1[jj] : s0;  // empty segment for an absent person
+                const int q0 = seg_cur.s0[jj] + 2 * gl;
 #pragma unroll
                 for (int d = 0; d < kTileDepth; ++d) {
                     const int4 x = e_cur.x[jj][d];
@@ -412,15 +424,14 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
                     }
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
-                        const int col = h ? x.z : x.x, vb = h ? x.w : x.y;
-                        const int q = s0 + 2 * gl + 8 * d + h;
-                        const bool ok = q < s1;
-                        const double pr = buf[ok ? col - c0 : kTileCols];            // masked-off: +inf
-                        const double v = (double)__int_as_float(vb) - pr;             // vi = cost - p[j]   (:350)
-                        const bool ge = ok && (v >= sv[j]);                           // :351
+                        const int vb = h ? x.w : x.y;
+                        // a masked-off element has v = -inf and changes neither sv nor sw; `ok` keeps it from
+                        // taking sg when sv is still -inf (rows whose objects all have an infinite price)
+                        const double v = (double)__int_as_float(vb) - prs[jj][d][h];  // vi = cost - p[j]   (:350)
+                        const bool ge = (8 * d + h < rem[jj]) & (v >= sv[j]);         // :351
                         sw[j] = __builtin_fmax(sw[j], __builtin_fmin(v, sv[j]));      // :353 / :357-358
                         sv[j] = __builtin_fmax(sv[j], v);
-                        sg[j] = ge ? q : sg[j];
+                        sg[j] = ge ? q0 + 8 * d + h : sg[j];
                     }
                 }
             }
@@ -446,7 +457,7 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
                         const bool ok = qx[jj] < s1x[jj];
                         const double pr = buf[ok ? y[jj].x - c0 : kTileCols];
                         const double v = (double)__int_as_float(y[jj].y) - pr;
-                        const bool ge = ok && (v >= sv[j]);
+                        const bool ge = ok & (v >= sv[j]);
                         sw[j] = __builtin_fmax(sw[j], __builtin_fmin(v, sv[j]));
                         sv[j] = __builtin_fmax(sv[j], v);
                         sg[j] = ge ? qx[jj] : sg[j];

@@ -5,7 +5,7 @@
 // per-edge and per-person work is in the kernels_*.hpp headers; this file only sequences launches on
 // one HIP stream and reads back a 100-byte control block when the loop needs a decision.
 //
-// Build: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -shared -fPIC misslap.hip -o libmisslap.so
+// Build: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fno-honor-nans -shared -fPIC misslap.hip -o libmisslap.so
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
