@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libmisslap.so")
+# MISSLAP_LIB selects another build of the same library (A/B timing of kernel variants on one GPU box)
+LIB_PATH = os.environ.get("MISSLAP_LIB") or os.path.join(_PKG, "libmisslap.so")
 
 MISSLAP_OK, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_STATE = 0, 1, 2, 3, 4
 

@@ -28,6 +28,7 @@ constexpr int kErrRowsUnsorted = 2;  // loc rows not ascending
 constexpr int kErrRowGap = 4;        // a row index is missing (empty row)
 constexpr int kErrNonFinite = 8;     // NaN / inf among the values
 constexpr int kErrColNegative = 16;  // negative row / column index
+constexpr int kErrLdsBase = 32;      // k_bid_tiled: the price buffers do not start at LDS address 0
 
 // Device-resident control block: the scalar part of the reference's solver state.
 struct Ctl {

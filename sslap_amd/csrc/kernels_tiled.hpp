@@ -180,18 +180,26 @@ __global__ __launch_bounds__(256) void k_pack_seg(const int *start, const int *l
         seg[k] = make_int2(start[k], len[k]);
 }
 
-// pass 3: copy every edge to its tile-major position
+// pass 3: copy every edge to its tile-major position.  For k_bid_tiled (tcol != nullptr) the column of the copy
+// is stored as the BYTE OFFSET of its price inside the kernel's LDS buffers -- (col - tile * cols) * 8, plus
+// `buf_stride` for odd tiles (double buffering) -- so that a price look-up needs no address arithmetic; the real
+// column goes to the parallel array `tcol` (read once per bidder, for the winner).
 __global__ __launch_bounds__(256) void k_tile_scatter(const int2 *edges, const int *row_ptr, int n_rows, int T,
                                                       int kTileCols, int rb, const int *start, const int *lrel,
-                                                      int2 *tiled) {
+                                                      int2 *tiled, int *tcol, int buf_stride) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int i = blockIdx.x * 4 + wave; i < n_rows; i += gridDim.x * 4) {
         const int s = row_ptr[i], e = row_ptr[i + 1];
         for (int g = s + lane; g < e; g += kWave) {
-            const int2 x = edges[g];
+            int2 x = edges[g];
             const int t = x.x / kTileCols;
             const int idx = tile_idx(i, t, T, rb);
-            tiled[start[idx] + (g - s - lrel[idx])] = x;
+            const int pos = start[idx] + (g - s - lrel[idx]);
+            if (tcol) {
+                tcol[pos] = x.x;
+                x.x = (x.x - t * kTileCols) * 8 + (t & 1) * buf_stride;
+            }
+            tiled[pos] = x;
         }
     }
 }
@@ -246,7 +254,9 @@ __device__ __forceinline__ int group4_max_i32(int v) {
 }
 
 struct TiledArgs {
-    const int2 *tiled;   // tile-major edges, every segment starts at an even position (16-byte aligned)
+    const int2 *tiled;   // tile-major edges {LDS byte offset of the price, fp32 value}; every segment starts at an
+                         // even position (16-byte aligned)
+    const int *tcol;     // real column of every tile-major entry
     const int2 *seg;     // {start, real length} per (person block, tile, person), n_blocks * T * RB entries
     int T;               // number of column tiles
     int min_K;           // the kernel runs only for K >= min_K (k_bid takes the smaller rounds)
@@ -269,10 +279,11 @@ struct TiledArgs {
 // Template: THREADS per workgroup, ROWS persons per 8-lane group, BATCH persons whose loads are in flight
 // together, DEPTH unconditional 8-lane loads per segment (longer segments finish in a short loop),
 // TILE_COLS prices per LDS tile.  ABL (diagnostics only, results wrong): 1 = no LDS fill, 2 = no
-// per-element arithmetic, 3 = no edge loads.
-template <int kTileThreads, int kTileRows, int kTileBatch, int kTileDepth, int kTileCols, int kLoaders, int ABL = 0>
+// per-element arithmetic, 3 = no edge loads, 4 = no barriers in the tile loop.
+template <int kTileThreads, int kTileRows, int kTileBatch, int kTileDepth, int kTileCols, int kLoaders, int ABL = 0, int kGL = 4>
 __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledArgs ta) {
-    constexpr int kTileGroups = (kTileThreads - kLoaders * kWave) / 4;  // 4-lane groups; loader wavefronts own none
+    static_assert(kGL == 4 || kGL == 8, "lanes per person: 4 or 8");
+    constexpr int kTileGroups = (kTileThreads - kLoaders * kWave) / kGL;  // kGL-lane groups; loader wavefronts own none
     constexpr int kBufDoubles = kTileCols + 2;  // + the +inf slot, keeps the second buffer 16-byte aligned
     // kTileColsBig: ONE buffer (fill, barrier, look up, barrier); kTileColsHalf: two buffers, fill overlapped
     constexpr bool kDouble = kTileCols != kTileColsBig;
@@ -289,8 +300,8 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
     const int p0 = lo + (int)blockIdx.x * per_wg;
     const int p1 = min(hi, p0 + per_wg);
     if (p0 >= p1) return;  // uniform over the workgroup
-    const int t = threadIdx.x, lane = t & 63, gl = lane & 3;
-    const int group = t >> 2;
+    const int t = threadIdx.x, lane = t & 63, gl = lane & (kGL - 1);
+    const int group = t / kGL;
     const double eps = (double)a.eps;
     const double ninf = -__builtin_huge_val();
     const int T = ta.T;
@@ -304,6 +315,18 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
     const int wave_u = __builtin_amdgcn_readfirstlane(t >> 6);
     const bool loader = kLoaders > 0 && wave_u >= kWaves - kLoaders;
 
+#ifndef MISSLAP_TILED_ROT
+#define MISSLAP_TILED_ROT 0
+#endif
+    // Tile order.  ROT: the workgroups of one XCD (blockIdx % 8 under round-robin dispatch) start at tiles spread
+    // evenly over [0, T) and wrap around, so that every price tile is re-read every few microseconds and stays
+    // in the XCD's L2 (in lockstep all 32 workgroups read a tile once and the edge stream evicts it before the
+    // stragglers arrive).  Needs an even T (the buffer parity of a tile is baked into the edges).
+    const int t0 = (MISSLAP_TILED_ROT && (T & 1) == 0) ? (int)(((blockIdx.x >> 3) * (unsigned)T) >> 5) % T : 0;
+    auto rot = [&](int it) {
+        const int x = t0 + it;
+        return x >= T ? x - T : x;
+    };
     int person[kTileRows];
     double sv[kTileRows], sw[kTileRows];
     int sg[kTileRows];  // position of the lane's best element (its column / cost are re-read at the end)
@@ -317,6 +340,14 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
         sg[j] = -1;
     }
     if (t < (kDouble ? 2 : 1)) s_price[t * kBufDoubles + kTileCols] = __builtin_huge_val();
+    // an edge carries the byte offset of its price inside s_price (tile parity included, see k_tile_scatter)
+    constexpr int kInfOff = kTileCols * 8;  // the +inf slot of buffer 0
+    // ... as an ABSOLUTE LDS address: s_price is the kernel's only LDS object and therefore starts at LDS address 0
+    // (checked below); going through the s_price symbol would cost a v_add of its link-time address per look-up
+    typedef const __attribute__((address_space(3))) double *lds_cdp;
+    if (t == 0 && (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) void *)s_price != 0u)
+        atomicOr(&a.ctl->err, kErrLdsBase);
+    auto lds_price = [&](int off) { return *(lds_cdp)(__UINTPTR_TYPE__)(unsigned)off; };
 
     // pieces first, first + stride, ... of `tile` -> buffer tile & 1; one piece = 64 lanes x 16 B = 128 prices
     auto dma_fill = [&](int tile, int first, int stride) {
@@ -332,29 +363,36 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
     };
     if (loader) {
         const int me = wave_u - (kWaves - kLoaders);
-        dma_fill(0, me, kLoaders);
+        dma_fill(rot(0), me, kLoaders);
         for (int tile = 0; tile < T; ++tile) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my pieces of tile `tile` have landed
-            __syncthreads();                                  // ... and tile - 1 is no longer read
-            if (tile + 1 < T) dma_fill(tile + 1, me, kLoaders);
+            if (ABL != 4) __syncthreads();                    // ... and tile - 1 is no longer read
+            if (tile + 1 < T) dma_fill(rot(tile + 1), me, kLoaders);
         }
     }
     // Software pipeline over steps = (tile, batch of kTileBatch persons): while step s is consumed, the edges
     // of step s+1 and the segment pointers of step s+2 are in flight; they do not depend on LDS.
     constexpr int kNB = kTileRows / kTileBatch;
+#ifndef MISSLAP_TILED_PF
+#define MISSLAP_TILED_PF 1  // steps of edge loads in flight ahead of the one being consumed
+#endif
     struct Seg {
         int s0[kTileBatch], s1[kTileBatch];
     };
     struct Edges {
         int4 x[kTileBatch][kTileDepth];  // two consecutive edges per lane and load (dwordx4)
     };
+    // Addresses are base (SGPR pair) + 32-bit unsigned BYTE offset (VGPR): the global_load "saddr" form, no
+    // 64-bit address arithmetic per load (the host enables this kernel only while both tables are < 4 GiB).
+    // `tiled` is allocated with 16 spare entries, so the unconditional loads of masked-off lanes (at most 15
+    // entries past a segment start) need no clamp.
     auto load_seg = [&](int tile, int b, Seg &sg_) {
-        const int tl = min(tile, T - 1);
+        const int tl = rot(min(tile, T - 1));
 #pragma unroll
         for (int jj = 0; jj < kTileBatch; ++jj) {
             const int pj = person[b * kTileBatch + jj];
-            const int idx = tile_idx(pj >= 0 ? pj : 0, tl, T);
-            const int2 sp = ta.seg[idx];
+            const unsigned boff = (unsigned)tile_idx(pj >= 0 ? pj : 0, tl, T) << 3;
+            const int2 sp = *reinterpret_cast<const int2 *>(reinterpret_cast<const char *>(ta.seg) + boff);
             sg_.s0[jj] = sp.x;
             sg_.s1[jj] = sp.x + sp.y;
         }
@@ -364,13 +402,14 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
         for (int jj = 0; jj < kTileBatch; ++jj)
 #pragma unroll
             for (int d = 0; d < kTileDepth; ++d) {
-                if (ABL == 3) e.x[jj][d] = make_int4(sg_.s0[jj] & 1023, gl, sg_.s0[jj] & 1023, gl);
+                if (ABL == 3) e.x[jj][d] = make_int4((sg_.s0[jj] & 1023) << 3, gl, (sg_.s0[jj] & 1023) << 3, gl);
                 else  // s0 is even: 16-byte aligned; a group of 4 lanes covers 8 consecutive edges per load
                 {
                     typedef int v4i_t __attribute__((ext_vector_type(4)));
-                    const v4i_t y = kNT ? __builtin_nontemporal_load(reinterpret_cast<const v4i_t *>(ta.tiled) +
-                                                                     min((sg_.s0[jj] >> 1) + gl + 4 * d, last >> 1))
-                                        : reinterpret_cast<const v4i_t *>(ta.tiled)[min((sg_.s0[jj] >> 1) + gl + 4 * d, last >> 1)];
+                    const unsigned boff = ((unsigned)sg_.s0[jj] << 3) + (unsigned)(16 * gl);
+                    const v4i_t *src =  // + 16 * kGL * d bytes goes into the instruction's immediate offset
+                        reinterpret_cast<const v4i_t *>(reinterpret_cast<const char *>(ta.tiled) + boff) + kGL * d;
+                    const v4i_t y = kNT ? __builtin_nontemporal_load(src) : *src;
                     e.x[jj][d] = make_int4(y.x, y.y, y.z, y.w);
                 }
             }
@@ -380,23 +419,33 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
     load_seg(0, 0, seg_cur);
     load_seg(0, 1, seg_nxt);
     load_edges(seg_cur, e_cur);
-    if (kLoaders == 0 && kDouble) dma_fill(0, wave_u, kWaves);
+#if MISSLAP_TILED_PF == 2
+    Seg seg_nx3;
+    Edges e_nx2;
+    load_seg(2 / kNB, 2 % kNB, seg_nx2);
+    load_edges(seg_nxt, e_nxt);
+#endif
+    if (kLoaders == 0 && kDouble) dma_fill(rot(0), wave_u, kWaves);
     for (int tile = 0; tile < (loader ? 0 : T); ++tile) {
         if (!kDouble) {
             __syncthreads();  // every lookup of the previous tile is done
-            dma_fill(tile, wave_u, kWaves);
+            dma_fill(rot(tile), wave_u, kWaves);
         }
         if (kLoaders == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my pieces of this tile
-        __syncthreads();  // every piece of this tile has landed; the other buffer may be refilled
-        const int c0 = tile * kTileCols;
-        const double *buf = s_price + (kDouble ? (tile & 1) : 0) * kBufDoubles;
+        if (ABL != 4) __syncthreads();  // every piece of this tile has landed; the other buffer may be refilled
 #pragma unroll
         for (int b = 0; b < kNB; ++b) {
             // issue: edges of the next step, segment pointers of the step after it
             const int n2t = (b + 2 < kNB) ? tile : tile + 1, n2b = (b + 2) % kNB;
+#if MISSLAP_TILED_PF == 2
+            load_edges(seg_nx2, e_nx2);
+            load_seg(tile + (b + 3) / kNB, (b + 3) % kNB, seg_nx3);
+            (void)n2t, (void)n2b;
+#else
             load_edges(seg_nxt, e_nxt);  // (a prefetch distance of two steps measured no faster)
             load_seg(n2t, n2b, seg_nx2);
-            if (kDouble && kLoaders == 0 && b == 0 && tile + 1 < T) dma_fill(tile + 1, wave_u, kWaves);
+#endif
+            if (kDouble && kLoaders == 0 && b == 0 && tile + 1 < T) dma_fill(rot(tile + 1), wave_u, kWaves);
             // consume step (tile, b): first ALL price look-ups of the step (independent ds_reads, one wait),
             // then the arithmetic -- a look-up followed by its use costs one LDS latency per element
             double prs[kTileBatch][kTileDepth][2];
@@ -407,10 +456,11 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
 #pragma unroll
                 for (int d = 0; d < kTileDepth; ++d) {
                     const int4 x = e_cur.x[jj][d];
-                    prs[jj][d][0] = buf[(8 * d < rem[jj]) ? x.x - c0 : kTileCols];      // masked-off: +inf
-                    prs[jj][d][1] = buf[(8 * d + 1 < rem[jj]) ? x.z - c0 : kTileCols];
+                    prs[jj][d][0] = lds_price((2 * kGL * d < rem[jj]) ? x.x : kInfOff);      // masked-off: +inf
+                    prs[jj][d][1] = lds_price((2 * kGL * d + 1 < rem[jj]) ? x.z : kInfOff);
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);  // keep the look-ups together, ahead of the arithmetic
 #pragma unroll
             for (int jj = 0; jj < kTileBatch; ++jj) {
                 const int j = b * kTileBatch + jj;
@@ -428,10 +478,14 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
                         // a masked-off element has v = -inf and changes neither sv nor sw; `ok` keeps it from
                         // taking sg when sv is still -inf (rows whose objects all have an infinite price)
                         const double v = (double)__int_as_float(vb) - prs[jj][d][h];  // vi = cost - p[j]   (:350)
-                        const bool ge = (8 * d + h < rem[jj]) & (v >= sv[j]);         // :351
+                        const int q = q0 + 2 * kGL * d + h;
+                        // in tile order a lane meets its elements in stored order and ">=" is the reference's
+                        // rule; with a rotated tile order the later STORED position must win a tie explicitly
+                        const bool ge = (2 * kGL * d + h < rem[jj]) &
+                                        (MISSLAP_TILED_ROT ? ((v > sv[j]) | ((v == sv[j]) & (q > sg[j]))) : (v >= sv[j]));  // :351
                         sw[j] = __builtin_fmax(sw[j], __builtin_fmin(v, sv[j]));      // :353 / :357-358
                         sv[j] = __builtin_fmax(sv[j], v);
-                        sg[j] = ge ? q0 + 8 * d + h : sg[j];
+                        sg[j] = ge ? q : sg[j];
                     }
                 }
             }
@@ -442,7 +496,7 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
                 bool more = false;
 #pragma unroll
                 for (int jj = 0; jj < kTileBatch; ++jj) {
-                    qx[jj] = seg_cur.s0[jj] + gl + 8 * kTileDepth;  // one edge per lane and pass from here on
+                    qx[jj] = seg_cur.s0[jj] + gl + 2 * kGL * kTileDepth;  // one edge per lane and pass from here on
                     s1x[jj] = person[b * kTileBatch + jj] >= 0 ? seg_cur.s1[jj] : seg_cur.s0[jj];
                     more |= qx[jj] < s1x[jj];
                 }
@@ -455,13 +509,13 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
                     for (int jj = 0; jj < kTileBatch; ++jj) {
                         const int j = b * kTileBatch + jj;
                         const bool ok = qx[jj] < s1x[jj];
-                        const double pr = buf[ok ? y[jj].x - c0 : kTileCols];
+                        const double pr = lds_price(ok ? y[jj].x : kInfOff);
                         const double v = (double)__int_as_float(y[jj].y) - pr;
-                        const bool ge = ok & (v >= sv[j]);
+                        const bool ge = ok & (MISSLAP_TILED_ROT ? ((v > sv[j]) | ((v == sv[j]) & (qx[jj] > sg[j]))) : (v >= sv[j]));
                         sw[j] = __builtin_fmax(sw[j], __builtin_fmin(v, sv[j]));
                         sv[j] = __builtin_fmax(sv[j], v);
                         sg[j] = ge ? qx[jj] : sg[j];
-                        qx[jj] += 4;
+                        qx[jj] += kGL;
                         more |= qx[jj] < s1x[jj];
                     }
                 }
@@ -469,6 +523,10 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
             seg_cur = seg_nxt;
             seg_nxt = seg_nx2;
             e_cur = e_nxt;
+#if MISSLAP_TILED_PF == 2
+            seg_nx2 = seg_nx3;
+            e_nxt = e_nx2;
+#endif
         }
     }
     // merge the 8 lanes of each group, once per person (same three all-reduces as top2_wave_reduce)
@@ -480,12 +538,15 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
     bool mine[kTileRows];
 #pragma unroll
     for (int j = 0; j < kTileRows; ++j) {
-        const double V = group4_max_f64(sv[j]);
-        const int G = group4_max_i32(sv[j] == V ? sg[j] : -1);
-        W[j] = group4_max_f64(sg[j] == G ? sw[j] : sv[j]);
+        const double V = kGL == 4 ? group4_max_f64(sv[j]) : group8_max_f64(sv[j]);
+        const int gsel = sv[j] == V ? sg[j] : -1;
+        const int G = kGL == 4 ? group4_max_i32(gsel) : group8_max_i32(gsel);
+        const double wsel = sg[j] == G ? sw[j] : sv[j];
+        W[j] = kGL == 4 ? group4_max_f64(wsel) : group8_max_f64(wsel);
         mine[j] = person[j] >= 0 && sg[j] == G && G >= 0;  // exactly one lane of the group
         const int pj = max(person[j], 0);
-        best[j] = ta.tiled[max(G, 0)];                     // unconditional loads, used under `mine`
+        best[j].x = ta.tcol[max(G, 0)];                    // unconditional loads, used under `mine`
+        best[j].y = ta.tiled[max(G, 0)].y;
         rlen[j] = a.row_ptr[pj + 1] - a.row_ptr[pj];
     }
 #pragma unroll
@@ -503,9 +564,11 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
             nb += 1;
         }
     }
-    // statistics: one atomic per workgroup
-    __shared__ unsigned long long s_e[kTileThreads / kWave];
-    __shared__ int s_n[kTileThreads / kWave];
+    // statistics: one atomic per workgroup.  The scratch lives BEHIND the price buffers in the dynamic allocation:
+    // a static __shared__ array would be placed first and shift s_price off LDS address 0, which costs one
+    // v_add per price look-up (the edges carry absolute LDS offsets)
+    unsigned long long *s_e = reinterpret_cast<unsigned long long *>(s_price + (kDouble ? 2 : 1) * kBufDoubles);
+    int *s_n = reinterpret_cast<int *>(s_e + kTileThreads / kWave);
     for (int off = 32; off >= 1; off >>= 1) {
         edges += ((unsigned long long)__shfl_xor((unsigned)(edges >> 32), off) << 32) |
                  (unsigned long long)__shfl_xor((unsigned)(edges & 0xffffffffull), off);

@@ -62,18 +62,19 @@ constexpr int kDefaultTailThreshold = 128;  // measured at C3: 64..128 best (111
 constexpr int kDefaultRoundsPerSync = 4;
 constexpr int kMaxGridBlocks = 2048;  // 256 CUs x 8 resident 256-thread blocks
 constexpr int kNumTiledShapes = 8;
-// launch shapes of k_bid_tiled: {threads, persons per 8-lane group, persons in flight, loads per segment,
-// prices per LDS tile}; see kernels_tiled.hpp
-const int kTiledShapes[kNumTiledShapes][6] = {
-    {1024, 4, 2, 2, kTileColsHalf, 1}, {1024, 4, 2, 2, kTileColsHalf, 0}, {1024, 4, 2, 3, kTileColsBig, 0},
-    {768, 5, 1, 2, kTileColsHalf, 1},  {768, 6, 3, 2, kTileColsHalf, 1},  {1024, 4, 1, 2, kTileColsHalf, 1},
-    {1024, 4, 2, 3, kTileColsHalf, 1}, {512, 8, 4, 2, kTileColsHalf, 1}};
+// launch shapes of k_bid_tiled: {threads, persons per lane group, persons in flight, loads per segment,
+// prices per LDS tile, loader wavefronts, lanes per person}; see kernels_tiled.hpp
+const int kTiledShapes[kNumTiledShapes][7] = {
+    {1024, 4, 2, 2, kTileColsHalf, 1, 4}, {1024, 4, 2, 2, kTileColsHalf, 0, 4}, {1024, 4, 2, 3, kTileColsBig, 0, 4},
+    {1024, 8, 2, 1, kTileColsHalf, 1, 8}, {1024, 8, 4, 1, kTileColsHalf, 1, 8}, {1024, 4, 1, 2, kTileColsHalf, 1, 4},
+    {1024, 4, 2, 3, kTileColsHalf, 1, 4}, {1024, 8, 2, 1, kTileColsHalf, 0, 8}};
 #define MISSLAP_FOR_TILED_SHAPES(X)                                                                                  \
-    X(0, 1024, 4, 2, 2, kTileColsHalf, 1) X(1, 1024, 4, 2, 2, kTileColsHalf, 0) X(2, 1024, 4, 2, 3, kTileColsBig, 0)  \
-    X(3, 768, 5, 1, 2, kTileColsHalf, 1) X(4, 768, 6, 3, 2, kTileColsHalf, 1) X(5, 1024, 4, 1, 2, kTileColsHalf, 1)    \
-    X(6, 1024, 4, 2, 3, kTileColsHalf, 1) X(7, 512, 8, 4, 2, kTileColsHalf, 1)
+    X(0, 1024, 4, 2, 2, kTileColsHalf, 1, 4) X(1, 1024, 4, 2, 2, kTileColsHalf, 0, 4)                                \
+    X(2, 1024, 4, 2, 3, kTileColsBig, 0, 4) X(3, 1024, 8, 2, 1, kTileColsHalf, 1, 8)                                 \
+    X(4, 1024, 8, 4, 1, kTileColsHalf, 1, 8) X(5, 1024, 4, 1, 2, kTileColsHalf, 1, 4)                                \
+    X(6, 1024, 4, 2, 3, kTileColsHalf, 1, 4) X(7, 1024, 8, 2, 1, kTileColsHalf, 0, 8)
 inline size_t tiled_lds_bytes(int tile_cols) {
-    return (tile_cols == kTileColsBig ? 1 : 2) * (size_t)(tile_cols + 2) * sizeof(double);
+    return (tile_cols == kTileColsBig ? 1 : 2) * (size_t)(tile_cols + 2) * sizeof(double) + 16 * 12;  // + statistics scratch
 }
 
 struct ProfRec {
@@ -113,6 +114,7 @@ struct misslap_solver {
     int launch_edges_cap = 0;
     // tile-major second copy of the edges for k_bid_tiled (kernels_tiled.hpp)
     int2 *tiled = nullptr;
+    int *tcol = nullptr;  // real columns of the tile-major copy (k_bid_tiled stores LDS offsets in `tiled`)
     int2 *seg = nullptr;
     int n_tiled = 0;  // entries of `tiled` including the padding entries
     int T = 0;
@@ -219,13 +221,13 @@ int launch_bid_tiled(misslap_solver *h) {
     const bool sharded = h->world > 1 && h->K_exact && h->K_ub >= h->shard_min_K;
     const long long share = sharded ? ((long long)h->K_ub + h->world - 1) / h->world : h->K_ub;
     const int *shp = kTiledShapes[h->tiled_shape];
-    const int groups = (shp[0] - 64 * shp[5]) / 4;  // 4-lane groups; loader wavefronts own no persons
+    const int groups = (shp[0] - 64 * shp[5]) / shp[6];  // lane groups; loader wavefronts own no persons
     const int per_wg_max = groups * shp[1];
     long long grid = (share + per_wg_max - 1) / per_wg_max;
     const long long resident = 256;  // one workgroup per CU: its two price tiles take the whole LDS
     const long long spread = std::min<long long>(resident, (share + groups - 1) / groups);
     if (grid < spread) grid = spread;
-    TiledArgs ta{h->tiled, h->seg, h->T, h->tiled_min_K, h->n_tiled};
+    TiledArgs ta{h->tiled, h->tcol, h->seg, h->T, h->tiled_min_K, h->n_tiled};
     ProfRec *pr = nullptr;
     if (h->profile) {
         if (h->launch_idx >= h->launch_edges_cap)
@@ -239,8 +241,8 @@ int launch_bid_tiled(misslap_solver *h) {
     const size_t lds = tiled_lds_bytes(shp[4]);
     const dim3 g((unsigned)grid);
     switch (h->tiled_shape) {
-#define X(I, TH, R, B, D, TC, LD) \
-    case I: hipLaunchKernelGGL((k_bid_tiled<TH, R, B, D, TC, LD>), g, dim3(TH), lds, h->stream, a, ta); break;
+#define X(I, TH, R, B, D, TC, LD, GL) \
+    case I: hipLaunchKernelGGL((k_bid_tiled<TH, R, B, D, TC, LD, 0, GL>), g, dim3(TH), lds, h->stream, a, ta); break;
         MISSLAP_FOR_TILED_SHAPES(X)
 #undef X
         default: return fail(MISSLAP_ERR_STATE, "bad tiled shape");
@@ -408,7 +410,7 @@ void free_all(misslap_solver *h) {
     (void)hipSetDevice(h->device);
     void *ptrs[] = {h->edges32, h->col,     h->val64,     h->row_ptr,    h->price,   h->p2o,     h->o2p,
                     h->U,       h->bid_key, h->bid_obj,   h->best_key,   h->best_pos, h->cnt,    h->hole_list,
-                    h->mover_list, h->ctl,  h->contrib,   h->nmatch,     h->launch_edges, h->tiled, h->seg, h->rec, h->part_v, h->part_w, h->part_g};
+                    h->mover_list, h->ctl,  h->contrib,   h->nmatch,     h->launch_edges, h->tiled, h->tcol, h->seg, h->rec, h->part_v, h->part_w, h->part_g};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_ctl) (void)hipHostFree(h->h_ctl);
@@ -489,7 +491,8 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
         const int rb = want2d ? rb2 : kTileRB;
         const long long nblk = ((long long)N + rb - 1) / rb;
         const long long L = nblk * T * rb;
-        if ((forced || (double)nnz / ((double)N * T) >= 4.0) && L < 0x7fffffffLL) {
+        // both tables are addressed with 32-bit byte offsets (8 B per entry): < 2^29 entries each
+        if ((forced || (double)nnz / ((double)N * T) >= 4.0) && L < 0x1fffffffLL) {
             h->T = T;
             const int nchunks = (int)((L + kScanChunk - 1) / kScanChunk);
             int *cnt = nullptr, *len = nullptr, *lrel = nullptr, *start = nullptr, *sums = nullptr, *flag = nullptr;
@@ -511,13 +514,20 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
             HIP_TRY(hipMemcpyAsync(&unsorted, flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(hipMemcpyAsync(&total, start + L, sizeof(int), hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(hipStreamSynchronize(h->stream));
-            if (!unsorted && total > 0) {
+            if (!unsorted && total > 0 && total < 0x1ffffff0) {
                 h->n_tiled = total;
                 if ((rc = dev_alloc(&h->tiled, (size_t)total + 16))) return rc;
                 if ((rc = dev_alloc(&h->seg, (size_t)L))) return rc;
                 HIP_TRY(hipMemsetAsync(h->tiled, 0, sizeof(int2) * ((size_t)total + 16), h->stream));
+                if (!want2d) {
+                    if ((rc = dev_alloc(&h->tcol, (size_t)total + 16))) return rc;
+                    HIP_TRY(hipMemsetAsync(h->tcol, 0, sizeof(int) * ((size_t)total + 16), h->stream));
+                }
+                // k_bid_tiled: columns stored as LDS byte offsets (buffer stride of the double-buffered shapes)
+                const int buf_stride = tcols == kTileColsBig ? 0 : (tcols + 2) * (int)sizeof(double);
                 hipLaunchKernelGGL(k_tile_scatter, dim3(blocks_for((long long)N, 4)), dim3(256), 0, h->stream,
-                                   h->edges32, h->row_ptr, h->n_rows, T, tcols, rb, start, lrel, h->tiled);
+                                   h->edges32, h->row_ptr, h->n_rows, T, tcols, rb, start, lrel, h->tiled,
+                                   want2d ? nullptr : h->tcol, buf_stride);
                 hipLaunchKernelGGL(k_pack_seg, dim3(blocks_for(L, 256)), dim3(256), 0, h->stream, start, len, L, h->seg);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipStreamSynchronize(h->stream));
@@ -540,8 +550,8 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
                 } else {
                     static bool attr_set = false;
                     if (!attr_set) {
-#define X(I, TH, R, B, D, TC, LD) \
-    HIP_TRY(hipFuncSetAttribute((const void *)k_bid_tiled<TH, R, B, D, TC, LD>, at, (int)tiled_lds_bytes(TC)));
+#define X(I, TH, R, B, D, TC, LD, GL) \
+    HIP_TRY(hipFuncSetAttribute((const void *)k_bid_tiled<TH, R, B, D, TC, LD, 0, GL>, at, (int)tiled_lds_bytes(TC)));
                         MISSLAP_FOR_TILED_SHAPES(X)
 #undef X
                         attr_set = true;
@@ -1012,24 +1022,34 @@ MISSLAP_API int misslap_debug_time_bid(misslap_solver *h, int32_t mode, int32_t 
     if (!h->f32) return fail(MISSLAP_ERR_STATE, "ablation kernels are instantiated for the 8 B/edge layout only");
     HIP_TRY(hipSetDevice(h->device));
     if (mode >= 10) {  // LDS-tiled kernel, shape 0: 10 complete, 11 no fill, 12 no arithmetic, 13 no edge loads
-        if (!h->tiled_ok || h->tiled_shape != 0) return fail(MISSLAP_ERR_STATE, "tiled ablations need tiled_shape 0");
+        if (!h->tiled_ok || (h->tiled_shape != 0 && mode != 10))
+            return fail(MISSLAP_ERR_STATE, "tiled ablations need tiled_shape 0");
         const hipFuncAttribute at = hipFuncAttributeMaxDynamicSharedMemorySize;
-        const int ldsb = (int)tiled_lds_bytes(kTileColsHalf);
+        const int ldsb = (int)tiled_lds_bytes(kTiledShapes[h->tiled_shape][4]);
         HIP_TRY(hipFuncSetAttribute((const void *)k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 1, 1>, at, ldsb));
         HIP_TRY(hipFuncSetAttribute((const void *)k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 1, 2>, at, ldsb));
         HIP_TRY(hipFuncSetAttribute((const void *)k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 1, 3>, at, ldsb));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 1, 4>, at, ldsb));
         RoundArgs a = round_args(h);
         a.launch_edges = nullptr;
-        TiledArgs ta{h->tiled, h->seg, h->T, 1, h->n_tiled};
+        TiledArgs ta{h->tiled, h->tcol, h->seg, h->T, 1, h->n_tiled};
         hipEvent_t t0, t1;
         HIP_TRY(hipEventCreate(&t0));
         HIP_TRY(hipEventCreate(&t1));
         auto launch_t = [&]() {
             const dim3 g(256), b(1024);
             switch (mode) {
-                case 10: hipLaunchKernelGGL((k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 1, 0>), g, b, ldsb, h->stream, a, ta); break;
+                case 10:  // the product kernel in the handle's launch shape
+                    switch (h->tiled_shape) {
+#define X(I, TH, R, B, D, TC, LD, GL) \
+    case I: hipLaunchKernelGGL((k_bid_tiled<TH, R, B, D, TC, LD, 0, GL>), g, dim3(TH), ldsb, h->stream, a, ta); break;
+                        MISSLAP_FOR_TILED_SHAPES(X)
+#undef X
+                    }
+                    break;
                 case 11: hipLaunchKernelGGL((k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 1, 1>), g, b, ldsb, h->stream, a, ta); break;
                 case 12: hipLaunchKernelGGL((k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 1, 2>), g, b, ldsb, h->stream, a, ta); break;
+                case 14: hipLaunchKernelGGL((k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 1, 4>), g, b, ldsb, h->stream, a, ta); break;
                 default: hipLaunchKernelGGL((k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 1, 3>), g, b, ldsb, h->stream, a, ta); break;
             }
         };
