@@ -180,10 +180,12 @@ __global__ __launch_bounds__(256) void k_pack_seg(const int *start, const int *l
         seg[k] = make_int2(start[k], len[k]);
 }
 
-// pass 3: copy every edge to its tile-major position.  For k_bid_tiled (tcol != nullptr) the column of the copy
-// is stored as the BYTE OFFSET of its price inside the kernel's LDS buffers -- (col - tile * cols) * 8, plus
-// `buf_stride` for odd tiles (double buffering) -- so that a price look-up needs no address arithmetic; the real
-// column goes to the parallel array `tcol` (read once per bidder, for the winner).
+// pass 3: copy every edge to its tile-major position.  tcol == nullptr (k_scan2d): plain {col, fp32} entries.
+// Otherwise (k_bid_tiled) the copy is PACKED to 6 bytes per edge, two edges per 12-byte record
+//   { u16 slot0, u16 slot1, f32 val0, f32 val1 }
+// where slot = (col - tile * cols) + (tile & 1) * buf_stride is the index of the edge's price inside the kernel's
+// LDS buffers (a look-up is `slot << 3`, no column arithmetic), and the real column goes to the parallel array
+// `tcol` (read once per bidder, for the winner).  A quarter less HBM traffic than {int32 col, f32 val}.
 __global__ __launch_bounds__(256) void k_tile_scatter(const int2 *edges, const int *row_ptr, int n_rows, int T,
                                                       int kTileCols, int rb, const int *start, const int *lrel,
                                                       int2 *tiled, int *tcol, int buf_stride) {
@@ -191,15 +193,18 @@ __global__ __launch_bounds__(256) void k_tile_scatter(const int2 *edges, const i
     for (int i = blockIdx.x * 4 + wave; i < n_rows; i += gridDim.x * 4) {
         const int s = row_ptr[i], e = row_ptr[i + 1];
         for (int g = s + lane; g < e; g += kWave) {
-            int2 x = edges[g];
+            const int2 x = edges[g];
             const int t = x.x / kTileCols;
             const int idx = tile_idx(i, t, T, rb);
             const int pos = start[idx] + (g - s - lrel[idx]);
             if (tcol) {
                 tcol[pos] = x.x;
-                x.x = (x.x - t * kTileCols) * 8 + (t & 1) * buf_stride;
+                const int slot = (x.x - t * kTileCols) + (t & 1) * buf_stride;
+                reinterpret_cast<unsigned short *>(tiled)[(size_t)(pos >> 1) * 6 + (pos & 1)] = (unsigned short)slot;
+                reinterpret_cast<int *>(tiled)[(size_t)(pos >> 1) * 3 + 1 + (pos & 1)] = x.y;
+            } else {
+                tiled[pos] = x;
             }
-            tiled[pos] = x;
         }
     }
 }
@@ -254,13 +259,13 @@ __device__ __forceinline__ int group4_max_i32(int v) {
 }
 
 struct TiledArgs {
-    const int2 *tiled;   // tile-major edges {LDS byte offset of the price, fp32 value}; every segment starts at an
-                         // even position (16-byte aligned)
+    const unsigned *tpk; // tile-major edges, packed 6 B/edge (see k_tile_scatter); every segment starts at an even
+                         // position, i.e. on a 12-byte record
     const int *tcol;     // real column of every tile-major entry
     const int2 *seg;     // {start, real length} per (person block, tile, person), n_blocks * T * RB entries
     int T;               // number of column tiles
     int min_K;           // the kernel runs only for K >= min_K (k_bid takes the smaller rounds)
-    int nnz;             // entries of `tiled` incl. padding (loads of masked-off lanes are clamped below it)
+    int nnz;             // entries of the tile-major copy incl. padding (leftover loads are clamped below it)
 };
 
 // All global loads of the tile loop are UNCONDITIONAL (masked-off lanes read a clamped, valid address and
@@ -284,7 +289,9 @@ template <int kTileThreads, int kTileRows, int kTileBatch, int kTileDepth, int k
 __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledArgs ta) {
     static_assert(kGL == 4 || kGL == 8, "lanes per person: 4 or 8");
     constexpr int kTileGroups = (kTileThreads - kLoaders * kWave) / kGL;  // kGL-lane groups; loader wavefronts own none
-    constexpr int kBufDoubles = kTileCols + 2;  // + the +inf slot, keeps the second buffer 16-byte aligned
+    // LDS (in doubles): buffer 0 at [0, kTileCols), the +inf slot at kTileCols, buffer 1 at [kBufDoubles, ...).
+    // A price slot must fit the 16-bit field of a packed edge: 2 * kTileCols + 128 < 65536.
+    constexpr int kBufDoubles = kTileCols + 128;
     // kTileColsBig: ONE buffer (fill, barrier, look up, barrier); kTileColsHalf: two buffers, fill overlapped
     constexpr bool kDouble = kTileCols != kTileColsBig;
     constexpr bool kNT = MISSLAP_TILED_NT;  // edge loads non-temporal (keeps the price tiles in L2?)
@@ -339,9 +346,9 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
         sw[j] = ninf;
         sg[j] = -1;
     }
-    if (t < (kDouble ? 2 : 1)) s_price[t * kBufDoubles + kTileCols] = __builtin_huge_val();
-    // an edge carries the byte offset of its price inside s_price (tile parity included, see k_tile_scatter)
-    constexpr int kInfOff = kTileCols * 8;  // the +inf slot of buffer 0
+    if (t == 0) s_price[kTileCols] = __builtin_huge_val();
+    // an edge carries the slot of its price inside s_price (tile parity included, see k_tile_scatter)
+    constexpr int kInfOff = kTileCols * 8;  // the +inf slot (behind buffer 0)
     // ... as an ABSOLUTE LDS address: s_price is the kernel's only LDS object and therefore starts at LDS address 0
     // (checked below); going through the s_price symbol would cost a v_add of its link-time address per look-up
     typedef const __attribute__((address_space(3))) double *lds_cdp;
@@ -380,7 +387,8 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
         int s0[kTileBatch], s1[kTileBatch];
     };
     struct Edges {
-        int4 x[kTileBatch][kTileDepth];  // two consecutive edges per lane and load (dwordx4)
+        unsigned c[kTileBatch][kTileDepth];  // two 16-bit price slots
+        int v0[kTileBatch][kTileDepth], v1[kTileBatch][kTileDepth];  // two fp32 values
     };
     // Addresses are base (SGPR pair) + 32-bit unsigned BYTE offset (VGPR): the global_load "saddr" form, no
     // 64-bit address arithmetic per load (the host enables this kernel only while both tables are < 4 GiB).
@@ -402,15 +410,18 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
         for (int jj = 0; jj < kTileBatch; ++jj)
 #pragma unroll
             for (int d = 0; d < kTileDepth; ++d) {
-                if (ABL == 3) e.x[jj][d] = make_int4((sg_.s0[jj] & 1023) << 3, gl, (sg_.s0[jj] & 1023) << 3, gl);
-                else  // s0 is even: 16-byte aligned; a group of 4 lanes covers 8 consecutive edges per load
-                {
-                    typedef int v4i_t __attribute__((ext_vector_type(4)));
-                    const unsigned boff = ((unsigned)sg_.s0[jj] << 3) + (unsigned)(16 * gl);
-                    const v4i_t *src =  // + 16 * kGL * d bytes goes into the instruction's immediate offset
-                        reinterpret_cast<const v4i_t *>(reinterpret_cast<const char *>(ta.tiled) + boff) + kGL * d;
-                    const v4i_t y = kNT ? __builtin_nontemporal_load(src) : *src;
-                    e.x[jj][d] = make_int4(y.x, y.y, y.z, y.w);
+                if (ABL == 3) {
+                    e.c[jj][d] = (unsigned)(sg_.s0[jj] & 1023) * 0x10001u;
+                    e.v0[jj][d] = e.v1[jj][d] = gl;
+                } else {  // s0 is even: record s0 / 2; a group of kGL lanes covers 2 * kGL consecutive edges per load
+                    typedef unsigned v3u_t __attribute__((ext_vector_type(3)));
+                    const unsigned boff = ((unsigned)sg_.s0[jj] >> 1) * 12u + (unsigned)(12 * gl);
+                    const char *src =  // + 12 * kGL * d bytes goes into the instruction's immediate offset
+                        reinterpret_cast<const char *>(ta.tpk) + boff;
+                    const v3u_t y = *reinterpret_cast<const v3u_t *>(src + 12 * kGL * d);
+                    e.c[jj][d] = y.x;
+                    e.v0[jj][d] = (int)y.y;
+                    e.v1[jj][d] = (int)y.z;
                 }
             }
     };
@@ -455,9 +466,9 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
                 rem[jj] = (person[b * kTileBatch + jj] >= 0 ? seg_cur.s1[jj] - seg_cur.s0[jj] : 0) - 2 * gl;
 #pragma unroll
                 for (int d = 0; d < kTileDepth; ++d) {
-                    const int4 x = e_cur.x[jj][d];
-                    prs[jj][d][0] = lds_price((2 * kGL * d < rem[jj]) ? x.x : kInfOff);      // masked-off: +inf
-                    prs[jj][d][1] = lds_price((2 * kGL * d + 1 < rem[jj]) ? x.z : kInfOff);
+                    const unsigned c = e_cur.c[jj][d];
+                    prs[jj][d][0] = lds_price((2 * kGL * d < rem[jj]) ? (int)((c << 3) & 0x7fff8u) : kInfOff);  // masked-off: +inf
+                    prs[jj][d][1] = lds_price((2 * kGL * d + 1 < rem[jj]) ? (int)((c >> 13) & 0x7fff8u) : kInfOff);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);  // keep the look-ups together, ahead of the arithmetic
@@ -467,14 +478,13 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
                 const int q0 = seg_cur.s0[jj] + 2 * gl;
 #pragma unroll
                 for (int d = 0; d < kTileDepth; ++d) {
-                    const int4 x = e_cur.x[jj][d];
                     if (ABL == 2) {
-                        asm volatile("" ::"v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w));  // keep the loads alive
+                        asm volatile("" ::"v"(e_cur.c[jj][d]), "v"(e_cur.v0[jj][d]), "v"(e_cur.v1[jj][d]));  // keep the loads alive
                         continue;
                     }
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
-                        const int vb = h ? x.w : x.y;
+                        const int vb = h ? e_cur.v1[jj][d] : e_cur.v0[jj][d];
                         // a masked-off element has v = -inf and changes neither sv nor sw; `ok` keeps it from
                         // taking sg when sv is still -inf (rows whose objects all have an infinite price)
                         const double v = (double)__int_as_float(vb) - prs[jj][d][h];  // vi = cost - p[j]   (:350)
@@ -501,15 +511,19 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
                     more |= qx[jj] < s1x[jj];
                 }
                 while (__any(more)) {
-                    int2 y[kTileBatch];
+                    int2 y[kTileBatch];  // {price slot, fp32 bits} of entry qx
 #pragma unroll
-                    for (int jj = 0; jj < kTileBatch; ++jj) y[jj] = ta.tiled[min(qx[jj], last)];
+                    for (int jj = 0; jj < kTileBatch; ++jj) {
+                        const int qc = min(qx[jj], last);
+                        y[jj].x = reinterpret_cast<const unsigned short *>(ta.tpk)[(qc >> 1) * 6 + (qc & 1)];
+                        y[jj].y = (int)ta.tpk[(qc >> 1) * 3 + 1 + (qc & 1)];
+                    }
                     more = false;
 #pragma unroll
                     for (int jj = 0; jj < kTileBatch; ++jj) {
                         const int j = b * kTileBatch + jj;
                         const bool ok = qx[jj] < s1x[jj];
-                        const double pr = lds_price(ok ? y[jj].x : kInfOff);
+                        const double pr = lds_price(ok ? y[jj].x << 3 : kInfOff);
                         const double v = (double)__int_as_float(y[jj].y) - pr;
                         const bool ge = ok & (MISSLAP_TILED_ROT ? ((v > sv[j]) | ((v == sv[j]) & (qx[jj] > sg[j]))) : (v >= sv[j]));
                         sw[j] = __builtin_fmax(sw[j], __builtin_fmin(v, sv[j]));
@@ -546,7 +560,7 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
         mine[j] = person[j] >= 0 && sg[j] == G && G >= 0;  // exactly one lane of the group
         const int pj = max(person[j], 0);
         best[j].x = ta.tcol[max(G, 0)];                    // unconditional loads, used under `mine`
-        best[j].y = ta.tiled[max(G, 0)].y;
+        best[j].y = (int)ta.tpk[(max(G, 0) >> 1) * 3 + 1 + (max(G, 0) & 1)];
         rlen[j] = a.row_ptr[pj + 1] - a.row_ptr[pj];
     }
 #pragma unroll
@@ -567,7 +581,7 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
     // statistics: one atomic per workgroup.  The scratch lives BEHIND the price buffers in the dynamic allocation:
     // a static __shared__ array would be placed first and shift s_price off LDS address 0, which costs one
     // v_add per price look-up (the edges carry absolute LDS offsets)
-    unsigned long long *s_e = reinterpret_cast<unsigned long long *>(s_price + (kDouble ? 2 : 1) * kBufDoubles);
+    unsigned long long *s_e = reinterpret_cast<unsigned long long *>(s_price + (kDouble ? kBufDoubles + kTileCols : kTileCols + 2));
     int *s_n = reinterpret_cast<int *>(s_e + kTileThreads / kWave);
     for (int off = 32; off >= 1; off >>= 1) {
         edges += ((unsigned long long)__shfl_xor((unsigned)(edges >> 32), off) << 32) |

@@ -73,8 +73,9 @@ const int kTiledShapes[kNumTiledShapes][7] = {
     X(2, 1024, 4, 2, 3, kTileColsBig, 0, 4) X(3, 1024, 8, 2, 1, kTileColsHalf, 1, 8)                                 \
     X(4, 1024, 8, 4, 1, kTileColsHalf, 1, 8) X(5, 1024, 4, 1, 2, kTileColsHalf, 1, 4)                                \
     X(6, 1024, 4, 2, 3, kTileColsHalf, 1, 4) X(7, 1024, 8, 2, 1, kTileColsHalf, 0, 8)
-inline size_t tiled_lds_bytes(int tile_cols) {
-    return (tile_cols == kTileColsBig ? 1 : 2) * (size_t)(tile_cols + 2) * sizeof(double) + 16 * 12;  // + statistics scratch
+inline size_t tiled_lds_bytes(int tile_cols) {  // see the LDS map in k_bid_tiled; + statistics scratch
+    const size_t doubles = tile_cols == kTileColsBig ? (size_t)tile_cols + 2 : 2 * (size_t)tile_cols + 128;
+    return doubles * sizeof(double) + 16 * 12;
 }
 
 struct ProfRec {
@@ -227,7 +228,7 @@ int launch_bid_tiled(misslap_solver *h) {
     const long long resident = 256;  // one workgroup per CU: its two price tiles take the whole LDS
     const long long spread = std::min<long long>(resident, (share + groups - 1) / groups);
     if (grid < spread) grid = spread;
-    TiledArgs ta{h->tiled, h->tcol, h->seg, h->T, h->tiled_min_K, h->n_tiled};
+    TiledArgs ta{reinterpret_cast<const unsigned *>(h->tiled), h->tcol, h->seg, h->T, h->tiled_min_K, h->n_tiled};
     ProfRec *pr = nullptr;
     if (h->profile) {
         if (h->launch_idx >= h->launch_edges_cap)
@@ -523,8 +524,8 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
                     if ((rc = dev_alloc(&h->tcol, (size_t)total + 16))) return rc;
                     HIP_TRY(hipMemsetAsync(h->tcol, 0, sizeof(int) * ((size_t)total + 16), h->stream));
                 }
-                // k_bid_tiled: columns stored as LDS byte offsets (buffer stride of the double-buffered shapes)
-                const int buf_stride = tcols == kTileColsBig ? 0 : (tcols + 2) * (int)sizeof(double);
+                // k_bid_tiled: 6-byte packed edges holding price slots (buffer stride of the double-buffered shapes)
+                const int buf_stride = tcols == kTileColsBig ? 0 : tcols + 128;
                 hipLaunchKernelGGL(k_tile_scatter, dim3(blocks_for((long long)N, 4)), dim3(256), 0, h->stream,
                                    h->edges32, h->row_ptr, h->n_rows, T, tcols, rb, start, lrel, h->tiled,
                                    want2d ? nullptr : h->tcol, buf_stride);
@@ -1032,7 +1033,7 @@ MISSLAP_API int misslap_debug_time_bid(misslap_solver *h, int32_t mode, int32_t 
         HIP_TRY(hipFuncSetAttribute((const void *)k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 1, 4>, at, ldsb));
         RoundArgs a = round_args(h);
         a.launch_edges = nullptr;
-        TiledArgs ta{h->tiled, h->tcol, h->seg, h->T, 1, h->n_tiled};
+        TiledArgs ta{reinterpret_cast<const unsigned *>(h->tiled), h->tcol, h->seg, h->T, 1, h->n_tiled};
         hipEvent_t t0, t1;
         HIP_TRY(hipEventCreate(&t0));
         HIP_TRY(hipEventCreate(&t1));
