@@ -21,6 +21,8 @@
 // position => the reference's ">=" rule applies unchanged).  Lanes of a group are merged only once,
 // after the last tile, with three 3-step DPP all-reduces inside the 8 lanes.
 #pragma once
+#include <type_traits>
+
 #include "device_common.hpp"
 #include "kernels_round.hpp"
 
@@ -180,6 +182,14 @@ __global__ __launch_bounds__(256) void k_pack_seg(const int *start, const int *l
         seg[k] = make_int2(start[k], len[k]);
 }
 
+// k_bid_tiled's segment table, 4 B per segment: start | (real length is odd).  Segments are laid out in table
+// order and padded to an even length, so the next entry's start gives the padded length; n + 1 entries.
+__global__ __launch_bounds__(256) void k_pack_seg4(const int *start, const int *len, long long n, int *seg4) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k <= n; k += stride)
+        seg4[k] = start[k] | (k < n ? (len[k] & 1) : 0);
+}
+
 // pass 3: copy every edge to its tile-major position.  tcol == nullptr (k_scan2d): plain {col, fp32} entries.
 // Otherwise (k_bid_tiled) the copy is PACKED to 6 bytes per edge, two edges per 12-byte record
 //   { u16 slot0, u16 slot1, f32 val0, f32 val1 }
@@ -262,7 +272,7 @@ struct TiledArgs {
     const unsigned *tpk; // tile-major edges, packed 6 B/edge (see k_tile_scatter); every segment starts at an even
                          // position, i.e. on a 12-byte record
     const int *tcol;     // real column of every tile-major entry
-    const int2 *seg;     // {start, real length} per (person block, tile, person), n_blocks * T * RB entries
+    const int *seg4;     // start | odd-length flag per (person block, tile, person), n_blocks * T * RB + 1 entries
     int T;               // number of column tiles
     int min_K;           // the kernel runs only for K >= min_K (k_bid takes the smaller rounds)
     int nnz;             // entries of the tile-major copy incl. padding (leftover loads are clamped below it)
@@ -284,7 +294,8 @@ struct TiledArgs {
 // Template: THREADS per workgroup, ROWS persons per 8-lane group, BATCH persons whose loads are in flight
 // together, DEPTH unconditional 8-lane loads per segment (longer segments finish in a short loop),
 // TILE_COLS prices per LDS tile.  ABL (diagnostics only, results wrong): 1 = no LDS fill, 2 = no
-// per-element arithmetic, 3 = no edge loads, 4 = no barriers in the tile loop.
+// per-element arithmetic, 3 = no edge loads, 4 = no barriers in the tile loop,
+// 5 = price look-ups without the arithmetic, 6 = arithmetic without the look-ups.
 template <int kTileThreads, int kTileRows, int kTileBatch, int kTileDepth, int kTileCols, int kLoaders, int ABL = 0, int kGL = 4>
 __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledArgs ta) {
     static_assert(kGL == 4 || kGL == 8, "lanes per person: 4 or 8");
@@ -399,10 +410,11 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
 #pragma unroll
         for (int jj = 0; jj < kTileBatch; ++jj) {
             const int pj = person[b * kTileBatch + jj];
-            const unsigned boff = (unsigned)tile_idx(pj >= 0 ? pj : 0, tl, T) << 3;
-            const int2 sp = *reinterpret_cast<const int2 *>(reinterpret_cast<const char *>(ta.seg) + boff);
-            sg_.s0[jj] = sp.x;
-            sg_.s1[jj] = sp.x + sp.y;
+            const unsigned boff = (unsigned)tile_idx(pj >= 0 ? pj : 0, tl, T) << 2;
+            typedef int v2i_t __attribute__((ext_vector_type(2), aligned(4)));  // this entry and the next one
+            const v2i_t sp = *reinterpret_cast<const v2i_t *>(reinterpret_cast<const char *>(ta.seg4) + boff);
+            sg_.s0[jj] = sp.x & ~1;
+            sg_.s1[jj] = (sp.y & ~1) - (sp.x & 1);  // start + padded length - pad
         }
     };
     auto load_edges = [&](const Seg &sg_, Edges &e) {
@@ -425,123 +437,164 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
                 }
             }
     };
-    Seg seg_cur, seg_nxt, seg_nx2;
-    Edges e_cur, e_nxt;
-    load_seg(0, 0, seg_cur);
-    load_seg(0, 1, seg_nxt);
-    load_edges(seg_cur, e_cur);
+    // Person rows beyond the workgroup's share are absent in every lane group (rows fill in order), so a round
+    // with few bidders (K well below N: half of the launches of a solve) needs fewer steps per tile: the tile loop
+    // is instantiated per number of person batches actually used.
+    auto run_tiles = [&](auto nbe_) {
+        constexpr int NBE = decltype(nbe_)::value;  // steps (person batches) per tile
+        Seg seg_cur, seg_nxt, seg_nx2;
+        Edges e_cur, e_nxt;
+        load_seg(0, 0, seg_cur);
+        load_seg(1 / NBE, 1 % NBE, seg_nxt);
+        load_edges(seg_cur, e_cur);
 #if MISSLAP_TILED_PF == 2
-    Seg seg_nx3;
-    Edges e_nx2;
-    load_seg(2 / kNB, 2 % kNB, seg_nx2);
-    load_edges(seg_nxt, e_nxt);
+        Seg seg_nx3;
+        Edges e_nx2;
+        load_seg(2 / NBE, 2 % NBE, seg_nx2);
+        load_edges(seg_nxt, e_nxt);
 #endif
-    if (kLoaders == 0 && kDouble) dma_fill(rot(0), wave_u, kWaves);
-    for (int tile = 0; tile < (loader ? 0 : T); ++tile) {
-        if (!kDouble) {
-            __syncthreads();  // every lookup of the previous tile is done
-            dma_fill(rot(tile), wave_u, kWaves);
-        }
-        if (kLoaders == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my pieces of this tile
-        if (ABL != 4) __syncthreads();  // every piece of this tile has landed; the other buffer may be refilled
+        if (kLoaders == 0 && kDouble) dma_fill(rot(0), wave_u, kWaves);
+        for (int tile = 0; tile < (loader ? 0 : T); ++tile) {
+            if (!kDouble) {
+                __syncthreads();  // every lookup of the previous tile is done
+                dma_fill(rot(tile), wave_u, kWaves);
+            }
+            if (kLoaders == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my pieces of this tile
+            if (ABL != 4) __syncthreads();  // every piece of this tile has landed; the other buffer may be refilled
 #pragma unroll
-        for (int b = 0; b < kNB; ++b) {
-            // issue: edges of the next step, segment pointers of the step after it
-            const int n2t = (b + 2 < kNB) ? tile : tile + 1, n2b = (b + 2) % kNB;
+            for (int b = 0; b < NBE; ++b) {
+                // issue: edges of the next step, segment pointers of the step after it
+                const int n2t = tile + (b + 2) / NBE, n2b = (b + 2) % NBE;
 #if MISSLAP_TILED_PF == 2
-            load_edges(seg_nx2, e_nx2);
-            load_seg(tile + (b + 3) / kNB, (b + 3) % kNB, seg_nx3);
-            (void)n2t, (void)n2b;
+                load_edges(seg_nx2, e_nx2);
+                load_seg(tile + (b + 3) / NBE, (b + 3) % NBE, seg_nx3);
+                (void)n2t, (void)n2b;
 #else
-            load_edges(seg_nxt, e_nxt);  // (a prefetch distance of two steps measured no faster)
-            load_seg(n2t, n2b, seg_nx2);
+                load_edges(seg_nxt, e_nxt);  // (a prefetch distance of two steps measured no faster)
+                load_seg(n2t, n2b, seg_nx2);
 #endif
-            if (kDouble && kLoaders == 0 && b == 0 && tile + 1 < T) dma_fill(rot(tile + 1), wave_u, kWaves);
-            // consume step (tile, b): first ALL price look-ups of the step (independent ds_reads, one wait),
-            // then the arithmetic -- a look-up followed by its use costs one LDS latency per element
-            double prs[kTileBatch][kTileDepth][2];
-            int rem[kTileBatch];  // real elements of the segment from this lane's first one on
+                if (kDouble && kLoaders == 0 && b == 0 && tile + 1 < T) dma_fill(rot(tile + 1), wave_u, kWaves);
+                // consume step (tile, b): first ALL price look-ups of a depth range (independent ds_reads, one wait),
+                // then the arithmetic -- a look-up followed by its use costs one LDS latency per element
+                int rem[kTileBatch];  // real elements of the segment from this lane's first one on
 #pragma unroll
-            for (int jj = 0; jj < kTileBatch; ++jj) {
-                rem[jj] = (person[b * kTileBatch + jj] >= 0 ? seg_cur.s1[jj] - seg_cur.s0[jj] : 0) - 2 * gl;
-#pragma unroll
-                for (int d = 0; d < kTileDepth; ++d) {
-                    const unsigned c = e_cur.c[jj][d];
-                    prs[jj][d][0] = lds_price((2 * kGL * d < rem[jj]) ? (int)((c << 3) & 0x7fff8u) : kInfOff);  // masked-off: +inf
-                    prs[jj][d][1] = lds_price((2 * kGL * d + 1 < rem[jj]) ? (int)((c >> 13) & 0x7fff8u) : kInfOff);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);  // keep the look-ups together, ahead of the arithmetic
-#pragma unroll
-            for (int jj = 0; jj < kTileBatch; ++jj) {
-                const int j = b * kTileBatch + jj;
-                const int q0 = seg_cur.s0[jj] + 2 * gl;
-#pragma unroll
-                for (int d = 0; d < kTileDepth; ++d) {
-                    if (ABL == 2) {
-                        asm volatile("" ::"v"(e_cur.c[jj][d]), "v"(e_cur.v0[jj][d]), "v"(e_cur.v1[jj][d]));  // keep the loads alive
-                        continue;
-                    }
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int vb = h ? e_cur.v1[jj][d] : e_cur.v0[jj][d];
-                        // a masked-off element has v = -inf and changes neither sv nor sw; `ok` keeps it from
-                        // taking sg when sv is still -inf (rows whose objects all have an infinite price)
-                        const double v = (double)__int_as_float(vb) - prs[jj][d][h];  // vi = cost - p[j]   (:350)
-                        const int q = q0 + 2 * kGL * d + h;
-                        // in tile order a lane meets its elements in stored order and ">=" is the reference's
-                        // rule; with a rotated tile order the later STORED position must win a tie explicitly
-                        const bool ge = (2 * kGL * d + h < rem[jj]) &
-                                        (MISSLAP_TILED_ROT ? ((v > sv[j]) | ((v == sv[j]) & (q > sg[j]))) : (v >= sv[j]));  // :351
-                        sw[j] = __builtin_fmax(sw[j], __builtin_fmin(v, sv[j]));      // :353 / :357-358
-                        sv[j] = __builtin_fmax(sv[j], v);
-                        sg[j] = ge ? q : sg[j];
-                    }
-                }
-            }
-            // segments longer than 8 * kTileDepth edges: wave-uniform loop with the loads of the whole batch
-            // issued together (a per-segment `for` with a load inside costs one HBM latency per segment)
-            if (ABL == 0) {
-                int qx[kTileBatch], s1x[kTileBatch];
-                bool more = false;
-#pragma unroll
-                for (int jj = 0; jj < kTileBatch; ++jj) {
-                    qx[jj] = seg_cur.s0[jj] + gl + 2 * kGL * kTileDepth;  // one edge per lane and pass from here on
-                    s1x[jj] = person[b * kTileBatch + jj] >= 0 ? seg_cur.s1[jj] : seg_cur.s0[jj];
-                    more |= qx[jj] < s1x[jj];
-                }
-                while (__any(more)) {
-                    int2 y[kTileBatch];  // {price slot, fp32 bits} of entry qx
+                for (int jj = 0; jj < kTileBatch; ++jj)
+                    rem[jj] = (person[b * kTileBatch + jj] >= 0 ? seg_cur.s1[jj] - seg_cur.s0[jj] : 0) - 2 * gl;
+                auto consume = [&](const int dlo, const int dhi) {
+                    double prs[kTileBatch][kTileDepth][2];
 #pragma unroll
                     for (int jj = 0; jj < kTileBatch; ++jj) {
-                        const int qc = min(qx[jj], last);
-                        y[jj].x = reinterpret_cast<const unsigned short *>(ta.tpk)[(qc >> 1) * 6 + (qc & 1)];
-                        y[jj].y = (int)ta.tpk[(qc >> 1) * 3 + 1 + (qc & 1)];
+#pragma unroll
+                        for (int d = dlo; d < dhi; ++d) {
+                            const unsigned c = e_cur.c[jj][d];
+                            const int a0 = (int)((c & 0xffffu) << 3), a1 = (int)((c >> 16) << 3);  // slot -> LDS byte address
+                            if (ABL == 6) {  // no LDS look-ups: the "price" is made from the slot bits
+                                prs[jj][d][0] = (double)a0;
+                                prs[jj][d][1] = (double)a1;
+                                continue;
+                            }
+                            prs[jj][d][0] = lds_price((2 * kGL * d < rem[jj]) ? a0 : kInfOff);  // masked-off: +inf
+                            prs[jj][d][1] = lds_price((2 * kGL * d + 1 < rem[jj]) ? a1 : kInfOff);
+                        }
                     }
-                    more = false;
+                    __builtin_amdgcn_sched_barrier(0);  // keep the look-ups together, ahead of the arithmetic
 #pragma unroll
                     for (int jj = 0; jj < kTileBatch; ++jj) {
                         const int j = b * kTileBatch + jj;
-                        const bool ok = qx[jj] < s1x[jj];
-                        const double pr = lds_price(ok ? y[jj].x << 3 : kInfOff);
-                        const double v = (double)__int_as_float(y[jj].y) - pr;
-                        const bool ge = ok & (MISSLAP_TILED_ROT ? ((v > sv[j]) | ((v == sv[j]) & (qx[jj] > sg[j]))) : (v >= sv[j]));
-                        sw[j] = __builtin_fmax(sw[j], __builtin_fmin(v, sv[j]));
-                        sv[j] = __builtin_fmax(sv[j], v);
-                        sg[j] = ge ? qx[jj] : sg[j];
-                        qx[jj] += kGL;
+                        const int q0 = seg_cur.s0[jj] + 2 * gl;
+#pragma unroll
+                        for (int d = dlo; d < dhi; ++d) {
+                            if (ABL == 2) {
+                                asm volatile("" ::"v"(e_cur.c[jj][d]), "v"(e_cur.v0[jj][d]), "v"(e_cur.v1[jj][d]));  // keep the loads alive
+                                continue;
+                            }
+                            if (ABL == 5) {  // look-ups but no arithmetic
+                                asm volatile("" ::"v"(prs[jj][d][0]), "v"(prs[jj][d][1]), "v"(e_cur.v0[jj][d]), "v"(e_cur.v1[jj][d]));
+                                continue;
+                            }
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                const int vb = h ? e_cur.v1[jj][d] : e_cur.v0[jj][d];
+                                // a masked-off element has v = -inf and changes neither sv nor sw; `ok` keeps it from
+                                // taking sg when sv is still -inf (rows whose objects all have an infinite price)
+                                const double v = (double)__int_as_float(vb) - prs[jj][d][h];  // vi = cost - p[j]   (:350)
+                                const int q = q0 + 2 * kGL * d + h;
+                                // in tile order a lane meets its elements in stored order and ">=" is the reference's
+                                // rule; with a rotated tile order the later STORED position must win a tie explicitly
+                                const bool ge = (2 * kGL * d + h < rem[jj]) &
+                                                (MISSLAP_TILED_ROT ? ((v > sv[j]) | ((v == sv[j]) & (q > sg[j]))) : (v >= sv[j]));  // :351
+                                sw[j] = __builtin_fmax(sw[j], __builtin_fmin(v, sv[j]));      // :353 / :357-358
+                                sv[j] = __builtin_fmax(sv[j], v);
+                                sg[j] = ge ? q : sg[j];
+                            }
+                        }
+                    }
+                };
+                // The first kFastDepth loads of a segment cover most segments and are consumed unconditionally; the
+                // loads beyond them are issued with the others (software-pipelined, no stall) but consumed only in the
+                // steps where some segment of the wavefront is that long (a wave-uniform branch with no load inside).
+                constexpr int kFastDepth = kTileDepth < 2 ? kTileDepth : 2;
+                consume(0, kFastDepth);
+                if (kTileDepth > kFastDepth) {
+                    bool more_d = false;
+#pragma unroll
+                    for (int jj = 0; jj < kTileBatch; ++jj) more_d |= rem[jj] > 2 * kGL * kFastDepth;
+                    if (__any(more_d)) consume(kFastDepth, kTileDepth);
+                }
+                // segments longer than 8 * kTileDepth edges: wave-uniform loop with the loads of the whole batch
+                // issued together (a per-segment `for` with a load inside costs one HBM latency per segment)
+                if (ABL == 0) {
+                    int qx[kTileBatch], s1x[kTileBatch];
+                    bool more = false;
+#pragma unroll
+                    for (int jj = 0; jj < kTileBatch; ++jj) {
+                        qx[jj] = seg_cur.s0[jj] + gl + 2 * kGL * kTileDepth;  // one edge per lane and pass from here on
+                        s1x[jj] = person[b * kTileBatch + jj] >= 0 ? seg_cur.s1[jj] : seg_cur.s0[jj];
                         more |= qx[jj] < s1x[jj];
                     }
+                    while (__any(more)) {
+                        int2 y[kTileBatch];  // {price slot, fp32 bits} of entry qx
+#pragma unroll
+                        for (int jj = 0; jj < kTileBatch; ++jj) {
+                            const int qc = min(qx[jj], last);
+                            y[jj].x = reinterpret_cast<const unsigned short *>(ta.tpk)[(qc >> 1) * 6 + (qc & 1)];
+                            y[jj].y = (int)ta.tpk[(qc >> 1) * 3 + 1 + (qc & 1)];
+                        }
+                        more = false;
+#pragma unroll
+                        for (int jj = 0; jj < kTileBatch; ++jj) {
+                            const int j = b * kTileBatch + jj;
+                            const bool ok = qx[jj] < s1x[jj];
+                            const double pr = lds_price(ok ? y[jj].x << 3 : kInfOff);
+                            const double v = (double)__int_as_float(y[jj].y) - pr;
+                            const bool ge = ok & (MISSLAP_TILED_ROT ? ((v > sv[j]) | ((v == sv[j]) & (qx[jj] > sg[j]))) : (v >= sv[j]));
+                            sw[j] = __builtin_fmax(sw[j], __builtin_fmin(v, sv[j]));
+                            sv[j] = __builtin_fmax(sv[j], v);
+                            sg[j] = ge ? qx[jj] : sg[j];
+                            qx[jj] += kGL;
+                            more |= qx[jj] < s1x[jj];
+                        }
+                    }
                 }
-            }
-            seg_cur = seg_nxt;
-            seg_nxt = seg_nx2;
-            e_cur = e_nxt;
+                seg_cur = seg_nxt;
+                seg_nxt = seg_nx2;
+                e_cur = e_nxt;
 #if MISSLAP_TILED_PF == 2
-            seg_nx2 = seg_nx3;
-            e_nxt = e_nx2;
+                seg_nx2 = seg_nx3;
+                e_nxt = e_nx2;
 #endif
+            }
         }
+    };
+    {
+        const int rows_used = (p1 - p0 + kTileGroups - 1) / kTileGroups;
+        const int nb_used = (rows_used + kTileBatch - 1) / kTileBatch;  // uniform over the workgroup
+        if (nb_used <= 1)
+            run_tiles(std::integral_constant<int, 1>{});
+        else if (kNB > 2 && nb_used <= 2)
+            run_tiles(std::integral_constant<int, (kNB > 2 ? 2 : 1)>{});
+        else
+            run_tiles(std::integral_constant<int, kNB>{});
     }
     // merge the 8 lanes of each group, once per person (same three all-reduces as top2_wave_reduce)
     unsigned long long edges = 0;

@@ -67,12 +67,12 @@ constexpr int kNumTiledShapes = 8;
 const int kTiledShapes[kNumTiledShapes][7] = {
     {1024, 4, 2, 2, kTileColsHalf, 1, 4}, {1024, 4, 2, 2, kTileColsHalf, 0, 4}, {1024, 4, 2, 3, kTileColsBig, 0, 4},
     {1024, 8, 2, 1, kTileColsHalf, 1, 8}, {1024, 8, 4, 1, kTileColsHalf, 1, 8}, {1024, 4, 1, 2, kTileColsHalf, 1, 4},
-    {1024, 4, 2, 3, kTileColsHalf, 1, 4}, {1024, 8, 2, 1, kTileColsHalf, 0, 8}};
+    {1024, 4, 2, 3, kTileColsHalf, 1, 4}, {1024, 4, 2, 2, kTileColsHalf, 2, 4}};
 #define MISSLAP_FOR_TILED_SHAPES(X)                                                                                  \
     X(0, 1024, 4, 2, 2, kTileColsHalf, 1, 4) X(1, 1024, 4, 2, 2, kTileColsHalf, 0, 4)                                \
     X(2, 1024, 4, 2, 3, kTileColsBig, 0, 4) X(3, 1024, 8, 2, 1, kTileColsHalf, 1, 8)                                 \
     X(4, 1024, 8, 4, 1, kTileColsHalf, 1, 8) X(5, 1024, 4, 1, 2, kTileColsHalf, 1, 4)                                \
-    X(6, 1024, 4, 2, 3, kTileColsHalf, 1, 4) X(7, 1024, 8, 2, 1, kTileColsHalf, 0, 8)
+    X(6, 1024, 4, 2, 3, kTileColsHalf, 1, 4) X(7, 1024, 4, 2, 2, kTileColsHalf, 2, 4)
 inline size_t tiled_lds_bytes(int tile_cols) {  // see the LDS map in k_bid_tiled; + statistics scratch
     const size_t doubles = tile_cols == kTileColsBig ? (size_t)tile_cols + 2 : 2 * (size_t)tile_cols + 128;
     return doubles * sizeof(double) + 16 * 12;
@@ -115,6 +115,7 @@ struct misslap_solver {
     int launch_edges_cap = 0;
     // tile-major second copy of the edges for k_bid_tiled (kernels_tiled.hpp)
     int2 *tiled = nullptr;
+    int *seg4 = nullptr;  // k_bid_tiled's 4-byte segment table
     int *tcol = nullptr;  // real columns of the tile-major copy (k_bid_tiled stores LDS offsets in `tiled`)
     int2 *seg = nullptr;
     int n_tiled = 0;  // entries of `tiled` including the padding entries
@@ -228,7 +229,7 @@ int launch_bid_tiled(misslap_solver *h) {
     const long long resident = 256;  // one workgroup per CU: its two price tiles take the whole LDS
     const long long spread = std::min<long long>(resident, (share + groups - 1) / groups);
     if (grid < spread) grid = spread;
-    TiledArgs ta{reinterpret_cast<const unsigned *>(h->tiled), h->tcol, h->seg, h->T, h->tiled_min_K, h->n_tiled};
+    TiledArgs ta{reinterpret_cast<const unsigned *>(h->tiled), h->tcol, h->seg4, h->T, h->tiled_min_K, h->n_tiled};
     ProfRec *pr = nullptr;
     if (h->profile) {
         if (h->launch_idx >= h->launch_edges_cap)
@@ -411,7 +412,7 @@ void free_all(misslap_solver *h) {
     (void)hipSetDevice(h->device);
     void *ptrs[] = {h->edges32, h->col,     h->val64,     h->row_ptr,    h->price,   h->p2o,     h->o2p,
                     h->U,       h->bid_key, h->bid_obj,   h->best_key,   h->best_pos, h->cnt,    h->hole_list,
-                    h->mover_list, h->ctl,  h->contrib,   h->nmatch,     h->launch_edges, h->tiled, h->tcol, h->seg, h->rec, h->part_v, h->part_w, h->part_g};
+                    h->mover_list, h->ctl,  h->contrib,   h->nmatch,     h->launch_edges, h->tiled, h->tcol, h->seg, h->seg4, h->rec, h->part_v, h->part_w, h->part_g};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_ctl) (void)hipHostFree(h->h_ctl);
@@ -518,7 +519,11 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
             if (!unsorted && total > 0 && total < 0x1ffffff0) {
                 h->n_tiled = total;
                 if ((rc = dev_alloc(&h->tiled, (size_t)total + 16))) return rc;
-                if ((rc = dev_alloc(&h->seg, (size_t)L))) return rc;
+                if (want2d) {
+                    if ((rc = dev_alloc(&h->seg, (size_t)L))) return rc;
+                } else {
+                    if ((rc = dev_alloc(&h->seg4, (size_t)L + 2))) return rc;
+                }
                 HIP_TRY(hipMemsetAsync(h->tiled, 0, sizeof(int2) * ((size_t)total + 16), h->stream));
                 if (!want2d) {
                     if ((rc = dev_alloc(&h->tcol, (size_t)total + 16))) return rc;
@@ -529,7 +534,10 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
                 hipLaunchKernelGGL(k_tile_scatter, dim3(blocks_for((long long)N, 4)), dim3(256), 0, h->stream,
                                    h->edges32, h->row_ptr, h->n_rows, T, tcols, rb, start, lrel, h->tiled,
                                    want2d ? nullptr : h->tcol, buf_stride);
-                hipLaunchKernelGGL(k_pack_seg, dim3(blocks_for(L, 256)), dim3(256), 0, h->stream, start, len, L, h->seg);
+                if (want2d)
+                    hipLaunchKernelGGL(k_pack_seg, dim3(blocks_for(L, 256)), dim3(256), 0, h->stream, start, len, L, h->seg);
+                else
+                    hipLaunchKernelGGL(k_pack_seg4, dim3(blocks_for(L + 1, 256)), dim3(256), 0, h->stream, start, len, L, h->seg4);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipStreamSynchronize(h->stream));
                 h->tiled_ok = true;
@@ -1031,9 +1039,11 @@ MISSLAP_API int misslap_debug_time_bid(misslap_solver *h, int32_t mode, int32_t 
         HIP_TRY(hipFuncSetAttribute((const void *)k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 1, 2>, at, ldsb));
         HIP_TRY(hipFuncSetAttribute((const void *)k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 1, 3>, at, ldsb));
         HIP_TRY(hipFuncSetAttribute((const void *)k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 1, 4>, at, ldsb));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 1, 5>, at, ldsb));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 1, 6>, at, ldsb));
         RoundArgs a = round_args(h);
         a.launch_edges = nullptr;
-        TiledArgs ta{reinterpret_cast<const unsigned *>(h->tiled), h->tcol, h->seg, h->T, 1, h->n_tiled};
+        TiledArgs ta{reinterpret_cast<const unsigned *>(h->tiled), h->tcol, h->seg4, h->T, 1, h->n_tiled};
         hipEvent_t t0, t1;
         HIP_TRY(hipEventCreate(&t0));
         HIP_TRY(hipEventCreate(&t1));
@@ -1051,6 +1061,8 @@ MISSLAP_API int misslap_debug_time_bid(misslap_solver *h, int32_t mode, int32_t 
                 case 11: hipLaunchKernelGGL((k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 1, 1>), g, b, ldsb, h->stream, a, ta); break;
                 case 12: hipLaunchKernelGGL((k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 1, 2>), g, b, ldsb, h->stream, a, ta); break;
                 case 14: hipLaunchKernelGGL((k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 1, 4>), g, b, ldsb, h->stream, a, ta); break;
+                case 15: hipLaunchKernelGGL((k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 1, 5>), g, b, ldsb, h->stream, a, ta); break;
+                case 16: hipLaunchKernelGGL((k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 1, 6>), g, b, ldsb, h->stream, a, ta); break;
                 default: hipLaunchKernelGGL((k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 1, 3>), g, b, ldsb, h->stream, a, ta); break;
             }
         };
