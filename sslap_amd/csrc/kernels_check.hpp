@@ -19,6 +19,9 @@ __global__ __launch_bounds__(256) void k_ece(Ctl *ctl, E ed, const int *row_ptr,
     const double eps = (double)eps_f;
     const double ninf = -__builtin_huge_val();
     for (int i = blockIdx.x * 4 + wave; i < n_rows; i += gridDim.x * 4) {
+        // The answer is one bit.  Once any row has failed, the rest of the pass is pointless -- and at the end of
+        // every eps-phase but the last the test fails for most rows: 200 000 atomicOr on one word cost 1.1 ms.
+        if (__atomic_load_n(&ctl->ece_fail, __ATOMIC_RELAXED)) return;  // wave-uniform
         const int s = row_ptr[i], e = row_ptr[i + 1];
         const int j = p2o[i];
         double vmax = ninf;

@@ -265,10 +265,9 @@ __global__ __launch_bounds__(256) void k_compact_fill(RoundArgs a) {
 // launches (count, scatter, fill, round_end) -- most grid rounds have K of a few hundred to a few thousand
 // and are bound by launch boundaries, not by work.  The host uses it while K_ub <= kCompactSmallMax.
 constexpr int kCompactSmallMax = 32768;
-__global__ __launch_bounds__(1024) void k_compact_small(RoundArgs a) {
-    Ctl *ctl = a.ctl;
-    if (!round_live(ctl, a.thr)) return;
-    const int K = ctl->K, nholes = ctl->nholes, Kn = K - nholes;
+// the body shared by k_compact_small and k_round_small: one 1024-thread workgroup, `nholes` uniform
+__device__ __forceinline__ void compact_small_body(const RoundArgs &a, Ctl *ctl, int K, int nholes) {
+    const int Kn = K - nholes;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     __shared__ int s_wl[16], s_wm[16];
     __shared__ int s_cl, s_cm;
@@ -322,6 +321,63 @@ __global__ __launch_bounds__(1024) void k_compact_small(RoundArgs a) {
         ctl->nits += 1;  // :273
         ctl->grid_rounds += 1;
     }
+}
+
+__global__ __launch_bounds__(1024) void k_compact_small(RoundArgs a) {
+    Ctl *ctl = a.ctl;
+    if (!round_live(ctl, a.thr)) return;
+    compact_small_body(a, ctl, ctl->K, ctl->nholes);
+}
+
+// RESOLVE + ASSIGN + push_all_left + round end of a round with few bidders in ONE launch (a single 1024-thread
+// workgroup; the host uses it while K_ub <= kRoundSmallMax and the round is not sharded over GPUs).  Same
+// operations as k_tiebreak, k_apply (seen from the bidder: position n won iff best_pos[object] == n) and
+// k_compact_small; such rounds are bound by launch boundaries (4 launches of ~5 us for a few hundred bids).
+constexpr int kRoundSmallMax = 4096;
+__global__ __launch_bounds__(1024) void k_round_small(RoundArgs a) {
+    Ctl *ctl = a.ctl;
+    if (!round_live(ctl, a.thr)) return;
+    const int K = ctl->K;
+    const int t = threadIdx.x;
+    __shared__ int s_holes[16];
+    // first bidder in list order among those holding the best bid of an object (:379, strict ">")
+    for (int n = t; n < K; n += 1024) {
+        const int j = a.bid_obj[n];
+        if (a.bid_key[n] == a.best_key[j]) atomicMin(&a.best_pos[j], n);
+    }
+    __threadfence();  // the atomics have reached L2 (best_pos is not in this CU's L1: nothing has read it yet)
+    __syncthreads();
+    int holes = 0;
+    for (int n = t; n < K; n += 1024) {
+        const int j = a.bid_obj[n];
+        if (a.best_pos[j] == n) {  // winner of object j; losers see either the winner's position or kPosNone
+            const int i = a.U[n];
+            PriceRec r;
+            r.price = key_to_bid(a.bid_key[n]);      // p[j] = best_bids[j]   (:397)
+            r.owner = i;
+            r.ostart = a.row_ptr[i];
+            a.rec[j] = r;
+            a.price[j] = r.price;
+            const int prev = a.o2p[j];               // :401
+            if (prev != -1) {
+                a.p2o[prev] = -1;                    // :404
+                a.U[n] = prev;                       // :409 evicted owner inherits the slot
+            } else {
+                a.U[n] = -1;                         // :412 hole
+                holes += 1;
+            }
+            a.p2o[i] = j;                            // :417
+            a.o2p[j] = i;                            // :418
+            a.best_key[j] = 0ull;                    // :421-422
+            a.best_pos[j] = kPosNone;
+        }
+    }
+    for (int off = 32; off >= 1; off >>= 1) holes += __shfl_xor(holes, off);
+    if ((t & 63) == 0) s_holes[t >> 6] = holes;
+    __syncthreads();  // also orders the U writes above before the compaction's reads (one CU, one L1)
+    int nholes = 0;
+    for (int w = 0; w < 16; ++w) nholes += s_holes[w];
+    compact_small_body(a, ctl, K, nholes);
 }
 
 __global__ void k_round_end(RoundArgs a) {

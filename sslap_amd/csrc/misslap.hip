@@ -320,7 +320,13 @@ int launch_bid(misslap_solver *h) {
     return MISSLAP_OK;
 }
 
+// rounds with few bidders that are not sharded over GPUs: tiebreak, apply and compaction in one launch
+bool use_round_small(const misslap_solver *h) {
+    return h->K_ub <= kRoundSmallMax && (h->world == 1 || h->K_ub < h->shard_min_K);
+}
+
 int launch_tiebreak(misslap_solver *h) {
+    if (use_round_small(h)) return MISSLAP_OK;  // k_round_small (launch_apply) resolves the ties itself
     RoundArgs a = round_args(h);
     const long long share = h->K_ub;
     hipLaunchKernelGGL(k_tiebreak, dim3(blocks_for(share, 256)), dim3(256), 0, h->stream, a);
@@ -329,8 +335,14 @@ int launch_tiebreak(misslap_solver *h) {
 }
 
 int launch_apply(misslap_solver *h) {
-    h->K_exact = false;
     RoundArgs a = round_args(h);
+    if (use_round_small(h)) {
+        h->K_exact = false;
+        hipLaunchKernelGGL(k_round_small, dim3(1), dim3(1024), 0, h->stream, a);
+        HIP_TRY(hipGetLastError());
+        return MISSLAP_OK;
+    }
+    h->K_exact = false;
     hipLaunchKernelGGL(k_apply, dim3(blocks_for(h->n_cols, 256)), dim3(256), 0, h->stream, a);
     if (h->K_ub <= kCompactSmallMax) {
         hipLaunchKernelGGL(k_compact_small, dim3(1), dim3(1024), 0, h->stream, a);
