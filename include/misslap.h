@@ -43,8 +43,9 @@ typedef struct misslap_options {
     int32_t tail_threshold;  /* rounds with K <= this run in the persistent one-workgroup kernel;
                                 < 0 = library default; 0 = grid kernels only; max 1024 */
     int32_t force_f64_values;/* keep 12 B/edge (int32 col + fp64 val) even when values are fp32-exact */
-    int32_t profile;         /* 1: record HIP events around every bid-kernel / tail-kernel launch;
-                                2: additionally run the stamped (diagnostic) tail kernel */
+    int32_t profile;         /* 1: record HIP events around the full-scan bid launches, every launch of the full-scan
+                                engine and every tail-kernel launch; 3: around every bid-kernel launch as well;
+                                2: like 3, and run the stamped (diagnostic) tail kernel */
     int32_t shard_rank;      /* multi-GPU: this process bids for U positions of its shard only */
     int32_t shard_world;     /* number of shards (1 = single GPU) */
     int32_t rounds_per_sync; /* grid rounds enqueued between host status reads; <= 0 = default */

@@ -334,38 +334,57 @@ __global__ __launch_bounds__(1024) void k_compact_small(RoundArgs a) {
 // operations as k_tiebreak, k_apply (seen from the bidder: position n won iff best_pos[object] == n) and
 // k_compact_small; such rounds are bound by launch boundaries (4 launches of ~5 us for a few hundred bids).
 constexpr int kRoundSmallMax = 4096;
+constexpr int kRoundSmallSlots = kRoundSmallMax / 1024;  // list positions per thread, kept in registers
 __global__ __launch_bounds__(1024) void k_round_small(RoundArgs a) {
     Ctl *ctl = a.ctl;
     if (!round_live(ctl, a.thr)) return;
     const int K = ctl->K;
-    const int t = threadIdx.x;
-    __shared__ int s_holes[16];
-    // first bidder in list order among those holding the best bid of an object (:379, strict ">")
-    for (int n = t; n < K; n += 1024) {
-        const int j = a.bid_obj[n];
-        if (a.bid_key[n] == a.best_key[j]) atomicMin(&a.best_pos[j], n);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    __shared__ int s_cnt[16], s_wl[16], s_wm[16];
+    __shared__ int s_hole[kRoundSmallMax], s_mover[kRoundSmallMax];  // push_all_left lists (32 KB)
+    // Everything a position needs is fetched up front (two dependent rounds of loads) and stays in registers;
+    // after the tie-break only best_pos is read again.
+    int obj[kRoundSmallSlots], who[kRoundSmallSlots], prev[kRoundSmallSlots], rstart[kRoundSmallSlots];
+    unsigned long long key[kRoundSmallSlots], bkey[kRoundSmallSlots];
+#pragma unroll
+    for (int q = 0; q < kRoundSmallSlots; ++q) {
+        const int n = min(q * 1024 + t, K - 1);  // unconditional loads, masked below
+        obj[q] = a.bid_obj[n];
+        key[q] = a.bid_key[n];
+        who[q] = a.U[n];
     }
+#pragma unroll
+    for (int q = 0; q < kRoundSmallSlots; ++q) {
+        bkey[q] = a.best_key[obj[q]];
+        prev[q] = a.o2p[obj[q]];     // :401
+        rstart[q] = a.row_ptr[who[q]];
+    }
+    // first bidder in list order among those holding the best bid of an object (:379, strict ">")
+#pragma unroll
+    for (int q = 0; q < kRoundSmallSlots; ++q)
+        if (q * 1024 + t < K && key[q] == bkey[q]) atomicMin(&a.best_pos[obj[q]], q * 1024 + t);
     __threadfence();  // the atomics have reached L2 (best_pos is not in this CU's L1: nothing has read it yet)
     __syncthreads();
+    int bpos[kRoundSmallSlots];
+#pragma unroll
+    for (int q = 0; q < kRoundSmallSlots; ++q) bpos[q] = a.best_pos[obj[q]];
     int holes = 0;
-    for (int n = t; n < K; n += 1024) {
-        const int j = a.bid_obj[n];
-        if (a.best_pos[j] == n) {  // winner of object j; losers see either the winner's position or kPosNone
-            const int i = a.U[n];
+    int u[kRoundSmallSlots];  // U[n] after the assignment phase
+#pragma unroll
+    for (int q = 0; q < kRoundSmallSlots; ++q) {
+        const int n = q * 1024 + t, j = obj[q];
+        u[q] = who[q];
+        if (n < K && bpos[q] == n) {  // winner of object j; losers see the winner's position
+            const int i = who[q];
             PriceRec r;
-            r.price = key_to_bid(a.bid_key[n]);      // p[j] = best_bids[j]   (:397)
+            r.price = key_to_bid(key[q]);            // p[j] = best_bids[j]   (:397)
             r.owner = i;
-            r.ostart = a.row_ptr[i];
+            r.ostart = rstart[q];
             a.rec[j] = r;
             a.price[j] = r.price;
-            const int prev = a.o2p[j];               // :401
-            if (prev != -1) {
-                a.p2o[prev] = -1;                    // :404
-                a.U[n] = prev;                       // :409 evicted owner inherits the slot
-            } else {
-                a.U[n] = -1;                         // :412 hole
-                holes += 1;
-            }
+            if (prev[q] != -1) a.p2o[prev[q]] = -1;  // :404
+            u[q] = prev[q];                          // :409 evicted owner inherits the slot / :412 hole (-1)
+            holes += prev[q] == -1;
             a.p2o[i] = j;                            // :417
             a.o2p[j] = i;                            // :418
             a.best_key[j] = 0ull;                    // :421-422
@@ -373,11 +392,63 @@ __global__ __launch_bounds__(1024) void k_round_small(RoundArgs a) {
         }
     }
     for (int off = 32; off >= 1; off >>= 1) holes += __shfl_xor(holes, off);
-    if ((t & 63) == 0) s_holes[t >> 6] = holes;
-    __syncthreads();  // also orders the U writes above before the compaction's reads (one CU, one L1)
+    if (lane == 0) s_cnt[wave] = holes;
+    __syncthreads();
     int nholes = 0;
-    for (int w = 0; w < 16; ++w) nholes += s_holes[w];
-    compact_small_body(a, ctl, K, nholes);
+    for (int w = 0; w < 16; ++w) nholes += s_cnt[w];
+    // push_all_left (:137-162) on the register copy of U: k-th hole in [0, K') <- k-th person in [K', K)
+    const int Kn = K - nholes;
+    int cl = 0, cm = 0;  // running list lengths (uniform)
+    unsigned filled = 0;  // my slots that are left holes: their final value comes from the mover list
+#pragma unroll
+    for (int q = 0; q < kRoundSmallSlots; ++q) {
+        const int n = q * 1024 + t;
+        if (q * 1024 >= K) break;  // uniform
+        const bool isl = (n < Kn) && (u[q] == -1);
+        const bool ism = (n >= Kn) && (n < K) && (u[q] != -1);
+        const unsigned long long bl = __ballot(isl), bm = __ballot(ism);
+        __syncthreads();  // s_wl / s_wm of the previous slot are no longer read
+        if (lane == 0) {
+            s_wl[wave] = __popcll(bl);
+            s_wm[wave] = __popcll(bm);
+        }
+        __syncthreads();
+        int wl = 0, wm = 0, tl = 0, tm = 0;
+        for (int w2 = 0; w2 < 16; ++w2) {
+            if (w2 < wave) {
+                wl += s_wl[w2];
+                wm += s_wm[w2];
+            }
+            tl += s_wl[w2];
+            tm += s_wm[w2];
+        }
+        if (ism) {
+            s_mover[cm + wm + __popcll(bm & lanemask_lt())] = u[q];
+            u[q] = -1;  // data[right_track] = -1   (:159)
+        }
+        if (isl) {
+            s_hole[cl + wl + __popcll(bl & lanemask_lt())] = n;
+            filled |= 1u << q;
+        }
+        cl += tl;
+        cm += tm;
+    }
+    __syncthreads();
+    // every position is written exactly once: a left hole takes its mover from the LDS lists (as many movers
+    // as left holes), every other position its value after the assignment phase
+#pragma unroll
+    for (int q = 0; q < kRoundSmallSlots; ++q) {
+        const int n = q * 1024 + t;
+        if (n < K && !((filled >> q) & 1u)) a.U[n] = u[q];
+    }
+    for (int k = t; k < cl; k += 1024) a.U[s_hole[k]] = s_mover[k];  // data[left_track] = i   (:158)
+    if (t == 0) {
+        ctl->K = Kn;  // :429
+        ctl->nholes = 0;
+        ctl->nleft = 0;
+        ctl->nits += 1;  // :273
+        ctl->grid_rounds += 1;
+    }
 }
 
 __global__ void k_round_end(RoundArgs a) {

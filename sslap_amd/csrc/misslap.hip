@@ -59,7 +59,7 @@ double now_ms() {
 }
 
 constexpr int kDefaultTailThreshold = 128;  // measured at C3: 64..128 best (1110 ms), 256: 1139 ms, 32: 1186 ms
-constexpr int kDefaultRoundsPerSync = 4;
+constexpr int kDefaultRoundsPerSync = 8;
 constexpr int kMaxGridBlocks = 2048;  // 256 CUs x 8 resident 256-thread blocks
 constexpr int kNumTiledShapes = 8;
 // launch shapes of k_bid_tiled: {threads, persons per lane group, persons in flight, loads per segment,
@@ -135,6 +135,7 @@ struct misslap_solver {
     bool finished = false;
     int64_t max_iter = 0;
     int thr = kDefaultTailThreshold;
+    bool profile_all = false;  // profile >= 2: events around every k_bid launch, not only the full scans
     int rounds_per_sync = kDefaultRoundsPerSync;
     int rank = 0, world = 1;
     int shard_min_K = 0;  // multi-GPU: only rounds with K >= this are sharded and exchanged
@@ -298,12 +299,16 @@ int launch_bid(misslap_solver *h) {
     const long long share = h->K_ub;  // upper bound: unsharded rounds bid for every list position
     const int grid = blocks_for(share, kBidBlock / kWave);
     ProfRec *pr = nullptr;
-    if (h->profile) {
+    // profile 1 times the full scans only (two event records around each of the ~3000 small launches of a solve
+    // cost more host time than the launches themselves); profile 2 / 3 time every launch
+    const bool fullscan = h->phase_fresh && h->world == 1 && !(h->tiled_ok && h->K_ub >= h->tiled_min_K);
+    if (!(h->profile && (h->profile_all || fullscan))) a.launch_edges = nullptr;
+    if (h->profile && (h->profile_all || fullscan)) {
         if (h->launch_idx >= h->launch_edges_cap)
             return fail(MISSLAP_ERR_STATE, "profile buffer exhausted (%d bid launches)", h->launch_idx);
         pr = prof_next(h, 0);
         if (!pr) return fail(MISSLAP_ERR_HIP, "hipEventCreate failed");
-        pr->fullscan = h->phase_fresh && h->world == 1 && !(h->tiled_ok && h->K_ub >= h->tiled_min_K);
+        pr->fullscan = fullscan;
         pr->launch_idx = a.launch_idx = h->launch_idx++;
         HIP_TRY(hipEventRecord(pr->start, h->stream));
     }
@@ -657,6 +662,7 @@ int new_handle(misslap_solver **out, const misslap_options *opt, misslap_solver 
     h->world = opt->shard_world > 0 ? opt->shard_world : 1;
     h->rank = opt->shard_world > 0 ? opt->shard_rank : 0;
     h->profile = opt->profile != 0;
+    h->profile_all = opt->profile >= 2;
     h->stamp = opt->profile == 2;
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;

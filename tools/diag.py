@@ -32,7 +32,7 @@ for mode in (0, 1, 2, 3, 0):
 shapes = ["1024x4x2x2h_L1", "1024x4x2x2h_L0", "1024x4x2x3big", "768x5x1x2h_L1", "768x6x3x2h_L1", "1024x4x1x2h_L1", "1024x4x2x3h_L1", "512x8x4x2h_L1"]
 for tk, shape, eng, name in [(0, k, 1, "tiled_" + n) for k, n in enumerate(shapes)] + [(0, 0, 2, "scan2d"), (-1, 0, 0, "gather_only")]:
     st = AuctionSolver.from_device_pointers(dl.data_ptr(), dv.data_ptr(), nnz, problem="max", max_iter=10**8,
-                                            profile=1, tiled_min_k=tk, tiled_shape=shape, engine=eng)
+                                            profile=3, tiled_min_k=tk, tiled_shape=shape, engine=eng)
     st.solve()
     g = st.gpu
     out["solve_" + name] = dict(solve_ms=g["solve_ms"], setup_ms=g["setup_ms"], fullscan_us=1e3 * g["fullscan_ms"] / max(g["fullscan_launches"], 1),
