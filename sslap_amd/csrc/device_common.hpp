@@ -263,10 +263,45 @@ struct __attribute__((aligned(16))) PriceRec {
 // records are gathered only after the edge loads have returned, the edge loads were issued after those
 // stores, and a wavefront's vector memory operations complete in issue order -- so the stores have been
 // written before any record is read (the same CU-level coherence the barrier-separated rounds rely on).
-template <class E, class S = NoStamp>
+// Chain mode (one bidder per round): the next bidder is the evicted owner and its row address comes with the
+// winning price record, so its first 256 edges and its row end can be requested as soon as the winning LANE is
+// known -- before the second-best reduction, the bid and the record store of the current round.
+struct NoRowPrefetch {
+    static constexpr bool kOn = false;
+    int c[4];
+    double a[4];
+    int e;
+    template <class E>
+    __device__ __forceinline__ void issue(const E &, const int *, int, int, int) {}
+};
+struct RowPrefetch {
+    static constexpr bool kOn = true;
+    int c[4], nc[4];    // this round's first four 64-edge chunks (already requested) / the next round's
+    double a[4], na[4];
+    int e, ne;          // row ends
+    const int *row_ptr;
+    template <class E>
+    __device__ __forceinline__ void issue(const E &ed, const int *, int prev_owner, int pstart_next, int lane) {
+        // prev_owner == -1 (nobody evicted, the chain ends): row_ptr[0] and a stale-but-valid row start are read
+        // and never used
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ed.load_nt(pstart_next + u * kWave + lane, nc[u], na[u]);
+        ne = row_ptr[prev_owner + 1];
+    }
+    __device__ __forceinline__ void advance() {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            c[u] = nc[u];
+            a[u] = na[u];
+        }
+        e = ne;
+    }
+};
+
+template <class E, class S = NoStamp, class PF = NoRowPrefetch>
 __device__ __forceinline__ void wave_bid_rec(const E &ed, const PriceRec *rec, int s, const int *e_ptr, double eps,
                                              unsigned long long &key, int &obj, int &prev, int &pstart,
-                                             int &row_end, int &err, const S &stamp = S()) {
+                                             int &row_end, int &err, const S &stamp = S(), PF *pf = nullptr) {
     const int lane = threadIdx.x & (kWave - 1);
     const double ninf = -__builtin_huge_val();
     Top2 x;
@@ -277,9 +312,19 @@ __device__ __forceinline__ void wave_bid_rec(const E &ed, const PriceRec *rec, i
     double a1 = 0.0;
     int c[4];
     double a[4];
+    int e;
+    if (PF::kOn) {  // requested during the previous round
 #pragma unroll
-    for (int u = 0; u < 4; ++u) ed.load_nt(s + u * kWave + lane, c[u], a[u]);  // speculative: e not known yet
-    const int e = *e_ptr;
+        for (int u = 0; u < 4; ++u) {
+            c[u] = pf->c[u];
+            a[u] = pf->a[u];
+        }
+        e = pf->e;
+    } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ed.load_nt(s + u * kWave + lane, c[u], a[u]);  // speculative: e not known yet
+        e = *e_ptr;
+    }
     row_end = e;
     for (int base = s; base < e; base += 4 * kWave) {
         if (base != s) {
@@ -320,18 +365,22 @@ __device__ __forceinline__ void wave_bid_rec(const E &ed, const PriceRec *rec, i
     double W;
     if (__popcll(cand) == 1) {  // wave-uniform
         src = __ffsll((long long)cand) - 1;
+        prev = __builtin_amdgcn_readlane(o1, src);
+        pstart = __builtin_amdgcn_readlane(os1, src);
+        if (PF::kOn) pf->issue(ed, e_ptr, prev, pstart, lane);
         W = wave_max_f64(lane == src ? x.w : x.v);
     } else {
         const int g_mine = x.g;
         const Top2 t2 = top2_wave_reduce(x);
         src = __ffsll((long long)__ballot(g_mine == t2.g)) - 1;
         W = t2.w;
+        prev = __builtin_amdgcn_readlane(o1, src);
+        pstart = __builtin_amdgcn_readlane(os1, src);
+        if (PF::kOn) pf->issue(ed, e_ptr, prev, pstart, lane);
     }
     stamp(3);
     const int col = __builtin_amdgcn_readlane(c1, src);
     const double cost = readlane_f64(a1, src);
-    prev = __builtin_amdgcn_readlane(o1, src);
-    pstart = __builtin_amdgcn_readlane(os1, src);
     stamp(4);
     const double bid = (cost - W) + eps;  // bbest = costbest - wi + eps   (:360)
     if (!(bid >= 0.0)) err |= kErrNegativeBid;

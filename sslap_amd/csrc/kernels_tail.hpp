@@ -125,6 +125,10 @@ __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
             if (wave == 0) {
                 int i = sU[0];
                 int s = sStart[0];
+                RowPrefetch pf;
+                pf.row_ptr = a.row_ptr;
+                pf.issue(ed, nullptr, i, s, lane);  // the first bidder's own row (row end = row_ptr[i + 1])
+                pf.advance();
                 for (;;) {
                     unsigned long long key;
                     int obj, prev, pstart, e;
@@ -132,10 +136,11 @@ __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
                         CycleStamp cs{st2, &t_prev2, true};
                         cs(15);
                         cs(0);
-                        wave_bid_rec(ed, a.rec, s, a.row_ptr + i + 1, eps, key, obj, prev, pstart, e, err, cs);
+                        wave_bid_rec(ed, a.rec, s, a.row_ptr + i + 1, eps, key, obj, prev, pstart, e, err, cs, &pf);
                     } else {
-                        wave_bid_rec(ed, a.rec, s, a.row_ptr + i + 1, eps, key, obj, prev, pstart, e, err);
+                        wave_bid_rec(ed, a.rec, s, a.row_ptr + i + 1, eps, key, obj, prev, pstart, e, err, NoStamp(), &pf);
                     }
+                    pf.advance();
                     edges += (unsigned long long)(e - s);
                     bids += 1;
                     nits += 1;
