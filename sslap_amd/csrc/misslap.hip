@@ -58,7 +58,12 @@ double now_ms() {
     return std::chrono::duration<double, std::milli>(clk::now().time_since_epoch()).count();
 }
 
-constexpr int kDefaultTailThreshold = 128;  // measured at C3: 64..128 best (1110 ms), 256: 1139 ms, 32: 1186 ms
+// Rounds with K <= threshold run in the tail kernel.  Break-even against a grid round (two launches since
+// k_round_small), measured with tools/sweep_thr.py: C2 48..64 (278 ms; 128: 286), C3 64 (814 ms; 128: 830; 256: 872),
+// C5 128 (6.28 s; 64: 6.40) -- a grid round costs more when the price table no longer fits L2.
+constexpr int kDefaultTailThreshold = 64;
+constexpr int kDefaultTailThresholdBig = 128;  // n_cols > kTailBigCols
+constexpr long long kTailBigCols = 500000;
 constexpr int kDefaultRoundsPerSync = 8;
 constexpr int kMaxGridBlocks = 2048;  // 256 CUs x 8 resident 256-thread blocks
 constexpr int kNumTiledShapes = 8;
@@ -134,7 +139,7 @@ struct misslap_solver {
     int nreductions = 0;
     bool finished = false;
     int64_t max_iter = 0;
-    int thr = kDefaultTailThreshold;
+    int thr = -1;
     bool profile_all = false;  // profile >= 2: events around every k_bid launch, not only the full scans
     int rounds_per_sync = kDefaultRoundsPerSync;
     int rank = 0, world = 1;
@@ -473,6 +478,8 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
                     "every row 0..N-1 must have at least one entry (auction_.pyx:33-48 contract)");
     if (st.err & kErrNonFinite) return fail(MISSLAP_ERR_INVALID, "val holds a NaN or an infinity");
     h->n_cols = st.max_col + 1;  // auction_.pyx:210
+    if (h->thr < 0)  // library default, resolved now that the number of objects is known
+        h->thr = (long long)h->n_cols > kTailBigCols ? kDefaultTailThresholdBig : kDefaultTailThreshold;
     h->f32 = !st.not_f32 && !opt->force_f64_values;
     const int flip = h->maximize ? 0 : 1;
     if (h->f32) {
@@ -657,7 +664,7 @@ int new_handle(misslap_solver **out, const misslap_options *opt, misslap_solver 
     misslap_solver *h = new misslap_solver();
     h->device = opt->device;
     h->maximize = opt->maximize ? 1 : 0;
-    h->thr = opt->tail_threshold < 0 ? kDefaultTailThreshold : opt->tail_threshold;
+    h->thr = opt->tail_threshold >= 0 ? opt->tail_threshold : -1;  // -1: resolved in build_from_device_coo
     h->rounds_per_sync = opt->rounds_per_sync > 0 ? opt->rounds_per_sync : kDefaultRoundsPerSync;
     h->world = opt->shard_world > 0 ? opt->shard_world : 1;
     h->rank = opt->shard_world > 0 ? opt->shard_rank : 0;
