@@ -191,6 +191,13 @@ int misslap_device_info(int32_t device, char *name, int32_t name_len, int32_t *c
  * (mode 0 complete, 1 no price gather, 2 no cross-lane reduction, 3 edge stream only); results discarded. */
 int misslap_debug_time_bid(misslap_solver *h, int32_t mode, int32_t reps, float *ms_avg);
 
+/* Feasibility guard of the front-end: maximum bipartite matching (Hopcroft-Karp) on the host, the reference's
+ * c_hopcroft_solve / sslap.hopcroft_solve (feasibility_.pyx:95-283; called at auction_.pyx:562-566, :608-612).
+ * loc: int32[nnz][2] (row, col), rows ascending.  size: cardinality; left_pairings int32[n_rows] / right_pairings
+ * int32[n_cols] (-1 = unmatched, either may be NULL) reproduce the reference's result() arrays.  Needs no GPU. */
+int misslap_hopcroft_karp(const int32_t *loc, int64_t nnz, int32_t n_rows, int32_t n_cols, int32_t *size,
+                          int32_t *left_pairings, int32_t *right_pairings);
+
 const char *misslap_last_error(void);
 int misslap_abi_version(void);
 

@@ -1,11 +1,12 @@
 """sslap_amd -- MI355X-native auction solver for sparse linear assignment problems.
 
 Drop-in for the hot path of OllieBoyne/sslap: `auction_solve`, `from_matrix` / `from_sparse`
-(the reference's `_from_matrix` / `_from_sparse`) and `AuctionSolver`.  Everything computes on the GPU
+(the reference's `_from_matrix` / `_from_sparse`), `AuctionSolver` and the feasibility guard `hopcroft_solve`.  Everything computes on the GPU
 through libmisslap.so (hand-written HIP for gfx950, C ABI in include/misslap.h); importing the
 package never touches the GPU, but every solver call raises if the library or the GPU is missing.
 """
 from .auction_solve import AuctionSolver, auction_solve, from_matrix, from_sparse, _from_matrix, _from_sparse
+from .check_feasible import hopcroft_solve
 
 __version__ = "0.1.0"
-__all__ = ["auction_solve", "from_matrix", "from_sparse", "AuctionSolver"]
+__all__ = ["auction_solve", "hopcroft_solve", "from_matrix", "from_sparse", "AuctionSolver"]

@@ -70,6 +70,7 @@ SYMBOLS = {
     "misslap_get_state": (C.c_int, [_VP, _VP, _VP, _VP, _VP]),
     "misslap_device_info": (C.c_int, [C.c_int32, C.c_char_p, C.c_int32, _I32P, C.POINTER(C.c_int64)]),
     "misslap_debug_time_bid": (C.c_int, [_VP, C.c_int32, C.c_int32, C.POINTER(C.c_float)]),
+    "misslap_hopcroft_karp": (C.c_int, [_VP, C.c_int64, C.c_int32, C.c_int32, _I32P, _VP, _VP]),
     "misslap_last_error": (C.c_char_p, []),
     "misslap_abi_version": (C.c_int, []),
 }

@@ -242,12 +242,9 @@ def _cname(dt):
 def _cardinality(loc, n_rows, n_cols):
     """Maximum-matching cardinality for the optional feasibility guard (reference: c_hopcroft_solve,
     feasibility_.pyx:95-225, called at auction_.pyx:562-566 / :608-612).  Only the cardinality reaches
-    the auction path; this host-side Hopcroft-Karp (scipy) is outside the hot path (SURVEY.md 8f #3)."""
-    from scipy.sparse import csr_matrix
-    from scipy.sparse.csgraph import maximum_bipartite_matching
-    g = csr_matrix((np.ones(loc.shape[0], dtype=np.int8), (loc[:, 0], loc[:, 1])), shape=(n_rows, n_cols))
-    match = maximum_bipartite_matching(g, perm_type="column")
-    return int((match >= 0).sum())
+    the auction path; the matching runs in the library (host C++ Hopcroft-Karp, SURVEY.md 8f #3)."""
+    from .check_feasible import cardinality
+    return cardinality(loc, n_rows, n_cols)
 
 
 def from_matrix(mat, problem="min", eps_start=0, max_iter=1000000, fast=False, cardinality_check=True,

@@ -26,9 +26,7 @@
 #include "device_common.hpp"
 #include "kernels_round.hpp"
 
-#ifndef MISSLAP_TILED_NT
-#define MISSLAP_TILED_NT 0
-#endif
+// (non-temporal edge loads were measured twice, on the 8- and the 6-byte layout: 5-20 % slower, removed)
 
 namespace misslap {
 
@@ -305,7 +303,6 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
     constexpr int kBufDoubles = kTileCols + 128;
     // kTileColsBig: ONE buffer (fill, barrier, look up, barrier); kTileColsHalf: two buffers, fill overlapped
     constexpr bool kDouble = kTileCols != kTileColsBig;
-    constexpr bool kNT = MISSLAP_TILED_NT;  // edge loads non-temporal (keeps the price tiles in L2?)
     static_assert(kDouble || kLoaders == 0, "the single-buffer variant has no loader wavefronts");
     static_assert(kTileRows % kTileBatch == 0 && kTileRows / kTileBatch >= 2, "ROWS = BATCH * (>= 2 steps)");
     extern __shared__ __attribute__((aligned(16))) double s_price[];  // 2 * kBufDoubles

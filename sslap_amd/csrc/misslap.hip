@@ -24,6 +24,7 @@
 #include "kernels_ingest.hpp"
 #include "kernels_round.hpp"
 #include "kernels_tail.hpp"
+#include "host_matching.hpp"
 #include "kernels_tiled.hpp"
 #include "kernels_scan2d.hpp"
 
@@ -684,6 +685,28 @@ int new_handle(misslap_solver **out, const misslap_options *opt, misslap_solver 
 
 // ------------------------------------------------------------------------------------------------
 MISSLAP_API int misslap_abi_version(void) { return MISSLAP_ABI_VERSION; }
+
+// Feasibility guard (host side by design, like the reference's): see host_matching.hpp.
+MISSLAP_API int misslap_hopcroft_karp(const int32_t *loc, int64_t nnz, int32_t n_rows, int32_t n_cols,
+                                      int32_t *size, int32_t *left_pairings, int32_t *right_pairings) {
+    if (!size || nnz < 0 || n_rows < 0 || n_cols < 0 || (nnz > 0 && !loc))
+        return fail(MISSLAP_ERR_INVALID, "bad argument");
+    for (int64_t k = 0; k < nnz; ++k) {
+        const int32_t i = loc[2 * k], j = loc[2 * k + 1];
+        if (i < 0 || i >= n_rows || j < 0 || j >= n_cols)
+            return fail(MISSLAP_ERR_INVALID, "loc entry %lld = (%d, %d) outside %d x %d", (long long)k, i, j, n_rows, n_cols);
+        if (k && i < loc[2 * (k - 1)]) return fail(MISSLAP_ERR_INVALID, "loc rows must be sorted in ascending order");
+    }
+    try {
+        HopcroftKarp hk(loc, nnz, n_rows, n_cols);
+        *size = hk.solve();
+        if (left_pairings) std::copy(hk.pair_u.begin(), hk.pair_u.end(), left_pairings);
+        if (right_pairings) std::copy(hk.pair_v.begin(), hk.pair_v.end(), right_pairings);
+    } catch (const std::bad_alloc &) {
+        return fail(MISSLAP_ERR_HIP, "out of host memory in misslap_hopcroft_karp");
+    }
+    return MISSLAP_OK;
+}
 MISSLAP_API const char *misslap_last_error(void) { return g_err.c_str(); }
 
 MISSLAP_API int misslap_device_info(int32_t device, char *name, int32_t name_len, int32_t *compute_units,

@@ -45,6 +45,21 @@ def golden_large():
 
 
 @pytest.fixture(scope="session")
+def golden_matching():
+    return _load("matching_cases")
+
+
+@pytest.fixture(scope="session")
+def built_lib():
+    """The loaded library for host-only entry points (no GPU needed); built in-tree if stale."""
+    from sslap_amd import _lib, build
+    import shutil
+    if build.stale() and (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        build.build()
+    return _lib.load()
+
+
+@pytest.fixture(scope="session")
 def gpu_lib():
     """The loaded HIP library; fails (not skips) when it is missing -- gpu tests must run native code."""
     from sslap_amd import _lib, build

@@ -151,3 +151,59 @@ def call_kwargs(entry, loc, val, spec):
 
 
 META_KEYS = ("start_eps", "eCE", "its", "nreductions", "soln_found", "n_assigned", "obj", "final_eps")
+
+
+# ---- maximum-matching fixtures (the feasibility guard: reference sslap.hopcroft_solve) ------------------
+def matching_graph(spec):
+    """spec -> int32 loc[nnz, 2] (rows ascending).  kind 'planted': synth.gen_sparse (has a perfect matching of
+    the rows); 'thinned': the same graph with every edge whose (counter-based) hash is not 0 mod `keep_mod`
+    removed, rows that lose all edges keep their first one (usually NO perfect matching left); 'narrow': all
+    columns folded into the first `m_eff` ones (at most m_eff rows can be matched)."""
+    loc, _ = synth.gen_sparse(spec["n"], spec["m"], spec["density"], seed=spec.get("seed", 1))
+    kind = spec["kind"]
+    if kind == "planted":
+        return loc
+    if kind == "thinned":
+        h = synth._stream(spec.get("seed", 1), 91, loc.shape[0])
+        keep = (h % np.uint64(spec["keep_mod"])) == 0
+        first = np.r_[True, loc[1:, 0] != loc[:-1, 0]]
+        has = np.zeros(spec["n"], bool)
+        has[loc[keep, 0]] = True
+        keep |= first & ~has[loc[:, 0]]
+        return np.ascontiguousarray(loc[keep])
+    if kind == "narrow":
+        out = loc.copy()
+        out[:, 1] %= spec["m_eff"]
+        key = out[:, 0].astype(np.int64) * spec["m"] + out[:, 1]
+        _, idx = np.unique(key, return_index=True)
+        return np.ascontiguousarray(out[np.sort(idx)])
+    raise KeyError(kind)
+
+
+# name -> (graph spec, entry): entry 'loc' | 'mat' (dense float64, -1 = no edge) | 'lookup' (dict i -> [j])
+MATCH_CASES = {
+    "planted_60": (dict(kind="planted", n=60, m=60, density=0.08, seed=3), "loc"),
+    "planted_400": (dict(kind="planted", n=400, m=400, density=0.01, seed=4), "loc"),
+    "planted_rect": (dict(kind="planted", n=150, m=220, density=0.03, seed=5), "loc"),
+    "thinned_300": (dict(kind="thinned", n=300, m=300, density=0.02, seed=6, keep_mod=3), "loc"),
+    "thinned_1000": (dict(kind="thinned", n=1000, m=1000, density=0.004, seed=7, keep_mod=2), "loc"),
+    "narrow_200": (dict(kind="narrow", n=200, m=200, density=0.05, seed=8, m_eff=120), "loc"),
+    "dense_mat_40": (dict(kind="thinned", n=40, m=55, density=0.2, seed=9, keep_mod=2), "mat"),
+    "lookup_80": (dict(kind="thinned", n=80, m=80, density=0.06, seed=10, keep_mod=2), "lookup"),
+}
+
+
+def matching_call(loc, spec, entry):
+    """kwargs for hopcroft_solve(loc= | mat= | lookup=) from a graph."""
+    if entry == "loc":
+        return dict(loc=loc)
+    if entry == "mat":
+        mat = np.full((spec["n"], spec["m"]), -1.0)
+        mat[loc[:, 0], loc[:, 1]] = 1.0 + (loc[:, 1] % 7)
+        return dict(mat=mat)
+    if entry == "lookup":
+        lk = {}
+        for i, j in loc.tolist():
+            lk.setdefault(i, []).append(j)
+        return dict(lookup=lk)
+    raise KeyError(entry)

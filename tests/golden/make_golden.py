@@ -15,7 +15,7 @@ Runs only in the build container (needs /root/reference and Cython):
 
 Nothing of the reference (source, bytecode, binaries) is written into the repo;
 only inputs/outputs are.  Usage:
-    python tests/golden/make_golden.py [small] [trace] [demo] [large] [C5]
+    python tests/golden/make_golden.py [small] [trace] [demo] [large] [C5] [matching]
 """
 import json
 import os
@@ -199,8 +199,26 @@ def do_large(ref_solve, versions, names):
         print(f"large {name}: {manifest['cases'][name]}")
 
 
+def do_matching(versions):
+    """sslap.hopcroft_solve (feasibility_.pyx:227-283) on the graphs of cases.MATCH_CASES: cardinality and
+    both pairing arrays."""
+    import sslap
+    out = {}
+    manifest = {"versions": versions, "cases": {}}
+    for name, (spec, entry) in cases.MATCH_CASES.items():
+        loc = cases.matching_graph(spec)
+        res = sslap.hopcroft_solve(**cases.matching_call(loc.astype(np.int32), spec, entry))
+        out[name + "/left"] = np.asarray(res["left_pairings"], dtype=np.int32)
+        out[name + "/right"] = np.asarray(res["right_pairings"], dtype=np.int32)
+        manifest["cases"][name] = dict(size=int(res["size"]), nnz=int(loc.shape[0]),
+                                       n_rows=int(len(res["left_pairings"])), n_cols=int(len(res["right_pairings"])))
+        print(f"matching {name}: size={res['size']} of {len(res['left_pairings'])} rows, nnz={loc.shape[0]}")
+    np.savez_compressed(os.path.join(HERE, "matching_cases.npz"), **out)
+    json.dump(manifest, open(os.path.join(HERE, "matching_cases.json"), "w"), indent=1, sort_keys=True)
+
+
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["small", "trace", "demo", "large"]
+    what = sys.argv[1:] or ["small", "trace", "demo", "large", "matching"]
     ref_solve, versions = load_reference()
     if "small" in what:
         do_small(ref_solve, versions)
@@ -212,3 +230,5 @@ if __name__ == "__main__":
         do_large(ref_solve, versions, ["C1", "C1_min", "C2", "C4", "C3"])
     if "C5" in what:
         do_large(ref_solve, versions, ["C5"])
+    if "matching" in what:
+        do_matching(versions)

@@ -1,0 +1,79 @@
+"""The feasibility guard: native Hopcroft-Karp in libmisslap.so against golden vectors captured
+from the real reference's sslap.hopcroft_solve (cardinality AND both pairing arrays), against scipy on random
+graphs, and the front-end's ValueError texts.  Host code only: runs without a GPU."""
+import numpy as np
+import pytest
+
+import cases
+from sslap_amd import from_sparse, hopcroft_solve, synth
+from sslap_amd.check_feasible import cardinality
+
+
+@pytest.mark.parametrize("name", sorted(cases.MATCH_CASES))
+def test_matching_matches_reference(name, golden_matching, built_lib):
+    man, arr = golden_matching
+    spec, entry = cases.MATCH_CASES[name]
+    loc = cases.matching_graph(spec)
+    res = hopcroft_solve(**cases.matching_call(loc.astype(np.int32), spec, entry))
+    assert res["size"] == man["cases"][name]["size"]
+    assert res["left_pairings"].dtype == np.int32
+    assert np.array_equal(res["left_pairings"], arr[name + "/left"])
+    assert np.array_equal(res["right_pairings"], arr[name + "/right"])
+
+
+def _valid_matching(loc, res):
+    left, right = res["left_pairings"], res["right_pairings"]
+    edges = set(map(tuple, loc.tolist()))
+    m = [(i, int(j)) for i, j in enumerate(left) if j >= 0]
+    assert len(m) == res["size"] == int((right >= 0).sum())
+    assert all(e in edges for e in m)
+    assert all(right[j] == i for i, j in m)
+    assert len({j for _, j in m}) == len(m)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_cardinality_equals_scipy_on_random_graphs(seed, built_lib):
+    from scipy.sparse import csr_matrix
+    from scipy.sparse.csgraph import maximum_bipartite_matching
+    spec = dict(kind="thinned", n=450 + 37 * seed, m=500 + 50 * seed, density=0.006, seed=20 + seed, keep_mod=2)
+    loc = cases.matching_graph(spec)
+    n, m = spec["n"], spec["m"]
+    res = hopcroft_solve(loc=loc)
+    g = csr_matrix((np.ones(loc.shape[0], np.int8), (loc[:, 0], loc[:, 1])), shape=(n, m))
+    assert res["size"] == int((maximum_bipartite_matching(g, perm_type="column") >= 0).sum())
+    _valid_matching(loc, res)
+
+
+def test_large_graph_needs_no_recursion_and_no_n_squared_queue(built_lib):
+    """200 000 rows: the reference allocates an N^2-int queue (160 GB) and recurses one frame per path vertex."""
+    loc, _ = synth.gen_sparse(200_000, 200_000, 0.00003, seed=5)  # ~7 edges per row, perfect matching planted
+    assert cardinality(loc, 200_000, 200_000) == 200_000
+    # a path graph forces ONE augmenting path through every vertex (depth 100 000)
+    n = 100_000
+    i = np.repeat(np.arange(n, dtype=np.int32), 2)
+    j = np.stack([np.arange(n, dtype=np.int32), np.arange(1, n + 1, dtype=np.int32)], axis=1).reshape(-1)
+    path = np.stack([i, j], axis=1)[:-1]  # row k -> columns k, k+1; the last row only k
+    res = hopcroft_solve(loc=path)
+    assert res["size"] == n
+
+
+def test_rows_must_be_sorted_and_in_range(built_lib):
+    loc = np.array([[1, 0], [0, 1]], dtype=np.int32)
+    with pytest.raises(ValueError, match="ascending"):
+        hopcroft_solve(loc=loc)
+    with pytest.raises(AssertionError):
+        hopcroft_solve()
+    with pytest.raises(AssertionError):
+        hopcroft_solve(loc=loc, mat=np.zeros((2, 2)))
+
+
+def test_front_end_rejects_infeasible_input_with_the_reference_text(built_lib):
+    """auction_.pyx:608-612: raised before any solver (or GPU) is touched."""
+    spec = dict(kind="narrow", n=50, m=50, density=0.1, seed=3, m_eff=30)
+    loc = cases.matching_graph(spec)
+    val = np.ones(loc.shape[0])
+    n_true = int(loc[:, 0].max()) + 1
+    card = cardinality(loc, n_true, int(loc[:, 1].max()) + 1)
+    assert card == 30
+    with pytest.raises(ValueError, match=rf"Maximum matching possible only involves {card} out of {n_true} rows"):
+        from_sparse(loc, val, problem="max", cardinality_check=True)
