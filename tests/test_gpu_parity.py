@@ -326,3 +326,31 @@ def test_integration_md_binding_stub_works(gpu_lib):
         assert np.array_equal(sol, ref["sol"])
         for k in ("its", "nreductions", "eCE", "soln_found", "n_assigned", "obj", "final_eps", "start_eps"):
             assert solver.meta[k] == ref["meta"][k], k
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_random_instances_vs_oracle(seed, gpu_lib):
+    """Random shapes / densities / value kinds / problems / thresholds / engines: sol, its, nreductions, objective
+    and the scanned-edge count against the C oracle.  Sizes chosen so that the tile-major engine (several
+    tiles, partial rounds), k_round_small, the large-round kernels and both tail paths all occur."""
+    r = np.random.default_rng(1000 + seed)
+    n = int(r.choice([90, 700, 2500, 9000, 20000]))
+    m = n if r.random() < 0.6 else int(n * r.uniform(1.05, 2.0))
+    density = float(r.choice([3.0, 8.0, 30.0])) / m
+    ints = int(r.choice([0, 0, 2, 7]))
+    prob = "max" if r.random() < 0.6 else "min"
+    loc, val = synth.gen_sparse(n, m, density, seed=50 + seed, integer_values=ints)
+    kw = dict(problem=prob, cardinality_check=False, max_iter=int(r.choice([10**8, 10**8, 500, 37])))
+    gpu = dict(tail_threshold=[None, 0, 5, 300][seed % 4], tiled_min_k=[None, 1, -1][seed % 3])
+    gpu = {k: v for k, v in gpu.items() if v is not None}
+    o = orc.from_sparse(loc, val.copy(), **kw)
+    osol = o.solve()
+    g = from_sparse(loc, val.copy(), **kw, **gpu)
+    gsol = g.solve()
+    assert np.array_equal(gsol, osol), (n, m, density, ints, prob, kw, gpu)
+    for k in cases.META_KEYS:
+        assert g.meta[k] == o.meta[k], k
+    sg, so = g.state(), o.state()
+    assert np.array_equal(sg["p"].view(np.uint64), so["p"].view(np.uint64))
+    assert np.array_equal(sg["U"][:sg["K"]], so["U"][:so["K"]])
+    assert g.gpu["edges_scanned"] == o.extra["edges_scanned"] and g.gpu["obj_f64"] == o.extra["obj_f64"]
