@@ -66,6 +66,162 @@ __global__ __launch_bounds__(256) void k_sync_from_rec(const PriceRec *rec, doub
 
 // STAMP = diagnostic build: wavefront 0 accumulates s_memtime deltas of the four segments of a round
 // (bid | barrier | resolve+assign+compact | barrier) into Ctl::dbg; never used for reported timings.
+// ---- pair mode: K == 2 (30 % of the small rounds at C3: two eviction chains running side by side) -------------
+// One wavefront runs both bidders of a round: their rows are requested together, their price records are gathered
+// together (eight gathers in flight instead of four), and each next occupant's row is requested as soon as its
+// winning lane is known -- so the round costs one row latency and one gather latency for both bids, with no
+// barrier and no LDS traffic.  The reference's round is reproduced operation by operation: both bids use the
+// prices of the previous round (records are stored after both bids are formed), RESOLVE keeps the earlier list
+// position on equal bids (:379), the evicted owner inherits the winner's slot (:409), push_all_left moves slot 1
+// into an emptied slot 0 (:137-162).  Returns with K < 2 (or nits == max_iter) and the list written back.
+template <class E>
+__device__ __forceinline__ void tail_pair_mode(const TailArgs &a, const E &ed, int *sU, int *sStart, int &K,
+                                               long long &nits, const long long max_iter, const double eps,
+                                               unsigned long long &edges, unsigned long long &bids, int &err) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const double ninf = -__builtin_huge_val();
+    int pi[2] = {sU[0], sU[1]}, ps[2] = {sStart[0], sStart[1]};
+    int c[2][4], e[2];
+    double av[2][4];
+    auto request = [&](int X, int person, int start) {  // first four 64-edge chunks of a row + its end
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ed.load_nt(start + u * kWave + lane, c[X][u], av[X][u]);
+        e[X] = a.row_ptr[person + 1];
+    };
+    request(0, pi[0], ps[0]);
+    request(1, pi[1], ps[1]);
+    for (;;) {
+        Top2 x[2];
+        int c1[2], o1[2], os1[2];
+        double a1[2];
+        PriceRec r[2][4];
+        int cc[2][4];
+#pragma unroll
+        for (int X = 0; X < 2; ++X) {
+            x[X].v = ninf;
+            x[X].w = ninf;
+            x[X].g = -1;
+            c1[X] = 0;
+            o1[X] = -1;
+            os1[X] = 0;
+            a1[X] = 0.0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {  // all eight gathers are issued before any of them is used
+                const bool ok = ps[X] + u * kWave + lane < e[X];
+                cc[X][u] = ok ? c[X][u] : -1;
+                r[X][u] = a.rec[ok ? c[X][u] : 0];
+            }
+        }
+#pragma unroll
+        for (int X = 0; X < 2; ++X) {
+            auto update = [&](int cu, double au, const PriceRec &ru, int g) {
+                const bool ok = cu >= 0;
+                const double v = ok ? au - ru.price : ninf;        // vi = cost - p[j]   (:350)
+                const bool ge = ok & (v >= x[X].v);                // :351
+                x[X].w = __builtin_fmax(x[X].w, __builtin_fmin(v, x[X].v));  // :353 / :357-358
+                x[X].v = __builtin_fmax(x[X].v, v);
+                x[X].g = ge ? g : x[X].g;
+                c1[X] = ge ? cu : c1[X];
+                a1[X] = ge ? au : a1[X];
+                o1[X] = ge ? ru.owner : o1[X];
+                os1[X] = ge ? ru.ostart : os1[X];
+            };
+#pragma unroll
+            for (int u = 0; u < 4; ++u) update(cc[X][u], av[X][u], r[X][u], ps[X] + u * kWave + lane);
+            // rows longer than 256 edges (wave-uniform, rare at the BASELINE densities): plain loads
+            for (int base = ps[X] + 4 * kWave; base < e[X]; base += kWave) {
+                const int g = base + lane;
+                int cu;
+                double au;
+                ed.load_nt(min(g, e[X] - 1), cu, au);
+                const PriceRec ru = a.rec[cu];
+                update(g < e[X] ? cu : -1, au, ru, g);
+            }
+        }
+        // winners first (see wave_bid_rec), then the next occupants' rows, then the second-best values
+        int src[2], prev[2], pst[2];
+        double W[2];
+        bool fast[2];
+        Top2 t2[2];
+#pragma unroll
+        for (int X = 0; X < 2; ++X) {
+            const int hi = __double2hiint(x[X].v);
+            const int k = hi ^ ((hi >> 31) & 0x7fffffff);
+            const int kmax = wave_max_i32(k);
+            const unsigned long long cand = __ballot(k == kmax);
+            fast[X] = __popcll(cand) == 1;  // wave-uniform
+            if (fast[X]) {
+                src[X] = __ffsll((long long)cand) - 1;
+            } else {
+                const int g_mine = x[X].g;
+                t2[X] = top2_wave_reduce(x[X]);
+                src[X] = __ffsll((long long)__ballot(g_mine == t2[X].g)) - 1;
+            }
+            prev[X] = __builtin_amdgcn_readlane(o1[X], src[X]);
+            pst[X] = __builtin_amdgcn_readlane(os1[X], src[X]);
+        }
+        const int len0 = e[0] - ps[0], len1 = e[1] - ps[1];
+        const int col0 = __builtin_amdgcn_readlane(c1[0], src[0]), col1 = __builtin_amdgcn_readlane(c1[1], src[1]);
+        // a bidder wins unless both bid on one object; which of the two wins is only known with the bids, so the
+        // rows are requested for the common case (both win) and re-requested for a loser below
+        request(0, prev[0], pst[0]);
+        request(1, prev[1], pst[1]);
+        unsigned long long key[2];
+#pragma unroll
+        for (int X = 0; X < 2; ++X) {
+            W[X] = fast[X] ? wave_max_f64(lane == src[X] ? x[X].w : x[X].v) : t2[X].w;
+            const double cost = readlane_f64(a1[X], src[X]);
+            const double bid = (cost - W[X]) + eps;  // bbest = costbest - wi + eps   (:360)
+            if (!(bid >= 0.0)) err |= kErrNegativeBid;
+            key[X] = bid_to_key(bid);
+        }
+        edges += (unsigned long long)(len0 + len1);
+        bids += 2;
+        nits += 1;
+        // RESOLVE (:375-385): strict ">" -- the earlier list position keeps an object on equal bids
+        bool win0 = true, win1 = true;
+        if (col0 == col1) {
+            if (key[1] > key[0]) win0 = false;
+            else win1 = false;
+        }
+        // ASSIGN (:396-418): a winner's slot goes to the evicted owner (or becomes a hole), a loser stays
+        if (lane == 0) {
+            if (win0) apply_winner(a, pi[0], ps[0], col0, prev[0], key[0]);
+            if (win1) apply_winner(a, pi[1], ps[1], col1, prev[1], key[1]);
+        }
+        if (!win0) request(0, pi[0], ps[0]);  // (wave-uniform, rare) the loser bids again from its own row
+        else {
+            pi[0] = prev[0];
+            ps[0] = pst[0];
+        }
+        if (!win1) request(1, pi[1], ps[1]);
+        else {
+            pi[1] = prev[1];
+            ps[1] = pst[1];
+        }
+        // push_all_left (:137-162) on two slots
+        if (pi[0] == -1 && pi[1] != -1) {
+            pi[0] = pi[1];
+            ps[0] = ps[1];
+            e[0] = e[1];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                c[0][u] = c[1][u];
+                av[0][u] = av[1][u];
+            }
+            pi[1] = -1;
+        }
+        K = (pi[0] != -1) + (pi[1] != -1);
+        if (K < 2 || nits >= max_iter) break;
+    }
+    if (lane == 0) {
+        sU[0] = pi[0];
+        sU[1] = pi[1];
+        sStart[0] = ps[0];
+        sStart[1] = ps[1];
+    }
+}
+
 template <class E, bool STAMP>
 __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
     __shared__ int sU[kTailMax];
@@ -115,6 +271,21 @@ __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
     if (STAMP) t_prev = __builtin_amdgcn_s_memtime();
 
     for (;;) {
+        if (K == 2 && !STAMP) {
+            // ---- pair mode: wavefront 0 runs the rounds alone until K < 2 (or max_iter), see tail_pair_mode
+            if (wave == 0) {
+                tail_pair_mode(a, ed, sU, sStart, K, nits, max_iter, eps, edges, bids, err);
+                if (lane == 0) {
+                    sK = K;
+                    sNits = nits;
+                }
+            }
+            __syncthreads();
+            K = sK;
+            nits = sNits;
+            if (K == 0 || nits >= max_iter) break;
+            continue;  // K == 1: chain mode
+        }
         // ---- BID: one wavefront per bidder ---------------------------------------------------
         if (K == 1) {
             // ---- chain mode: one bidder per round until the phase ends (K never grows).  Wavefront 0 runs
