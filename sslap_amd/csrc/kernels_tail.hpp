@@ -222,6 +222,179 @@ __device__ __forceinline__ void tail_pair_mode(const TailArgs &a, const E &ed, i
     }
 }
 
+// ---- team mode: 3 <= K <= 16 ------------------------------------------------------------------------------------
+// Chain mode on every wavefront: wavefront w serves list slot w, keeps that slot's row in registers and requests the
+// row of its next occupant (the owner its bidder evicts inherits the slot, :409 -- true for 99.9 % of the bids) as
+// soon as the winning lane is known.  The bids of a round go to LDS; wavefront 0 runs RESOLVE / ASSIGN /
+// push_all_left on lanes = slots and publishes the new list; two barriers per round, both ordering LDS traffic
+// ONLY (s_waitcnt lgkmcnt(0); s_barrier), so that the row requests stay in flight across the resolve phase.
+// Two traps: (1) a wave-uniform row_ptr[person + 1] would be a SCALAR load, which shares lgkmcnt with LDS and would
+// make every barrier wait an L2 / HBM latency -- the row end is loaded through the vector path; (2) the winners'
+// records are stored by wavefront 0 before the second barrier and gathered by everybody after it (one CU, one
+// in-order vector L1), without waiting for the stores' acknowledgement.
+constexpr int kTeamMax = 16;
+__device__ __forceinline__ void tail_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <class E>
+__device__ __forceinline__ void tail_team_mode(const TailArgs &a, const E &ed, int *sU, int *sStart,
+                                               unsigned long long *sKey, int *sObj, int *sPrev, int *sPst, int &K,
+                                               long long &nits, const long long max_iter, const double eps,
+                                               unsigned long long &edges, unsigned long long &bids, int &err) {
+    const int lane = threadIdx.x & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const double ninf = -__builtin_huge_val();
+    __shared__ int mU[2][kTeamMax], mS[2][kTeamMax], mK[2];  // the list and K, double-buffered by round parity
+    int pi, ps, c[4], e;
+    double av[4];
+    const int lane_zero = (int)__builtin_amdgcn_mbcnt_hi(0u, __builtin_amdgcn_mbcnt_lo(0u, 0u));  // 0, not uniform
+    auto request = [&](int person, int start) {  // first four 64-edge chunks of a row + its end (vector loads)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ed.load_nt(start + u * kWave + lane, c[u], av[u]);
+        e = a.row_ptr[person + 1 + lane_zero];
+    };
+    if (threadIdx.x < kTeamMax) {
+        mU[0][threadIdx.x] = threadIdx.x < K ? sU[threadIdx.x] : -1;
+        mS[0][threadIdx.x] = threadIdx.x < K ? sStart[threadIdx.x] : 0;
+    }
+    pi = wave < K ? sU[wave] : -1;
+    ps = wave < K ? sStart[wave] : 0;
+    if (wave < K) request(pi, ps);
+    __syncthreads();
+    int par = 0;
+    for (;;) {
+        int prev = -1, pst = 0;
+        if (wave < K) {  // wave-uniform: BID for my slot (slots < K are always occupied: the list is compact)
+            Top2 x;
+            x.v = ninf;
+            x.w = ninf;
+            x.g = -1;
+            int c1 = 0, o1 = -1, os1 = 0;
+            double a1 = 0.0;
+            PriceRec r[4];
+            int cc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool ok = ps + u * kWave + lane < e;
+                cc[u] = ok ? c[u] : -1;
+                r[u] = a.rec[ok ? c[u] : 0];
+            }
+            auto update = [&](int cu, double au, const PriceRec &ru, int g) {
+                const bool ok = cu >= 0;
+                const double v = ok ? au - ru.price : ninf;        // vi = cost - p[j]   (:350)
+                const bool ge = ok & (v >= x.v);                   // :351
+                x.w = __builtin_fmax(x.w, __builtin_fmin(v, x.v)); // :353 / :357-358
+                x.v = __builtin_fmax(x.v, v);
+                x.g = ge ? g : x.g;
+                c1 = ge ? cu : c1;
+                a1 = ge ? au : a1;
+                o1 = ge ? ru.owner : o1;
+                os1 = ge ? ru.ostart : os1;
+            };
+#pragma unroll
+            for (int u = 0; u < 4; ++u) update(cc[u], av[u], r[u], ps + u * kWave + lane);
+            for (int base = ps + 4 * kWave; base < e; base += kWave) {  // rows longer than 256 edges
+                const int g = base + lane;
+                int cu;
+                double au;
+                ed.load_nt(min(g, e - 1), cu, au);
+                const PriceRec ru = a.rec[cu];
+                update(g < e ? cu : -1, au, ru, g);
+            }
+            const int len = e - ps;
+            const int hi = __double2hiint(x.v);
+            const int k = hi ^ ((hi >> 31) & 0x7fffffff);
+            const int kmax = wave_max_i32(k);
+            const unsigned long long cand = __ballot(k == kmax);
+            const bool fast = __popcll(cand) == 1;  // wave-uniform
+            int src;
+            Top2 t2;
+            if (fast) {
+                src = __ffsll((long long)cand) - 1;
+            } else {
+                const int g_mine = x.g;
+                t2 = top2_wave_reduce(x);
+                src = __ffsll((long long)__ballot(g_mine == t2.g)) - 1;
+            }
+            prev = __builtin_amdgcn_readlane(o1, src);
+            pst = __builtin_amdgcn_readlane(os1, src);
+            const int col = __builtin_amdgcn_readlane(c1, src);
+            request(prev, pst);  // the owner my bidder evicts if it wins (prev == -1: a valid, unused address)
+            const double W = fast ? wave_max_f64(lane == src ? x.w : x.v) : t2.w;
+            const double cost = readlane_f64(a1, src);
+            const double bid = (cost - W) + eps;  // bbest = costbest - wi + eps   (:360)
+            if (!(bid >= 0.0)) err |= kErrNegativeBid;
+            edges += (unsigned long long)len;
+            bids += 1;
+            if (lane == 0) {
+                sKey[wave] = bid_to_key(bid);
+                sObj[wave] = col;
+                sPrev[wave] = prev;
+                sPst[wave] = pst;
+            }
+        }
+        tail_barrier_lds();  // the bids are in LDS; row requests stay in flight
+        if (wave == 0) {     // RESOLVE / ASSIGN / push_all_left on lanes = slots
+            const bool act = lane < K;
+            const unsigned long long lkey = act ? sKey[lane] : 0ull;
+            const int lobj = act ? sObj[lane] : (-2 - lane);
+            bool lose = false;
+            for (int m = 0; m < K; ++m) {  // :375-385, all pairs via readlane
+                const int om = __builtin_amdgcn_readlane(lobj, m);
+                const bool same = (om == lobj) && (m != lane);
+                if (__any(same)) {  // wave-uniform; two bidders on one object are the exception
+                    const unsigned long long km = readlane_u64(lkey, m);
+                    lose |= same && (km > lkey || (km == lkey && m < lane));
+                }
+            }
+            const int me = act ? mU[par][lane] : -1;
+            const int mst = act ? mS[par][lane] : 0;
+            const bool won = act && !lose;
+            const int lprev = sPrev[lane], lpst = sPst[lane];
+            if (won) apply_winner(a, me, mst, lobj, lprev, lkey);  // :396-418
+            int u = won ? lprev : me;  // the evicted owner inherits the slot (:409) / hole (:412) / a loser stays
+            int st = won ? lpst : mst;
+            const unsigned long long kmask = (1ull << K) - 1ull;
+            const unsigned long long holes = __ballot(act && u == -1) & kmask;
+            const int Kn = K - __popcll(holes);
+            const unsigned long long lmask = (1ull << Kn) - 1ull;
+            unsigned long long hl = holes & lmask;            // empty slots left of K'
+            unsigned long long mv = ~holes & ~lmask & kmask;  // persons right of K'
+            while (hl) {  // wave-uniform, rare: k-th hole <- k-th mover (:137-162)
+                const int hk = __ffsll((long long)hl) - 1, mk = __ffsll((long long)mv) - 1;
+                const int mu = __builtin_amdgcn_readlane(u, mk), ms = __builtin_amdgcn_readlane(st, mk);
+                if (lane == hk) {
+                    u = mu;
+                    st = ms;
+                }
+                hl &= hl - 1;
+                mv &= mv - 1;
+            }
+            if (lane < kTeamMax) {
+                mU[par ^ 1][lane] = lane < Kn ? u : -1;
+                mS[par ^ 1][lane] = st;
+            }
+            if (lane == 0) mK[par ^ 1] = Kn;
+        }
+        tail_barrier_lds();  // the new list is in LDS, the winners' records have been issued
+        par ^= 1;
+        const int Kold = K;
+        K = mK[par];
+        nits += 1;
+        if (wave < Kold) {  // my slot's new occupant: usually exactly the row requested above
+            const int np = wave < kTeamMax ? mU[par][wave] : -1, ns = wave < kTeamMax ? mS[par][wave] : 0;
+            if (np >= 0 && !(prev >= 0 && np == prev && ns == pst)) request(np, ns);  // lost, or moved by push_all_left
+            pi = np;
+            ps = ns;
+        }
+        if (K <= 2 || nits >= max_iter) break;
+    }
+    __syncthreads();
+    if (threadIdx.x < kTeamMax) {
+        sU[threadIdx.x] = mU[par][threadIdx.x];
+        sStart[threadIdx.x] = mS[par][threadIdx.x];
+    }
+    __syncthreads();
+}
+
 template <class E, bool STAMP>
 __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
     __shared__ int sU[kTailMax];
@@ -271,6 +444,12 @@ __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
     if (STAMP) t_prev = __builtin_amdgcn_s_memtime();
 
     for (;;) {
+        if (K >= 3 && K <= kTeamMax && !STAMP) {
+            // ---- team mode: every wavefront, until K <= 2 (or max_iter), see tail_team_mode
+            tail_team_mode(a, ed, sU, sStart, sKey, sObj, sPrev, sPst, K, nits, max_iter, eps, edges, bids, err);
+            if (K == 0 || nits >= max_iter) break;
+            continue;
+        }
         if (K == 2 && !STAMP) {
             // ---- pair mode: wavefront 0 runs the rounds alone until K < 2 (or max_iter), see tail_pair_mode
             if (wave == 0) {
