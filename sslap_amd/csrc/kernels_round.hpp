@@ -33,6 +33,7 @@ struct RoundArgs {
     int thr;                      // tail threshold
     int rank, world;              // bidder shard
     int shard_min_K;              // shard only rounds with K >= this (multi-GPU), see shard_range
+    int small_round;              // this round is finished by k_round_small: k_bid skips the global atomicMax
     float eps;
     int launch_idx;
     int gather_max_K;             // k_bid runs only for K < gather_max_K (k_bid_tiled takes the rest); 0 = no limit
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(kBidBlock) void k_bid(RoundArgs a, E ed) {
         if (lane == 0) {
             a.bid_key[n] = key;
             a.bid_obj[n] = obj;
-            atomicMax(&a.best_key[obj], key);
+            if (!a.small_round) atomicMax(&a.best_key[obj], key);  // k_round_small forms the maxima itself
         }
         edges += (unsigned long long)(e - s);
         nb += 1;
@@ -330,22 +331,33 @@ __global__ __launch_bounds__(1024) void k_compact_small(RoundArgs a) {
 }
 
 // RESOLVE + ASSIGN + push_all_left + round end of a round with few bidders in ONE launch (a single 1024-thread
-// workgroup; the host uses it while K_ub <= kRoundSmallMax and the round is not sharded over GPUs).  Same
-// operations as k_tiebreak, k_apply (seen from the bidder: position n won iff best_pos[object] == n) and
-// k_compact_small; such rounds are bound by launch boundaries (4 launches of ~5 us for a few hundred bids).
-constexpr int kRoundSmallMax = 4096;
+// workgroup; the host uses it while K_ub <= kRoundSmallMax, the round is not sharded over GPUs and the bids were
+// made by k_bid with RoundArgs::small_round set, i.e. WITHOUT the global atomicMax).  The per-object arg-max of
+// :375-385 -- highest bid, earliest list position among equal bids -- is formed in an LDS hash table keyed by
+// object (64-bit ds_max on the bid's bit pattern, then ds_min on the position among the holders of the maximum),
+// so the resolve phase costs LDS latencies instead of two global atomic round trips; best_key / best_pos are not
+// touched.  Such rounds are bound by latency and launch boundaries, not by work.
+constexpr int kRoundSmallMax = 2048;
 constexpr int kRoundSmallSlots = kRoundSmallMax / 1024;  // list positions per thread, kept in registers
+constexpr int kRoundSmallHash = 2 * kRoundSmallMax;      // load factor <= 0.5
 __global__ __launch_bounds__(1024) void k_round_small(RoundArgs a) {
     Ctl *ctl = a.ctl;
     if (!round_live(ctl, a.thr)) return;
     const int K = ctl->K;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     __shared__ int s_cnt[16], s_wl[16], s_wm[16];
-    __shared__ int s_hole[kRoundSmallMax], s_mover[kRoundSmallMax];  // push_all_left lists (32 KB)
-    // Everything a position needs is fetched up front (two dependent rounds of loads) and stays in registers;
-    // after the tie-break only best_pos is read again.
+    __shared__ int s_hole[kRoundSmallMax], s_mover[kRoundSmallMax];  // push_all_left lists
+    __shared__ int hObj[kRoundSmallHash], hPos[kRoundSmallHash];
+    __shared__ unsigned long long hKey[kRoundSmallHash];
+    for (int h = t; h < kRoundSmallHash; h += 1024) {
+        hObj[h] = -1;
+        hKey[h] = 0ull;
+        hPos[h] = kPosNone;
+    }
+    // Everything a position needs is fetched up front and stays in registers.
     int obj[kRoundSmallSlots], who[kRoundSmallSlots], prev[kRoundSmallSlots], rstart[kRoundSmallSlots];
-    unsigned long long key[kRoundSmallSlots], bkey[kRoundSmallSlots];
+    int hs[kRoundSmallSlots];
+    unsigned long long key[kRoundSmallSlots];
 #pragma unroll
     for (int q = 0; q < kRoundSmallSlots; ++q) {
         const int n = min(q * 1024 + t, K - 1);  // unconditional loads, masked below
@@ -354,20 +366,34 @@ __global__ __launch_bounds__(1024) void k_round_small(RoundArgs a) {
         who[q] = a.U[n];
     }
 #pragma unroll
-    for (int q = 0; q < kRoundSmallSlots; ++q) {
-        bkey[q] = a.best_key[obj[q]];
+    for (int q = 0; q < kRoundSmallSlots; ++q) {  // in flight during the LDS phases below
         prev[q] = a.o2p[obj[q]];     // :401
         rstart[q] = a.row_ptr[who[q]];
     }
+    __syncthreads();  // table cleared
+#pragma unroll
+    for (int q = 0; q < kRoundSmallSlots; ++q) {
+        hs[q] = 0;
+        if (q * 1024 + t < K) {
+            int h = (int)(((unsigned)obj[q] * 2654435761u) >> 16) & (kRoundSmallHash - 1);
+            for (;;) {  // open addressing; K <= half the table
+                const int old = atomicCAS(&hObj[h], -1, obj[q]);
+                if (old == -1 || old == obj[q]) break;
+                h = (h + 1) & (kRoundSmallHash - 1);
+            }
+            hs[q] = h;
+            atomicMax(&hKey[h], key[q]);  // best bid of the object
+        }
+    }
+    __syncthreads();
     // first bidder in list order among those holding the best bid of an object (:379, strict ">")
 #pragma unroll
     for (int q = 0; q < kRoundSmallSlots; ++q)
-        if (q * 1024 + t < K && key[q] == bkey[q]) atomicMin(&a.best_pos[obj[q]], q * 1024 + t);
-    __threadfence();  // the atomics have reached L2 (best_pos is not in this CU's L1: nothing has read it yet)
+        if (q * 1024 + t < K && hKey[hs[q]] == key[q]) atomicMin(&hPos[hs[q]], q * 1024 + t);
     __syncthreads();
     int bpos[kRoundSmallSlots];
 #pragma unroll
-    for (int q = 0; q < kRoundSmallSlots; ++q) bpos[q] = a.best_pos[obj[q]];
+    for (int q = 0; q < kRoundSmallSlots; ++q) bpos[q] = hPos[hs[q]];
     int holes = 0;
     int u[kRoundSmallSlots];  // U[n] after the assignment phase
 #pragma unroll
@@ -386,9 +412,7 @@ __global__ __launch_bounds__(1024) void k_round_small(RoundArgs a) {
             u[q] = prev[q];                          // :409 evicted owner inherits the slot / :412 hole (-1)
             holes += prev[q] == -1;
             a.p2o[i] = j;                            // :417
-            a.o2p[j] = i;                            // :418
-            a.best_key[j] = 0ull;                    // :421-422
-            a.best_pos[j] = kPosNone;
+            a.o2p[j] = i;                            // :418 (:421-422: best_key / best_pos were never written)
         }
     }
     for (int off = 32; off >= 1; off >>= 1) holes += __shfl_xor(holes, off);

@@ -251,9 +251,9 @@ __device__ __forceinline__ void tail_team_mode(const TailArgs &a, const E &ed, i
         for (int u = 0; u < 4; ++u) ed.load_nt(start + u * kWave + lane, c[u], av[u]);
         e = a.row_ptr[person + 1 + lane_zero];
     };
-    if (threadIdx.x < kTeamMax) {
-        mU[0][threadIdx.x] = threadIdx.x < K ? sU[threadIdx.x] : -1;
-        mS[0][threadIdx.x] = threadIdx.x < K ? sStart[threadIdx.x] : 0;
+    if ((int)threadIdx.x < kTeamMax) {
+        mU[0][threadIdx.x] = (int)threadIdx.x < K ? sU[threadIdx.x] : -1;
+        mS[0][threadIdx.x] = (int)threadIdx.x < K ? sStart[threadIdx.x] : 0;
     }
     pi = wave < K ? sU[wave] : -1;
     ps = wave < K ? sStart[wave] : 0;

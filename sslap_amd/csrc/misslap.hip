@@ -141,6 +141,7 @@ struct misslap_solver {
     bool finished = false;
     int64_t max_iter = 0;
     int thr = -1;
+    bool round_small = false;  // the current round's bids skip the global atomicMax and k_round_small finishes it
     bool profile_all = false;  // profile >= 2: events around every k_bid launch, not only the full scans
     int rounds_per_sync = kDefaultRoundsPerSync;
     int rank = 0, world = 1;
@@ -187,6 +188,7 @@ RoundArgs round_args(misslap_solver *h) {
     a.rank = h->rank;
     a.world = h->world;
     a.shard_min_K = h->world > 1 ? h->shard_min_K : 0;
+    a.small_round = h->round_small ? 1 : 0;
     a.eps = h->eps;
     a.launch_idx = 0;
     a.gather_max_K = h->tiled_ok ? h->tiled_min_K : 0;
@@ -290,7 +292,14 @@ int launch_bid_scan2d(misslap_solver *h) {
     return MISSLAP_OK;
 }
 
+// rounds with few bidders that are not sharded over GPUs: tiebreak, apply and compaction in one launch
+bool use_round_small(const misslap_solver *h) {
+    return h->K_ub <= kRoundSmallMax && (h->world == 1 || h->K_ub < h->shard_min_K);
+}
+
 int launch_bid(misslap_solver *h) {
+    // (not behind a full-scan engine launch: the engines always feed best_key, which k_round_small ignores)
+    h->round_small = use_round_small(h) && !(h->tiled_ok && h->K_ub >= h->tiled_min_K);
     if (h->tiled_ok && h->K_ub >= h->tiled_min_K) {
         int rc = h->scan2d ? launch_bid_scan2d(h) : launch_bid_tiled(h);  // no-op on the device when K < tiled_min_K
         if (rc) return rc;
@@ -331,13 +340,8 @@ int launch_bid(misslap_solver *h) {
     return MISSLAP_OK;
 }
 
-// rounds with few bidders that are not sharded over GPUs: tiebreak, apply and compaction in one launch
-bool use_round_small(const misslap_solver *h) {
-    return h->K_ub <= kRoundSmallMax && (h->world == 1 || h->K_ub < h->shard_min_K);
-}
-
 int launch_tiebreak(misslap_solver *h) {
-    if (use_round_small(h)) return MISSLAP_OK;  // k_round_small (launch_apply) resolves the ties itself
+    if (h->round_small) return MISSLAP_OK;  // k_round_small (launch_apply) resolves the ties itself
     RoundArgs a = round_args(h);
     const long long share = h->K_ub;
     hipLaunchKernelGGL(k_tiebreak, dim3(blocks_for(share, 256)), dim3(256), 0, h->stream, a);
@@ -347,7 +351,8 @@ int launch_tiebreak(misslap_solver *h) {
 
 int launch_apply(misslap_solver *h) {
     RoundArgs a = round_args(h);
-    if (use_round_small(h)) {
+    if (h->round_small) {
+        h->round_small = false;
         h->K_exact = false;
         hipLaunchKernelGGL(k_round_small, dim3(1), dim3(1024), 0, h->stream, a);
         HIP_TRY(hipGetLastError());
