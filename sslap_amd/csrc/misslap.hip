@@ -65,7 +65,7 @@ double now_ms() {
 constexpr int kDefaultTailThreshold = 64;
 constexpr int kDefaultTailThresholdBig = 128;  // n_cols > kTailBigCols
 constexpr long long kTailBigCols = 500000;
-constexpr int kDefaultRoundsPerSync = 8;
+constexpr int kDefaultRoundsPerSync = 16;
 constexpr int kMaxGridBlocks = 2048;  // 256 CUs x 8 resident 256-thread blocks
 constexpr int kNumTiledShapes = 8;
 // launch shapes of k_bid_tiled: {threads, persons per lane group, persons in flight, loads per segment,
