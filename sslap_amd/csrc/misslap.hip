@@ -59,11 +59,12 @@ double now_ms() {
     return std::chrono::duration<double, std::milli>(clk::now().time_since_epoch()).count();
 }
 
-// Rounds with K <= threshold run in the tail kernel.  Break-even against a grid round (two launches since
-// k_round_small), measured with tools/sweep_thr.py: C2 48..64 (278 ms; 128: 286), C3 64 (814 ms; 128: 830; 256: 872),
-// C5 128 (6.28 s; 64: 6.40) -- a grid round costs more when the price table no longer fits L2.
-constexpr int kDefaultTailThreshold = 64;
-constexpr int kDefaultTailThresholdBig = 128;  // n_cols > kTailBigCols
+// Rounds with K <= threshold run in the tail kernel.  Break-even against a grid round (two launches: k_bid +
+// k_round_small), measured with tools/sweep_thr.py after every change of either side: C2 32 (249 ms; 64: 253),
+// C3 32..48 (707 ms; 64: 713; 24: 723), C5 64 (5.85 s; 48: 5.97; 96: 6.08) -- a grid round costs more when the
+// price table no longer fits L2.
+constexpr int kDefaultTailThreshold = 40;
+constexpr int kDefaultTailThresholdBig = 64;  // n_cols > kTailBigCols
 constexpr long long kTailBigCols = 500000;
 constexpr int kDefaultRoundsPerSync = 16;
 constexpr int kMaxGridBlocks = 2048;  // 256 CUs x 8 resident 256-thread blocks
