@@ -142,8 +142,16 @@ def main():
         e = torch.tensor([sh], dtype=torch.int64, device="cuda")
         dist.all_reduce(e, op=dist.ReduceOp.SUM)
         edges_all = int(e.item()) + repl
+        # bid-phase throughput of the full scans over all ranks: every rank scans its shard of the K = N rounds at
+        # the same time, so the aggregate rate is (sum of the shards' edges) / (slowest rank's kernel time)
+        fe = torch.tensor([sum(g["fullscan_edges"] for _, g in runs)], dtype=torch.int64, device="cuda")
+        fm = torch.tensor([sum(g["fullscan_ms"] for _, g in runs)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(fe, op=dist.ReduceOp.SUM)
+        dist.all_reduce(fm, op=dist.ReduceOp.MAX)
+        fs_all_edges, fs_max_ms = int(fe.item()), float(fm.item())
     else:
         edges_all = sum(g["edges_scanned"] for _, g in runs)
+        fs_all_edges, fs_max_ms = None, None
 
     if rank == 0:
         from sslap_amd import _lib
@@ -205,6 +213,12 @@ def main():
                 "fullscan_launches": fs_launches, "fullscan_avg_us": round(1e3 * fs_ms / max(fs_launches, 1), 2),
                 "fullscan_medges_s": round(fs_edges / (fs_ms * 1e-3) / 1e6, 1) if fs_ms else None,
                 "fullscan_GBs": round(fs_achieved, 1), "fullscan_frac_of_hbm_peak": round(fs_achieved / HBM_PEAK_GBS, 4),
+                # N > 1: the full scans of all ranks together (rank 0's own share is the line above)
+                "fullscan_all_ranks_medges_s": (round(fs_all_edges / (fs_max_ms * 1e-3) / 1e6, 1)
+                                                if fs_all_edges and fs_max_ms else None),
+                "fullscan_all_ranks_frac_of_hbm_peak": (round(fs_all_edges * bpe / (fs_max_ms * 1e-3) / 1e9
+                                                              / (HBM_PEAK_GBS * world), 4)
+                                                        if fs_all_edges and fs_max_ms else None),
                 "k_bid_tiled": {"launches": til_launches, "ms": round(til_ms, 3), "edges": til_edges,
                                 "min_K": gpu.get("tiled_min_K")},
                 # profile level 1 times only the FULL-SCAN launches of the gather kernel (configs where the tiled

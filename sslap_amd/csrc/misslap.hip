@@ -246,7 +246,7 @@ int launch_bid_tiled(misslap_solver *h) {
             return fail(MISSLAP_ERR_STATE, "profile buffer exhausted (%d bid launches)", h->launch_idx);
         pr = prof_next(h, 2);
         if (!pr) return fail(MISSLAP_ERR_HIP, "hipEventCreate failed");
-        pr->fullscan = h->phase_fresh && h->world == 1;
+        pr->fullscan = h->phase_fresh;  // K == N; with several ranks: this rank's share of the full scan
         pr->launch_idx = a.launch_idx = h->launch_idx++;
         HIP_TRY(hipEventRecord(pr->start, h->stream));
     }
@@ -317,7 +317,7 @@ int launch_bid(misslap_solver *h) {
     ProfRec *pr = nullptr;
     // profile 1 times the full scans only (two event records around each of the ~3000 small launches of a solve
     // cost more host time than the launches themselves); profile 2 / 3 time every launch
-    const bool fullscan = h->phase_fresh && h->world == 1 && !(h->tiled_ok && h->K_ub >= h->tiled_min_K);
+    const bool fullscan = h->phase_fresh && !(h->tiled_ok && h->K_ub >= h->tiled_min_K);
     if (!(h->profile && (h->profile_all || fullscan))) a.launch_edges = nullptr;
     if (h->profile && (h->profile_all || fullscan)) {
         if (h->launch_idx >= h->launch_edges_cap)
