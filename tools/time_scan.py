@@ -16,7 +16,7 @@ modes = [int(m) for m in sys.argv[3:]] or [10, 10, 10]
 loc, val = synth.gen_config(cfg)
 dl, dv = torch.from_numpy(loc).cuda(), torch.from_numpy(val).cuda()
 s = AuctionSolver.from_device_pointers(dl.data_ptr(), dv.data_ptr(), int(loc.shape[0]), problem="max", max_iter=10**8,
-                                       tiled_shape=int(os.environ.get("MISSLAP_TILED_SHAPE", 0)))
+                                       tiled_shape=int(os.environ.get("MISSLAP_TILED_SHAPE", 0)))  # ablation modes 11-16 need shape 3
 out = []
 for m in modes:
     ms = C.c_float()
