@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Extended randomized parity run on the GPU box (same checks as tests/test_gpu_parity.py::test_fuzz_*, more
+seeds and more option mixes).  usage: fuzz_gpu.py [first_seed] [count]"""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
+import numpy as np
+import cases
+from oracle import oracle as orc
+from sslap_amd import from_sparse, synth
+
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+bad = 0
+for seed in range(first, first + count):
+    r = np.random.default_rng(7000 + seed)
+    n = int(r.choice([40, 90, 300, 700, 2500, 6000, 12000]))
+    m = n if r.random() < 0.6 else int(n * r.uniform(1.02, 2.5))
+    density = float(r.choice([2.0, 4.0, 8.0, 30.0, 120.0])) / m
+    ints = int(r.choice([0, 0, 0, 2, 5, 11]))
+    prob = "max" if r.random() < 0.6 else "min"
+    loc, val = synth.gen_sparse(n, m, density, seed=900 + seed, integer_values=ints)
+    kw = dict(problem=prob, cardinality_check=False, max_iter=int(r.choice([10**8, 10**8, 10**8, 3000, 211, 17])),
+              eps_start=float(r.choice([0.0, 0.0, 1.0, 0.01])))
+    gpu = dict(tail_threshold=[None, 0, 3, 17, 40, 200, 1024][seed % 7], tiled_min_k=[None, None, 1, -1][seed % 4],
+               rounds_per_sync=[None, 1, 5][seed % 3])
+    gpu = {k: v for k, v in gpu.items() if v is not None}
+    o = orc.from_sparse(loc, val.copy(), **kw)
+    osol = o.solve()
+    g = from_sparse(loc, val.copy(), **kw, **gpu)
+    gsol = g.solve()
+    sg, so = g.state(), o.state()
+    ok = (np.array_equal(gsol, osol) and all(g.meta[k] == o.meta[k] for k in cases.META_KEYS)
+          and np.array_equal(sg["p"].view(np.uint64), so["p"].view(np.uint64))
+          and np.array_equal(sg["U"][:sg["K"]], so["U"][:so["K"]])
+          and g.gpu["edges_scanned"] == o.extra["edges_scanned"] and g.gpu["obj_f64"] == o.extra["obj_f64"])
+    if not ok:
+        bad += 1
+        print("MISMATCH", seed, n, m, density, ints, prob, kw, gpu, flush=True)
+    elif seed % 20 == 0:
+        print("ok", seed, n, m, g.meta["its"], flush=True)
+print("done", count, "cases,", bad, "mismatches", flush=True)
+sys.exit(1 if bad else 0)
