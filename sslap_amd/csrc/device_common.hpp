@@ -47,6 +47,9 @@ struct Ctl {
     unsigned long long tail_edges;
     unsigned long long shard_edges;  // edges scanned in sharded rounds (multi-GPU: this rank's share only)
     double obj;            // objective accumulator (auction_.pyx:491)
+    double obj_abs;        // sum of |contribution| (any order: only used as a bound, see k_obj_sum)
+    int obj_minexp;        // smallest binary exponent of a lowest set bit among the contributions
+    int pad1;
     unsigned long long dbg[16]; // diagnostic cycle counters of the stamped tail build (profile == 2)
 };
 

@@ -59,6 +59,11 @@ __global__ __launch_bounds__(256) void k_ece(Ctl *ctl, E ed, const int *row_ptr,
     }
 }
 
+__global__ void k_obj_reset(Ctl *ctl) {
+    ctl->obj_abs = 0.0;
+    ctl->obj_minexp = 1 << 20;
+}
+
 // get_obj, step 1 (parallel): the contribution of every person, in row order inside the row:
 // contrib[i] = +val / -val of the stored entry (i, p2o[i]) ('max' / 'min'; val is the sign-flipped
 // copy, so obj -= val restores the caller's sign, :518-521).  Rows whose assigned column is stored
@@ -67,6 +72,8 @@ template <class E>
 __global__ __launch_bounds__(256) void k_obj_rows(Ctl *ctl, E ed, const int *row_ptr, const int *p2o,
                                                   int n_rows, int maximize, double *contrib, int *nmatch) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double abs_sum = 0.0;      // lane 0: bound material for the order-independence test of k_obj_sum
+    int min_exp = 1 << 20;
     for (int i = blockIdx.x * 4 + wave; i < n_rows; i += gridDim.x * 4) {
         const int j = p2o[i];
         int cnt = 0, gsel = -1;
@@ -98,16 +105,55 @@ __global__ __launch_bounds__(256) void k_obj_rows(Ctl *ctl, E ed, const int *row
             contrib[i] = cv;
             nmatch[i] = cnt;
             if (cnt > 1) atomicAdd(&ctl->dup_rows, 1);
+            if (cv != 0.0) {  // binary exponent of the lowest set bit of cv
+                const unsigned long long b = (unsigned long long)__double_as_longlong(cv) & 0x7fffffffffffffffull;
+                const int ex = (int)(b >> 52);
+                const unsigned long long mant = (b & 0xfffffffffffffull) | (ex ? (1ull << 52) : 0ull);
+                const int q = (ex ? ex - 1075 : -1074) + (__ffsll((long long)mant) - 1);
+                min_exp = q < min_exp ? q : min_exp;
+                abs_sum += cv < 0.0 ? -cv : cv;
+            }
         }
+    }
+    if (lane == 0 && abs_sum != 0.0) {
+        atomicMin(&ctl->obj_minexp, min_exp);
+        atomicAdd(&ctl->obj_abs, abs_sum);
     }
 }
 
 // get_obj, step 2: the reference adds in person order into ONE double (:491, :519-521); floating-point
 // addition is not associative, so the sum is reproduced sequentially by a single lane.
+//
+// Exception that costs nothing in exactness: if every contribution is an integer multiple of 2^q and the sum of
+// their magnitudes stays below 2^(q+52), EVERY partial sum in ANY order is exactly representable, no addition
+// rounds, and the result does not depend on the order -- then 1024 threads add in parallel (fp32-exact values of
+// similar magnitude, the usual case, qualify: q >= -20 or so against sums below 2^30).
 template <class E>
-__global__ void k_obj_sum(Ctl *ctl, E ed, const int *row_ptr, const int *p2o, int n_rows, int maximize,
-                          const double *contrib, const int *nmatch) {
-    if (blockIdx.x != 0 || threadIdx.x >= kWave) return;  // one wavefront
+__global__ __launch_bounds__(1024) void k_obj_sum(Ctl *ctl, E ed, const int *row_ptr, const int *p2o, int n_rows,
+                                                  int maximize, const double *contrib, const int *nmatch) {
+    if (blockIdx.x != 0) return;
+    if (ctl->dup_rows == 0) {  // uniform
+        const int q = ctl->obj_minexp;
+        const bool order_free = q >= (1 << 20) || (q > -1000 && 2.0 * ctl->obj_abs < __builtin_ldexp(1.0, q + 52));
+        if (order_free) {
+            __shared__ double s_part[16];
+            double part = 0.0;
+            for (int i = threadIdx.x; i < n_rows; i += 1024) part += contrib[i];
+            for (int off = 32; off >= 1; off >>= 1) {
+                const int lo = __shfl_xor(__double2loint(part), off), hi = __shfl_xor(__double2hiint(part), off);
+                part += __hiloint2double(hi, lo);
+            }
+            if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = part;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double obj = 0.0;
+                for (int w = 0; w < 16; ++w) obj += s_part[w];
+                ctl->obj = obj;
+            }
+            return;
+        }
+    }
+    if (threadIdx.x >= kWave) return;  // one wavefront
     const int lane = threadIdx.x;
     double obj = 0.0;
     if (ctl->dup_rows == 0) {

@@ -946,18 +946,19 @@ MISSLAP_API int misslap_finish(misslap_solver *h, int32_t *person_to_object_out,
     if ((rc = run_ece(h, h->target_eps, &ece))) return rc;  // :297 / :300
     // objective (:302, :489-523)
     HIP_TRY(hipMemsetAsync(&h->ctl->dup_rows, 0, sizeof(int), h->stream));
+    hipLaunchKernelGGL(k_obj_reset, dim3(1), dim3(1), 0, h->stream, h->ctl);
     const int grid = blocks_for(h->n_rows, 4);
     if (h->f32) {
         EdgesF32 ed{h->edges32};
         hipLaunchKernelGGL(k_obj_rows<EdgesF32>, dim3(grid), dim3(256), 0, h->stream, h->ctl, ed, h->row_ptr, h->p2o,
                            h->n_rows, h->maximize, h->contrib, h->nmatch);
-        hipLaunchKernelGGL(k_obj_sum<EdgesF32>, dim3(1), dim3(64), 0, h->stream, h->ctl, ed, h->row_ptr, h->p2o,
+        hipLaunchKernelGGL(k_obj_sum<EdgesF32>, dim3(1), dim3(1024), 0, h->stream, h->ctl, ed, h->row_ptr, h->p2o,
                            h->n_rows, h->maximize, h->contrib, h->nmatch);
     } else {
         EdgesF64 ed{h->col, h->val64};
         hipLaunchKernelGGL(k_obj_rows<EdgesF64>, dim3(grid), dim3(256), 0, h->stream, h->ctl, ed, h->row_ptr, h->p2o,
                            h->n_rows, h->maximize, h->contrib, h->nmatch);
-        hipLaunchKernelGGL(k_obj_sum<EdgesF64>, dim3(1), dim3(64), 0, h->stream, h->ctl, ed, h->row_ptr, h->p2o,
+        hipLaunchKernelGGL(k_obj_sum<EdgesF64>, dim3(1), dim3(1024), 0, h->stream, h->ctl, ed, h->row_ptr, h->p2o,
                            h->n_rows, h->maximize, h->contrib, h->nmatch);
     }
     HIP_TRY(hipGetLastError());
