@@ -354,3 +354,37 @@ def test_fuzz_random_instances_vs_oracle(seed, gpu_lib):
     assert np.array_equal(sg["p"].view(np.uint64), so["p"].view(np.uint64))
     assert np.array_equal(sg["U"][:sg["K"]], so["U"][:so["K"]])
     assert g.gpu["edges_scanned"] == o.extra["edges_scanned"] and g.gpu["obj_f64"] == o.extra["obj_f64"]
+
+
+def test_plain_c_client_of_the_c_abi(tmp_path, gpu_lib):
+    """tests/cabi_client.c -- plain C, no Python / torch in the process -- solves a problem through
+    include/misslap.h (create / solve / destroy + the matching guard) and must print the oracle's answer."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cc = shutil.which("gcc") or shutil.which("cc")
+    assert cc, "a C compiler is needed for the C-ABI client test"
+    exe = str(tmp_path / "cabi_client")
+    subprocess.check_call([cc, "-std=c11", "-Wall", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cabi_client.c"), "-L", os.path.join(root, "sslap_amd"),
+                           "-lmisslap", "-Wl,-rpath," + os.path.join(root, "sslap_amd"), "-o", exe])
+    for prob, maximize in (("max", 1), ("min", 0)):
+        loc, val = synth.gen_sparse(1200, 1500, 0.01, seed=21, integer_values=0)
+        inp, out = str(tmp_path / f"in_{prob}.bin"), str(tmp_path / f"out_{prob}.txt")
+        with open(inp, "wb") as f:
+            f.write(np.int64(loc.shape[0]).tobytes())
+            f.write(np.int32(maximize).tobytes())
+            f.write(np.ascontiguousarray(loc, dtype=np.int32).tobytes())
+            f.write(np.ascontiguousarray(val, dtype=np.float64).tobytes())
+        env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+        subprocess.check_call([exe, inp, out], env=env, timeout=120)
+        lines = open(out).read().split("\n")
+        its, nred, nass, obj, card, n, m = lines[0].split()
+        sol = np.array([int(x) for x in lines[1:1 + int(n)]], dtype=np.int32)
+        ref = orc.auction_solve(loc=loc, val=val.copy(), problem=prob, cardinality_check=False, max_iter=10**8)
+        assert np.array_equal(sol, ref["sol"])
+        assert (int(its), int(nred), int(nass)) == (ref["meta"]["its"], ref["meta"]["nreductions"],
+                                                    ref["meta"]["n_assigned"])
+        assert float(obj) == ref["extra"]["obj_f64"]
+        assert (int(card), int(n), int(m)) == (1200, 1200, int(loc[:, 1].max()) + 1)
