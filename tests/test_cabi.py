@@ -96,3 +96,15 @@ def test_frontend_validation_before_ffi():
     inf_loc = np.array([[0, 0], [1, 0]], dtype=np.int64)
     with pytest.raises(ValueError, match="Maximum matching possible only involves 1 out of 2 rows"):
         auction_solve(loc=inf_loc, val=np.ones(2), size=(2, 2))
+
+
+def test_header_is_plain_c_and_the_c_client_compiles(tmp_path):
+    """include/misslap.h must be consumable by a C compiler (no C++-isms, no torch / HIP types)."""
+    import shutil
+    import subprocess
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if not cc:
+        pytest.skip("no C compiler")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call([cc, "-std=c11", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(root, "include"),
+                           "-c", os.path.join(root, "tests", "cabi_client.c"), "-o", str(tmp_path / "client.o")])
