@@ -67,6 +67,7 @@ constexpr int kDefaultTailThreshold = 40;
 constexpr int kDefaultTailThresholdBig = 64;  // n_cols > kTailBigCols
 constexpr long long kTailBigCols = 500000;
 constexpr int kDefaultRoundsPerSync = 16;
+constexpr int kRoundsPerSyncLargeK = 2;  // batch length while K > kRoundSmallMax
 constexpr int kMaxGridBlocks = 2048;  // 256 CUs x 8 resident 256-thread blocks
 constexpr int kNumTiledShapes = 8;
 // (shape 0 is the default: three loader wavefronts measured 1-2 % faster than one inside a solve)
@@ -1047,7 +1048,12 @@ MISSLAP_API int misslap_solve(misslap_solver *h, int32_t *person_to_object_out, 
             if (c.K > h->thr) {
                 // rounds big enough for the tiled kernel are few (a handful per phase): enqueue them one at
                 // a time so that neither bid kernel is launched for a round the other one takes
-                const int batch = (h->tiled_ok && c.K >= h->tiled_min_K) ? 1 : h->rounds_per_sync;
+                // ... and while K is still above the small-round limit it falls fast (by a third or more per round):
+                // short batches there, so that the stale upper bound K_ub does not keep the four-launch path and a
+                // 2048-block bid grid alive for rounds that have long become small
+                const int batch = (h->tiled_ok && c.K >= h->tiled_min_K) ? 1
+                                  : c.K > kRoundSmallMax ? std::min(h->rounds_per_sync, kRoundsPerSyncLargeK)
+                                                         : h->rounds_per_sync;
                 for (int r = 0; r < batch; ++r) {
                     if ((rc = launch_bid(h))) return rc;
                     if ((rc = launch_tiebreak(h))) return rc;
