@@ -41,7 +41,7 @@ typedef struct misslap_options {
     int64_t max_iter;        /* rounds, auction_.pyx:204,:308 */
     int32_t input_on_device; /* loc / val are device pointers already resident in HBM */
     int32_t tail_threshold;  /* rounds with K <= this run in the persistent one-workgroup kernel;
-                                < 0 = library default; 0 = grid kernels only; max 1024 */
+                                < 0 = library default; 0 = grid kernels only; max 512 */
     int32_t force_f64_values;/* keep 12 B/edge (int32 col + fp64 val) even when values are fp32-exact */
     int32_t profile;         /* 1: record HIP events around the full-scan bid launches, every launch of the full-scan
                                 engine and every tail-kernel launch; 3: around every bid-kernel launch as well;
@@ -53,7 +53,9 @@ typedef struct misslap_options {
                                 [1]: launch shape of k_bid_tiled (tuning knob, see misslap.hip:kTiledShapes);
                                 [2]: full-scan engine: 0 / 1 k_bid_tiled (default), 2 k_scan2d + k_merge2d (experimental);
                                 [3]: multi-GPU shard threshold: 0 = default (the full-scan threshold, 0.3 N), > 0 = minimum K
-                                     of a sharded round, < 0 = shard every grid round */
+                                     of a sharded round, < 0 = shard every grid round;
+                                [4]: 1 = no candidate lines (every bid scans its whole row; A/B timing, parity tests);
+                                [5]: 1 = do not stream the candidate lines into the Infinity Cache before a tail launch */
 } misslap_options;
 
 /* Result block of misslap_finish: the reference's `meta` dict (auction_.pyx:264,:297-304)
@@ -99,7 +101,10 @@ typedef struct misslap_meta {
     double merge_ms;
     uint64_t shard_edges;        /* multi-GPU: edges scanned in sharded rounds (this rank's share); the rest of
                                     edges_scanned is replicated work, identical on every rank */
-    double reserved_d[11];       /* diagnostic cycle counters of the stamped tail build */
+    uint64_t cand_hits;          /* bids answered from the person's candidate line (exactly the same bid, no row scan) */
+    uint64_t cand_edges;         /* edges of those bidders' rows: part of edges_scanned (reference-equivalent count),
+                                    never read from memory */
+    double reserved_d[9];
 } misslap_meta;
 
 /* Snapshot of the round state (tests / multi-GPU driver). */

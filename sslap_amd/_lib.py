@@ -35,7 +35,8 @@ class Meta(C.Structure):
         ("tiled_launches", C.c_int64), ("tiled_ms", C.c_double), ("tiled_edges", C.c_uint64),
         ("tiled_active", C.c_int32), ("tiled_min_K", C.c_int32),
         ("merge_launches", C.c_int64), ("merge_ms", C.c_double),
-        ("shard_edges", C.c_uint64), ("reserved_d", C.c_double * 11),
+        ("shard_edges", C.c_uint64), ("cand_hits", C.c_uint64), ("cand_edges", C.c_uint64),
+        ("reserved_d", C.c_double * 9),
     ]
 
 

@@ -16,11 +16,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace misslap {
 
 constexpr int kWave = 64;
 constexpr int kPosNone = 0x7fffffff;
-constexpr int kTailMax = 1024;  // threads of the persistent tail workgroup = max K it handles
+constexpr int kTailMax = 512;  // threads of the persistent tail workgroup (8 wavefronts: 256 VGPRs each) = max K it handles
 
 // sticky device-side error bits (Ctl::err)
 constexpr int kErrNegativeBid = 1;   // a bid < 0 was formed (breaks the bits-as-integer ordering)
@@ -46,6 +48,8 @@ struct Ctl {
     long long tail_rounds;
     unsigned long long tail_edges;
     unsigned long long shard_edges;  // edges scanned in sharded rounds (multi-GPU: this rank's share only)
+    unsigned long long cand_hits;    // bids answered from the person's candidate line (no row scan)
+    unsigned long long cand_edges;   // edges of those rows (counted in `edges` like every bid, but never read)
     double obj;            // objective accumulator (auction_.pyx:491)
     double obj_abs;        // sum of |contribution| (any order: only used as a bound, see k_obj_sum)
     int obj_minexp;        // smallest binary exponent of a lowest set bit among the contributions
@@ -55,7 +59,18 @@ struct Ctl {
 
 // ---- edge storage ------------------------------------------------------------------------------
 struct EdgesF32 {  // 8 B / edge
+    static constexpr bool kCand = true;  // persons keep candidate lines (see below)
+    typedef int2 Raw;                    // one edge as loaded (a row requested ahead of its use stays in this form)
     const int2 *e;
+    __device__ __forceinline__ Raw load_raw_nt(int g) const {
+        typedef int v2i_t __attribute__((ext_vector_type(2)));
+        const v2i_t x = __builtin_nontemporal_load(reinterpret_cast<const v2i_t *>(e) + g);
+        return make_int2(x.x, x.y);
+    }
+    static __device__ __forceinline__ void decode(const Raw &x, int &col, double &val) {
+        col = x.x;
+        val = (double)__int_as_float(x.y);
+    }
     __device__ __forceinline__ void load(int g, int &col, double &val) const {
         const int2 x = e[g];
         col = x.x;
@@ -70,8 +85,23 @@ struct EdgesF32 {  // 8 B / edge
     }
 };
 struct EdgesF64 {  // 12 B / edge
+    static constexpr bool kCand = false;  // a line slot holds an fp32 value: no lines in this layout
+    struct Raw {
+        int c;
+        double v;
+    };
     const int *col;
     const double *val;
+    __device__ __forceinline__ Raw load_raw_nt(int g) const {
+        Raw x;
+        x.c = __builtin_nontemporal_load(col + g);
+        x.v = __builtin_nontemporal_load(val + g);
+        return x;
+    }
+    static __device__ __forceinline__ void decode(const Raw &x, int &c, double &v) {
+        c = x.c;
+        v = x.v;
+    }
     __device__ __forceinline__ void load(int g, int &c, double &v) const {
         c = col[g];
         v = val[g];
@@ -102,6 +132,7 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int off) {
 // Diagnostic stamp hook: drains the memory counters, then adds the s_memtime delta to slot k.
 struct NoStamp {
     __device__ __forceinline__ void operator()(int) const {}
+    __device__ __forceinline__ void light(int) const {}
 };
 struct CycleStamp {
     unsigned long long *acc;
@@ -109,6 +140,11 @@ struct CycleStamp {
     bool on;
     __device__ __forceinline__ void operator()(int k) const {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        if (on) acc[k] += t - *prev;
+        *prev = t;
+    }
+    __device__ __forceinline__ void light(int k) const {  // without draining the memory counters
         const unsigned long long t = __builtin_amdgcn_s_memtime();
         if (on) acc[k] += t - *prev;
         *prev = t;
@@ -146,10 +182,11 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
         v = o > v ? o : v;             \
     }
 __device__ __forceinline__ int wave_max_i32(int v) {
-    MISSLAP_WAVE_MAX_STEP(int, dpp_i32<kDppXor1>(v))
-    MISSLAP_WAVE_MAX_STEP(int, dpp_i32<kDppXor2>(v))
-    MISSLAP_WAVE_MAX_STEP(int, dpp_i32<kDppHalfMirror>(v))
-    MISSLAP_WAVE_MAX_STEP(int, dpp_i32<kDppMirror>(v))
+    // (mov_dpp form: folds into v_max_i32_dpp, one instruction per step)
+    MISSLAP_WAVE_MAX_STEP(int, __builtin_amdgcn_mov_dpp(v, kDppXor1, 0xF, 0xF, true))
+    MISSLAP_WAVE_MAX_STEP(int, __builtin_amdgcn_mov_dpp(v, kDppXor2, 0xF, 0xF, true))
+    MISSLAP_WAVE_MAX_STEP(int, __builtin_amdgcn_mov_dpp(v, kDppHalfMirror, 0xF, 0xF, true))
+    MISSLAP_WAVE_MAX_STEP(int, __builtin_amdgcn_mov_dpp(v, kDppMirror, 0xF, 0xF, true))
     MISSLAP_WAVE_MAX_STEP(int, (dpp_i32<kDppBcast15, 0xA>(v)))
     MISSLAP_WAVE_MAX_STEP(int, (dpp_i32<kDppBcast31, 0xC>(v)))
     return __builtin_amdgcn_readlane(v, 63);
@@ -394,6 +431,329 @@ __device__ __forceinline__ void wave_bid_rec(const E &ed, const PriceRec *rec, i
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
 __device__ __forceinline__ unsigned long long lanemask_lt() {
     return (1ull << lane_id()) - 1ull;
+}
+
+// ---- per-person candidate lines ---------------------------------------------------------------------------------
+// Prices only rise (a bid is >= price + eps, auction_.pyx:360, and prices survive the eps-phase restart, :283-292),
+// so the value  cost - p[j]  of every edge only falls.  When a wavefront has scanned a whole row it therefore knows a
+// bound that holds for the rest of the solve: pick a threshold t, remember the row's edges with value >= t ("the
+// candidates", at most kCandMax of them, in stored order) and tau = t; every OTHER edge of the row has value <= tau
+// now and for ever.  A later bid of the same person is answered from the candidates alone -- 256 bytes and <= 30
+// price look-ups instead of the whole row -- whenever that is provably the same bid:
+//     v1 > tau   the best candidate beats every edge outside the line strictly, so it is the row's best, and among
+//                equal candidates the later stored index wins exactly as in the full scan (:351)
+//     v2 >= tau  no edge outside the line exceeds the second-best candidate, so it is the row's second best (:357)
+// and bid = (cost1 - v2) + eps is formed with the same operations in the same order (:360).  Otherwise the row is
+// scanned in full and the line is rebuilt.  Nothing is approximate: a line only decides WHICH edges are looked at.
+//
+// Line of person i = 32 slots of 8 bytes at cand[32 * i]: slot 0 = tau (fp64; +inf = no line yet), slots 1..30 =
+// {int32 col, fp32 val} (col -1 = empty), slot 31 = {row length, 0} (the scanned-edge statistics count whole rows).
+// Only the 8 B/edge layout (fp32-exact values) keeps lines; rows longer than kCandRowMax are never cached.
+constexpr int kCandLanes = 32;
+constexpr int kCandMax = 30;
+constexpr int kCandMin = 24;            // the threshold search aims at [kCandMin, kCandMax] candidates
+constexpr int kCandRowMax = 4 * kWave;  // the full scan keeps four 64-edge chunks in registers
+
+// Lane permutation that the compiler can fold into the consuming VOP2 instruction (v_max_i32_dpp ...): every lane
+// of these controls reads a valid source lane, so the "old" operand of update_dpp is not needed.
+template <int CTRL>
+__device__ __forceinline__ int dppf_i32(int v) {
+    return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true);
+}
+template <int CTRL>
+__device__ __forceinline__ double dppf_f64(double v) {
+    return __hiloint2double(dppf_i32<CTRL>(__double2hiint(v)), dppf_i32<CTRL>(__double2loint(v)));
+}
+// maximum over each 32-lane half of the wavefront; valid in lanes 16..31 (half 0) and 48..63 (half 1)
+__device__ __forceinline__ double half_max_f64(double v) {
+    v = __builtin_fmax(v, dppf_f64<kDppXor1>(v));
+    v = __builtin_fmax(v, dppf_f64<kDppXor2>(v));
+    v = __builtin_fmax(v, dppf_f64<kDppHalfMirror>(v));
+    v = __builtin_fmax(v, dppf_f64<kDppMirror>(v));
+    v = __builtin_fmax(v, (dpp_f64<kDppBcast15, 0xA>(v)));
+    return v;
+}
+__device__ __forceinline__ int half_max_i32(int v) {
+    v = max(v, dppf_i32<kDppXor1>(v));
+    v = max(v, dppf_i32<kDppXor2>(v));
+    v = max(v, dppf_i32<kDppHalfMirror>(v));
+    v = max(v, dppf_i32<kDppMirror>(v));
+    v = max(v, (dpp_i32<kDppBcast15, 0xA>(v)));
+    return v;
+}
+
+// What one half-wavefront (32 lanes) knows after evaluating one person's line.  All members are wave-uniform.
+struct CandBid {
+    bool hit;
+    unsigned long long key;  // bid as key
+    int obj;                 // object bid on
+    int prev, pstart;        // its owner and the owner's row start (only when the price source carries them)
+    int len;                 // row length of the person
+};
+
+// price sources of the line evaluation / the full scan: the tail's 16-byte records or the plain price array
+struct RecSource {
+    const PriceRec *rec;
+    __device__ __forceinline__ PriceRec get(int col) const { return rec[col]; }
+};
+struct PriceSource {
+    const double *price;
+    __device__ __forceinline__ PriceRec get(int col) const {
+        PriceRec r;
+        r.price = price[col];
+        r.owner = -1;
+        r.ostart = 0;
+        return r;
+    }
+};
+
+// Evaluate the lines of up to two persons at once: lanes 0..31 hold the slots of person A, lanes 32..63 those of
+// person B (`slot` = the lane's 8-byte slot; act0 / act1 = the half holds a person at all, wave-uniform).  One gather
+// serves both.  out[0] / out[1] are wave-uniform.
+// Winner first: if exactly one lane of a half holds the largest HIGH WORD of the values, that lane holds the best
+// candidate (no tie is possible), so one 32-bit reduction decides the winner and only the second-best value still
+// needs a 64-bit pass.  As soon as the winners are known -- and everything else has been read out of `slot` --
+// `early(out)` is called with obj / prev / pstart of both halves filled in: the owners of the winning objects are the
+// next bidders if the bids win,
+// so the caller can request their lines (into `slot` itself) before the rest of the round is computed.
+template <class Src, class Early, class S = NoStamp>
+__device__ __forceinline__ void cand_eval2(int2 &slot, const bool act0, const bool act1, const Src &src,
+                                           const double eps, CandBid (&out)[2], int &err, Early &&early,
+                                           const S &stamp = S()) {
+    const int lane = lane_id(), l32 = lane & (kCandLanes - 1);
+    const double ninf = -__builtin_huge_val();
+    const bool active = lane < kCandLanes ? act0 : act1;
+    stamp(1);  // (diagnostic builds: drains the memory counters) the line has landed
+    const bool is_cand = active & (l32 >= 1) & (l32 <= kCandMax) & (slot.x >= 0);
+    const PriceRec r = src.get(is_cand ? slot.x : 0);
+    stamp(2);  // the records have landed
+    const double cost = (double)__int_as_float(slot.y);
+    double tau[2];
+    tau[0] = readlane_f64(__hiloint2double(slot.y, slot.x), 0);
+    tau[1] = readlane_f64(__hiloint2double(slot.y, slot.x), kCandLanes);
+    out[0].len = __builtin_amdgcn_readlane(slot.x, kCandLanes - 1);
+    out[1].len = __builtin_amdgcn_readlane(slot.x, 2 * kCandLanes - 1);
+    const double v = is_cand ? cost - r.price : ninf;  // vi = cost - p[j]   (:350)
+    const int hi = __double2hiint(v);
+    const int k = hi ^ ((hi >> 31) & 0x7fffffff);  // signed order of k == order of the doubles' high words
+    const int km = half_max_i32(k);
+    const int km0 = __builtin_amdgcn_readlane(km, 31), km1 = __builtin_amdgcn_readlane(km, 63);
+    const unsigned long long eq = __ballot(k == (lane < kCandLanes ? km0 : km1));
+    const unsigned eq0 = (unsigned)(eq & 0xffffffffull), eq1 = (unsigned)(eq >> 32);
+    double V[2], W[2];
+    int G[2];
+    if ((!act0 || __popc(eq0) == 1) && (!act1 || __popc(eq1) == 1)) {  // wave-uniform, the common case
+        G[0] = act0 ? __ffs((int)eq0) - 1 : -1;
+        G[1] = act1 ? __ffs((int)eq1) - 1 : -1;
+        V[0] = readlane_f64(v, max(G[0], 0));
+        V[1] = readlane_f64(v, kCandLanes + max(G[1], 0));
+        if (!act0) V[0] = ninf;
+        if (!act1) V[1] = ninf;
+    } else {
+        const double vm = half_max_f64(v);
+        V[0] = readlane_f64(vm, 31);
+        V[1] = readlane_f64(vm, 63);
+        const double Vv = lane < kCandLanes ? V[0] : V[1];
+        const int gm = half_max_i32((is_cand & (v == Vv)) ? l32 : -1);  // the LAST slot (= stored index) holding the best
+        G[0] = __builtin_amdgcn_readlane(gm, 31);
+        G[1] = __builtin_amdgcn_readlane(gm, 63);
+    }
+    double c1[2];
+#pragma unroll
+    for (int X = 0; X < 2; ++X) {
+        const int sl = kCandLanes * X + max(G[X], 0);
+        out[X].obj = __builtin_amdgcn_readlane(slot.x, sl);
+        out[X].prev = __builtin_amdgcn_readlane(r.owner, sl);
+        out[X].pstart = __builtin_amdgcn_readlane(r.ostart, sl);
+        c1[X] = (double)__int_as_float(__builtin_amdgcn_readlane(slot.y, sl));
+    }
+    early(out);  // `slot` is dead from here on
+    stamp.light(3);  // winners known, next lines requested
+    const int Gv = lane < kCandLanes ? G[0] : G[1];
+    const double wm = half_max_f64(l32 == Gv ? ninf : v);  // second best, counting multiplicity
+    W[0] = readlane_f64(wm, 31);
+    W[1] = readlane_f64(wm, 63);
+#pragma unroll
+    for (int X = 0; X < 2; ++X) {
+        out[X].hit = (G[X] >= 0) & (V[X] > tau[X]) & (W[X] >= tau[X]);
+        const double bid = (c1[X] - W[X]) + eps;  // bbest = costbest - wi + eps   (:360)
+        if (out[X].hit && !(bid >= 0.0)) err |= kErrNegativeBid;
+        out[X].key = bid_to_key(bid);
+    }
+}
+struct NoEarly {
+    __device__ __forceinline__ void operator()(const CandBid (&)[2]) const {}
+};
+
+// What a full scan leaves behind for the (re)build of the person's line: column, cost and value of the lane's
+// element in each of the row's four 64-edge chunks, the row's best and second-best value.  Kept in registers so that
+// the caller can publish its bid / request the next data first and build the line while it waits.
+struct CandBuildArgs {
+    int c[4];
+    double a[4], v[4];
+    double V, W;
+    int len;
+    bool want;  // the row fits the four chunks and the layout keeps lines
+};
+
+// (Re)build the line of `person` from a full scan of its row (len <= kCandRowMax).  The threshold t is searched
+// below W (count(v >= W) >= 2): the first probe is W - hint, where `hint` is the distance the wavefront's previous
+// build ended with (rows of one problem look alike, so one or two probes usually suffice); the distance then
+// doubles / halves until the count has passed the window [kCandMin, kCandMax], followed by a short bisection.
+// Every probe is four compares + popcounts on the wave's ballots.  Any t <= W with a count in [2, kCandMax]
+// gives a valid line: the search only decides how full the line gets.
+__device__ __forceinline__ void cand_build(int2 *cand, int person, const CandBuildArgs &ba, double eps,
+                                           double &hint) {
+    const int lane = lane_id();
+    const double ninf = -__builtin_huge_val();
+    const int len = ba.len;
+    const double W = ba.W;
+    unsigned long long okm[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int rem = len - kWave * u;
+        okm[u] = rem >= kWave ? ~0ull : (rem <= 0 ? 0ull : ((1ull << rem) - 1ull));
+    }
+    auto count = [&](double t) {
+        int n = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) n += __popcll(__ballot(ba.v[u] >= t) & okm[u]);
+        return n;
+    };
+    double t = ninf;
+    int n = len;
+    if (len > kCandMax) {
+        n = count(W);
+        if (n > kCandMax) return;  // more than kCandMax ties at the top: the old line (if any) stays valid
+        t = W;
+        // distances: d_ok = largest known with count <= kCandMax, d_bad = smallest known with count > kCandMax
+        double d_ok = 0.0, d_bad = __builtin_huge_val();
+        double d = hint > 0.0 ? hint : 4.0 * __builtin_fmax(ba.V - W, eps);
+        for (int k = 0; k < 40 && n < kCandMin; ++k) {
+            const double t2 = W - d;
+            const int n2 = count(t2);
+            if (n2 <= kCandMax) {
+                d_ok = d;
+                t = t2;
+                n = n2;
+                d = d_bad == __builtin_huge_val() ? 2.0 * d : 0.5 * (d_ok + d_bad);
+            } else {
+                d_bad = d;
+                d = 0.5 * (d_ok + d_bad);
+            }
+            if (!(d > d_ok) || !(d < d_bad)) break;  // the interval has collapsed (or d overflowed)
+        }
+        hint = d_ok > 0.0 ? d_ok : hint;
+    }
+    int2 *line = cand + (size_t)person * kCandLanes;
+    int base = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {  // candidates in stored order: rank = elements before it that qualify
+        const unsigned long long m = __ballot(ba.v[u] >= t) & okm[u];
+        if ((m >> lane) & 1ull)
+            line[1 + base + __popcll(m & lanemask_lt())] = make_int2(ba.c[u], __float_as_int((float)ba.a[u]));
+        base += __popcll(m);
+    }
+    if (lane < kCandLanes && (lane == 0 || lane == kCandLanes - 1 || lane > n)) {
+        int2 x = make_int2(-1, 0);  // empty slot
+        if (lane == 0) x = make_int2(__double2loint(t), __double2hiint(t));
+        if (lane == kCandLanes - 1) x = make_int2(len, 0);
+        line[lane] = x;
+    }
+}
+
+// The bid of one person by a FULL scan of its row [s, e) by one wavefront (auction_.pyx:339-365), as wave_bid /
+// wave_bid_rec; `ba` receives what the (re)build of the person's candidate line needs.  `e` may still be in flight
+// when the function is entered: the first four chunks are requested before it is used (the edge arrays are padded).
+// kPre: the first four chunks were requested earlier and arrive in `pre`.  kNT: the row is read once and must not
+// evict the price records from L2 (tail kernel).
+template <class E, class Src, bool kNT, bool kPre>
+__device__ __forceinline__ void wave_bid_full(const E &ed, const Src &src, int s, int e_in,
+                                              const typename E::Raw (&pre)[4], double eps, CandBid &out,
+                                              CandBuildArgs &ba, int &err) {
+    const int lane = lane_id();
+    const double ninf = -__builtin_huge_val();
+    Top2 x;
+    x.v = ninf;
+    x.w = ninf;
+    x.g = -1;
+    int c1 = 0, o1 = -1, os1 = 0;
+    double a1 = 0.0;
+    int c[4];
+    double a[4];
+    auto load = [&](int g, int &cc, double &aa) {
+        if (kNT) ed.load_nt(g, cc, aa);
+        else ed.load(g, cc, aa);
+    };
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        if (kPre) E::decode(pre[u], c[u], a[u]);
+        else load(s + u * kWave + lane, c[u], a[u]);  // speculative: e may not have landed
+    }
+    const int e = __builtin_amdgcn_readfirstlane(e_in);  // (the same value in every lane)
+    auto chunk = [&](int base, auto first_) {
+        constexpr bool kFirst = decltype(first_)::value;
+        PriceRec r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool ok = base + u * kWave + lane < e;
+            if (!ok) c[u] = -1;
+            r[u] = src.get(ok ? c[u] : 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {  // branch-free: a masked-off element has value -inf and changes nothing
+            const bool ok = c[u] >= 0;
+            const double v = ok ? a[u] - r[u].price : ninf;     // vi = cost - p[j]   (:350)
+            const bool ge = ok & (v >= x.v);                    // :351
+            x.w = __builtin_fmax(x.w, __builtin_fmin(v, x.v));  // :353 / :357-358
+            x.v = __builtin_fmax(x.v, v);
+            x.g = ge ? base + u * kWave + lane : x.g;
+            c1 = ge ? c[u] : c1;
+            a1 = ge ? a[u] : a1;
+            o1 = ge ? r[u].owner : o1;
+            os1 = ge ? r[u].ostart : os1;
+            if (kFirst && E::kCand) {
+                ba.c[u] = c[u];
+                ba.a[u] = a[u];
+                ba.v[u] = v;
+            }
+        }
+    };
+    chunk(s, std::true_type{});
+    for (int base = s + 4 * kWave; base < e; base += 4 * kWave) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) load(min(base + u * kWave + lane, e - 1), c[u], a[u]);
+        chunk(base, std::false_type{});
+    }
+    // winner first (see wave_bid_rec)
+    const int hi = __double2hiint(x.v);
+    const int k = hi ^ ((hi >> 31) & 0x7fffffff);
+    const int kmax = wave_max_i32(k);
+    const unsigned long long cnd = __ballot(k == kmax);
+    int sl;
+    double W;
+    if (__popcll(cnd) == 1) {  // wave-uniform
+        sl = __ffsll((long long)cnd) - 1;
+        W = wave_max_f64(lane == sl ? x.w : x.v);
+    } else {
+        const int g_mine = x.g;
+        const Top2 t2 = top2_wave_reduce(x);
+        sl = __ffsll((long long)__ballot(g_mine == t2.g)) - 1;
+        W = t2.w;
+    }
+    out.hit = false;
+    out.obj = __builtin_amdgcn_readlane(c1, sl);
+    out.prev = __builtin_amdgcn_readlane(o1, sl);
+    out.pstart = __builtin_amdgcn_readlane(os1, sl);
+    out.len = e - s;
+    const double cost = readlane_f64(a1, sl);
+    const double bid = (cost - W) + eps;  // bbest = costbest - wi + eps   (:360)
+    if (!(bid >= 0.0)) err |= kErrNegativeBid;
+    out.key = bid_to_key(bid);
+    ba.want = E::kCand && e - s <= kCandRowMax;
+    ba.len = e - s;
+    ba.W = W;
+    ba.V = readlane_f64(x.v, sl);
 }
 
 }  // namespace misslap

@@ -89,13 +89,19 @@ __global__ __launch_bounds__(256) void k_build_edges_f64(const int *loc, const d
 }
 
 __global__ __launch_bounds__(256) void k_init_state(Ctl *ctl, double *price, PriceRec *rec, int *p2o, int *o2p, int *U,
-                                                    unsigned long long *best_key, int *best_pos, int n_rows,
-                                                    int n_cols, long long max_iter) {
+                                                    unsigned long long *best_key, int *best_pos, int2 *cand,
+                                                    int n_rows, int n_cols, long long max_iter) {
     const int stride = gridDim.x * blockDim.x;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     for (int i = t; i < n_rows; i += stride) {
         p2o[i] = -1;  // :231
         U[i] = i;     // :260
+    }
+    if (cand) {  // candidate lines: tau = +inf (no line yet), every slot empty
+        const double inf = __builtin_huge_val();
+        for (long long k = t; k < (long long)n_rows * kCandLanes; k += stride)
+            cand[k] = (k & (kCandLanes - 1)) == 0 ? make_int2(__double2loint(inf), __double2hiint(inf))
+                                                  : make_int2(-1, 0);
     }
     for (int j = t; j < n_cols; j += stride) {
         price[j] = 0.0;        // :220
@@ -121,6 +127,8 @@ __global__ __launch_bounds__(256) void k_init_state(Ctl *ctl, double *price, Pri
         ctl->dup_rows = 0;
         ctl->grid_rounds = 0;
         ctl->tail_rounds = 0;
+        ctl->cand_hits = 0;
+        ctl->cand_edges = 0;
         ctl->tail_edges = 0;
         ctl->shard_edges = 0;
         ctl->obj_abs = 0.0;

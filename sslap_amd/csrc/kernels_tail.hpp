@@ -2,15 +2,27 @@
 //
 // At the BASELINE sizes > 98 % of all rounds have <= 64 bidders and
 // every round depends on the prices of the previous one, so the tail is a latency chain, not a
-// bandwidth problem.  One 1024-thread workgroup (16 wavefronts, one CU) loops over rounds on the
-// device: the unassigned list lives in LDS, each wavefront bids for one person at a time
-// (auction_.pyx:339-365), conflicts are resolved in LDS (:375-385), winners are applied (:388-427)
-// and the list is compacted (push_all_left, :137-162) without leaving the kernel.  K never grows
-// inside an eps-phase (every winner evicts at most one owner), so once K <= threshold the whole
-// rest of the phase runs here.  The kernel exits when K == 0 or nits == max_iter.
+// bandwidth problem.  One 512-thread workgroup (8 wavefronts, one CU) loops over rounds on the
+// device: the unassigned list lives in LDS, bids are formed per person (auction_.pyx:339-365),
+// conflicts are resolved in LDS (:375-385), winners are applied (:388-427) and the list is
+// compacted (push_all_left, :137-162) without leaving the kernel.  K never grows inside an
+// eps-phase (every winner evicts at most one owner), so once K <= threshold the whole rest of the
+// phase runs here.  The kernel exits when K == 0 or nits == max_iter.
 //
-// Visibility: prices / o2p / p2o are written and re-read by this one workgroup only (same CU, same
-// vector L1, __syncthreads() between phases); the CSR is read-only.  No other workgroup runs.
+// A bid is first tried on the person's CANDIDATE LINE (device_common.hpp: 256 bytes, <= 30 price records, an
+// exactness test) and only on a miss by a full scan of the row, which also rebuilds the line.  With the lines
+// about 90 % of the tail's bids need one 256-byte read and one 30-wide record gather instead of the whole row and
+// ~200 gathers; the dependent chain of a round is  line -> records -> 32-lane reduction -> next line.
+//
+// Three modes by K (K only falls, so a phase moves block -> team -> solo):
+//   solo  (K <= 2, two thirds of all rounds): wavefront 0 alone, no barrier, no LDS; the two persons' lines sit
+//         in the two 32-lane halves and are evaluated by one gather;
+//   team  (3 <= K <= 16): one wavefront per list slot, the line of the slot's next occupant requested as soon as the
+//         winning candidate is known; two LDS-only barriers per round, wavefront 0 resolves;
+//   block (K > 16): several slots per wavefront, __syncthreads, LDS hash table above 64 bidders.
+//
+// Visibility: records / lines are written and re-read by this one workgroup only (same CU, same
+// vector L1, barriers between phases); the CSR is read-only.  No other workgroup runs.
 #pragma once
 #include "device_common.hpp"
 
@@ -24,6 +36,7 @@ struct TailArgs {
     int *p2o;
     int *o2p;
     int *U;
+    int2 *cand;     // candidate lines (nullptr in the 12 B/edge layout)
     int thr;
     float eps;
 };
@@ -38,8 +51,8 @@ __device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v,
 
 // assignment of one winner (auction_.pyx:396-418); returns the new content of its U slot.  Inside the tail
 // kernel the price record is the ONLY copy that is kept current: one 16-byte store per winner instead of
-// five scattered ones, and price[] / o2p[] / p2o[] lines stay out of the CU's L2 working set.  k_sync_price /
-// k_sync_p2o rebuild the three plain arrays from the records when the kernel has finished.
+// five scattered ones, and price[] / o2p[] / p2o[] lines stay out of the CU's L2 working set.  k_sync_from_rec
+// rebuilds the three plain arrays from the records when the kernel has finished.
 __device__ __forceinline__ int apply_winner(const TailArgs &a, int person, int pstart, int obj, int prev,
                                             unsigned long long key) {
     PriceRec r;
@@ -64,156 +77,197 @@ __global__ __launch_bounds__(256) void k_sync_from_rec(const PriceRec *rec, doub
     }
 }
 
-// STAMP = diagnostic build: wavefront 0 accumulates s_memtime deltas of the four segments of a round
-// (bid | barrier | resolve+assign+compact | barrier) into Ctl::dbg; never used for reported timings.
-// ---- pair mode: K == 2 (30 % of the small rounds at C3: two eviction chains running side by side) -------------
-// One wavefront runs both bidders of a round: their rows are requested together, their price records are gathered
-// together (eight gathers in flight instead of four), and each next occupant's row is requested as soon as its
-// winning lane is known -- so the round costs one row latency and one gather latency for both bids, with no
-// barrier and no LDS traffic.  The reference's round is reproduced operation by operation: both bids use the
-// prices of the previous round (records are stored after both bids are formed), RESOLVE keeps the earlier list
-// position on equal bids (:379), the evicted owner inherits the winner's slot (:409), push_all_left moves slot 1
-// into an emptied slot 0 (:137-162).  Returns with K < 2 (or nits == max_iter) and the list written back.
+// Before a tail launch: stream the candidate lines through the memory hierarchy once (51 MB at C3, a few
+// microseconds at HBM rate), so that the tail's dependent line reads are served by the 256 MiB Infinity Cache
+// (~550 cycles) instead of HBM (~900+).  The lines stay resident through the launch: the tail itself moves little
+// data.  Pure prefetch: nothing is computed; `sink` is never written (the test cannot succeed for real lines).
+__global__ __launch_bounds__(256) void k_warm_lines(const int4 *lines, long long n16, int *sink) {
+    int acc = 0;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < n16; k += stride) {
+        const int4 x = lines[k];
+        acc |= x.x & x.y & x.z & x.w;
+    }
+    if (acc == 0x7fffffff) *sink = acc;
+}
+
+// per-wavefront statistics, flushed once when the kernel ends
+struct TailStats {
+    unsigned long long edges, bids, hits, hit_edges, builds;
+    int err;
+    double hint;  // cand_build's search distance, carried from one build of this wavefront to the next
+};
+
+// zero in every lane, but not wave-uniform to the compiler: an index built with it goes through the VECTOR memory
+// path.  A wave-uniform row_ptr[person + 1] would be a scalar load, which shares lgkmcnt with LDS and makes every
+// LDS-only barrier wait an L2 / HBM latency for a value nobody needs yet.
+__device__ __forceinline__ int lane_zero() {
+    return (int)__builtin_amdgcn_mbcnt_hi(0u, __builtin_amdgcn_mbcnt_lo(0u, 0u));
+}
+
+// What a wavefront requests for its (up to) two persons ahead of their bids: the candidate lines -- person A's in
+// lanes 0..31, person B's in lanes 32..63, they answer ~90 % of the bids -- and, speculatively, the first 256 edges of
+// both rows plus the row ends, so that a miss costs one memory latency, not two.  The lines are requested FIRST: a
+// wavefront's loads return in issue order, so a line can be used while the rows are still on their way, and a hit
+// never waits for a row at all.
+// the lane's slot of a line that never hits: tau = +inf in slot 0, every other slot empty
+__device__ __forceinline__ int2 cand_no_line() {
+    return (lane_id() & (kCandLanes - 1)) == 0 ? make_int2(0, 0x7ff00000) : make_int2(-1, 0);
+}
 template <class E>
-__device__ __forceinline__ void tail_pair_mode(const TailArgs &a, const E &ed, int *sU, int *sStart, int &K,
-                                               long long &nits, const long long max_iter, const double eps,
-                                               unsigned long long &edges, unsigned long long &bids, int &err) {
-    const int lane = threadIdx.x & (kWave - 1);
-    const double ninf = -__builtin_huge_val();
-    int pi[2] = {sU[0], sU[1]}, ps[2] = {sStart[0], sStart[1]};
-    int c[2][4], e[2];
-    double av[2][4];
-    auto request = [&](int X, int person, int start) {  // first four 64-edge chunks of a row + its end
+struct TwoFetch {
+    int2 slot;                  // the lane's slot of its half's line
+    typename E::Raw row[2][4];  // 12 B/edge layout (no lines): first four 64-edge chunks of each row, requested ahead
+    int ev[2];                  // ... and the row ends (vector registers, the same value in every lane)
+};
+template <class E>
+__device__ __forceinline__ void fetch_row(const TailArgs &a, const E &ed, int person, int start,
+                                          typename E::Raw (&row)[4], int &e) {
+    const int lane = lane_id();
 #pragma unroll
-        for (int u = 0; u < 4; ++u) ed.load_nt(start + u * kWave + lane, c[X][u], av[X][u]);
-        e[X] = a.row_ptr[person + 1];
-    };
-    request(0, pi[0], ps[0]);
-    request(1, pi[1], ps[1]);
-    for (;;) {
-        Top2 x[2];
-        int c1[2], o1[2], os1[2];
-        double a1[2];
-        PriceRec r[2][4];
-        int cc[2][4];
+    for (int u = 0; u < 4; ++u) row[u] = ed.load_raw_nt(start + u * kWave + lane);  // the edge arrays are padded
+    e = a.row_ptr[max(person, 0) + 1 + lane_zero()];
+}
+// Request what the next bids of persons p0 / p1 (-1 = none: a valid, unused address is read) need first: with
+// candidate lines the two lines (p0's in lanes 0..31, p1's in lanes 32..63); without (12 B/edge layout) the rows.
+// A wavefront's loads return in issue order, so nothing is requested speculatively BEHIND which a later,
+// more urgent load would have to wait: rows are only read when a line has not decided.
+template <class E>
+__device__ __forceinline__ void request_two(const TailArgs &a, const E &ed, int p0, int s0, int p1, int s1,
+                                            TwoFetch<E> &tf) {
+    if (E::kCand) {
+        const int pme = lane_id() < kCandLanes ? p0 : p1;
+        tf.slot = a.cand != nullptr ? a.cand[(size_t)max(pme, 0) * kCandLanes + (lane_id() & (kCandLanes - 1))]
+                                    : cand_no_line();
+    } else {
+        fetch_row<E>(a, ed, p0, s0, tf.row[0], tf.ev[0]);
+        fetch_row<E>(a, ed, p1, s1, tf.row[1], tf.ev[1]);
+    }
+}
+
+__device__ __forceinline__ void tail_build(const TailArgs &a, int person, const CandBuildArgs &ba, double eps,
+                                           TailStats &st) {
+    cand_build(a.cand, person, ba, eps, st.hint);
+    st.builds += 1;
+}
+
+// The bids of the wavefront's two persons (auction_.pyx:339-365): both lines by one gather, then a full scan for
+// every person whose line did not decide.  `early(b)` is cand_eval2's hook (the winners' owners are known).  The
+// rebuild of the (last) scanned person's line is left to the caller (bd / bd_person), who first publishes the bids
+// and requests the next data.
+template <class E, class Early, class S = NoStamp>
+__device__ __forceinline__ void bid_two(const TailArgs &a, const E &ed, const int (&pi)[2], const int (&ps)[2],
+                                        TwoFetch<E> &tf, double eps, CandBid (&b)[2], CandBuildArgs &bd,
+                                        int &bd_person, TailStats &st, Early &&early, const S &stamp = S()) {
+    const RecSource src{a.rec};
+    b[0].hit = b[1].hit = false;
+    if (E::kCand) cand_eval2(tf.slot, pi[0] >= 0, pi[1] >= 0, src, eps, b, st.err, early, stamp);
+    stamp.light(4);  // lines evaluated
+    bd_person = -1;
 #pragma unroll
-        for (int X = 0; X < 2; ++X) {
-            x[X].v = ninf;
-            x[X].w = ninf;
-            x[X].g = -1;
-            c1[X] = 0;
-            o1[X] = -1;
-            os1[X] = 0;
-            a1[X] = 0.0;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {  // all eight gathers are issued before any of them is used
-                const bool ok = ps[X] + u * kWave + lane < e[X];
-                cc[X][u] = ok ? c[X][u] : -1;
-                r[X][u] = a.rec[ok ? c[X][u] : 0];
-            }
-        }
-#pragma unroll
-        for (int X = 0; X < 2; ++X) {
-            auto update = [&](int cu, double au, const PriceRec &ru, int g) {
-                const bool ok = cu >= 0;
-                const double v = ok ? au - ru.price : ninf;        // vi = cost - p[j]   (:350)
-                const bool ge = ok & (v >= x[X].v);                // :351
-                x[X].w = __builtin_fmax(x[X].w, __builtin_fmin(v, x[X].v));  // :353 / :357-358
-                x[X].v = __builtin_fmax(x[X].v, v);
-                x[X].g = ge ? g : x[X].g;
-                c1[X] = ge ? cu : c1[X];
-                a1[X] = ge ? au : a1[X];
-                o1[X] = ge ? ru.owner : o1[X];
-                os1[X] = ge ? ru.ostart : os1[X];
-            };
-#pragma unroll
-            for (int u = 0; u < 4; ++u) update(cc[X][u], av[X][u], r[X][u], ps[X] + u * kWave + lane);
-            // rows longer than 256 edges (wave-uniform, rare at the BASELINE densities): plain loads
-            for (int base = ps[X] + 4 * kWave; base < e[X]; base += kWave) {
-                const int g = base + lane;
-                int cu;
-                double au;
-                ed.load_nt(min(g, e[X] - 1), cu, au);
-                const PriceRec ru = a.rec[cu];
-                update(g < e[X] ? cu : -1, au, ru, g);
-            }
-        }
-        // winners first (see wave_bid_rec), then the next occupants' rows, then the second-best values
-        int src[2], prev[2], pst[2];
-        double W[2];
-        bool fast[2];
-        Top2 t2[2];
-#pragma unroll
-        for (int X = 0; X < 2; ++X) {
-            const int hi = __double2hiint(x[X].v);
-            const int k = hi ^ ((hi >> 31) & 0x7fffffff);
-            const int kmax = wave_max_i32(k);
-            const unsigned long long cand = __ballot(k == kmax);
-            fast[X] = __popcll(cand) == 1;  // wave-uniform
-            if (fast[X]) {
-                src[X] = __ffsll((long long)cand) - 1;
+    for (int X = 0; X < 2; ++X) {
+        if (pi[X] < 0) continue;  // wave-uniform
+        if (!b[X].hit) {
+            if (bd_person >= 0) tail_build(a, bd_person, bd, eps, st);  // two misses in one round: rare
+            if (E::kCand) {
+                const typename E::Raw none[4] = {};
+                const int e = a.row_ptr[pi[X] + 1 + lane_zero()];
+                wave_bid_full<E, RecSource, true, false>(ed, src, ps[X], e, none, eps, b[X], bd, st.err);
             } else {
-                const int g_mine = x[X].g;
-                t2[X] = top2_wave_reduce(x[X]);
-                src[X] = __ffsll((long long)__ballot(g_mine == t2[X].g)) - 1;
+                wave_bid_full<E, RecSource, true, true>(ed, src, ps[X], tf.ev[X], tf.row[X], eps, b[X], bd, st.err);
             }
-            prev[X] = __builtin_amdgcn_readlane(o1[X], src[X]);
-            pst[X] = __builtin_amdgcn_readlane(os1[X], src[X]);
+            bd.want = bd.want && a.cand != nullptr;
+            bd_person = bd.want ? pi[X] : -1;
+        } else {
+            st.hits += 1;
+            st.hit_edges += (unsigned long long)b[X].len;
         }
-        const int len0 = e[0] - ps[0], len1 = e[1] - ps[1];
-        const int col0 = __builtin_amdgcn_readlane(c1[0], src[0]), col1 = __builtin_amdgcn_readlane(c1[1], src[1]);
-        // a bidder wins unless both bid on one object; which of the two wins is only known with the bids, so the
-        // rows are requested for the common case (both win) and re-requested for a loser below
-        request(0, prev[0], pst[0]);
-        request(1, prev[1], pst[1]);
-        unsigned long long key[2];
-#pragma unroll
-        for (int X = 0; X < 2; ++X) {
-            W[X] = fast[X] ? wave_max_f64(lane == src[X] ? x[X].w : x[X].v) : t2[X].w;
-            const double cost = readlane_f64(a1[X], src[X]);
-            const double bid = (cost - W[X]) + eps;  // bbest = costbest - wi + eps   (:360)
-            if (!(bid >= 0.0)) err |= kErrNegativeBid;
-            key[X] = bid_to_key(bid);
-        }
-        edges += (unsigned long long)(len0 + len1);
-        bids += 2;
+        st.edges += (unsigned long long)b[X].len;
+        st.bids += 1;
+    }
+}
+
+// ---- solo mode: K <= 2 ---------------------------------------------------------------------------------------------
+// Wavefront 0 runs the rounds alone until the phase ends (K never grows), without barriers and without LDS.  The
+// reference's round is reproduced operation by operation: both bids use the prices of the previous round (records
+// are stored after both bids are formed), RESOLVE keeps the earlier list position on equal bids (:379), the evicted
+// owner inherits the winner's slot (:409), push_all_left moves slot 1 into an emptied slot 0 (:137-162).  The next
+// bidder of a slot is the owner its bidder evicts, and that owner comes with the winning price record -- no o2p /
+// row_ptr look-ups between rounds: its line is requested as soon as the winning candidate is known, before the
+// second-best reduction, the bid, the resolve step and the record stores of the current round.  A line that had to
+// be rebuilt is rebuilt after the next round's data has been requested.
+template <class E>
+__device__ __forceinline__ void tail_solo_mode(const TailArgs &a, const E &ed, int *sU, int *sStart, int &K,
+                                               long long &nits, const long long max_iter, const double eps,
+                                               TailStats &st) {
+    const int lane = lane_id();
+    int pi[2], ps[2];
+    pi[0] = __builtin_amdgcn_readfirstlane(sU[0]);
+    ps[0] = __builtin_amdgcn_readfirstlane(sStart[0]);
+    pi[1] = K > 1 ? __builtin_amdgcn_readfirstlane(sU[1]) : -1;
+    ps[1] = K > 1 ? __builtin_amdgcn_readfirstlane(sStart[1]) : 0;
+    TwoFetch<E> tf;
+    tf.slot = cand_no_line();
+    request_two(a, ed, pi[0], ps[0], pi[1], ps[1], tf);
+#ifdef MISSLAP_TAIL_STAMP
+    // diagnostic build: cycles of wavefront 0 per segment of a solo round -> Ctl::dbg[6..11] (+ dbg[15] = rounds):
+    // [6] wait for the line, [7] record gather, [8] winner known + next line requested, [9] rest of the line
+    // evaluation, [10] full scans of missed persons, [11] resolve / stores / re-request / line rebuild
+    unsigned long long sacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sprev = __builtin_amdgcn_s_memtime();
+    const CycleStamp stamp{sacc, &sprev, true};
+#else
+    const NoStamp stamp;
+#endif
+    for (;;) {
+        CandBid b[2];
+        CandBuildArgs bd;
+        int bd_person;
+        int sp[2] = {-2, -2};  // persons whose lines were requested early (-2: nothing requested)
+        bid_two(a, ed, pi, ps, tf, eps, b, bd, bd_person, st, [&](const CandBid(&w)[2]) {
+            sp[0] = pi[0] >= 0 ? w[0].prev : -1;
+            sp[1] = pi[1] >= 0 ? w[1].prev : -1;
+            request_two(a, ed, sp[0], 0, sp[1], 0, tf);  // (kCand only: the row starts are not needed)
+        }, stamp);
+        stamp.light(5);  // full scans of missed persons done
         nits += 1;
         // RESOLVE (:375-385): strict ">" -- the earlier list position keeps an object on equal bids
-        bool win0 = true, win1 = true;
-        if (col0 == col1) {
-            if (key[1] > key[0]) win0 = false;
+        bool win0 = true, win1 = pi[1] >= 0;
+        if (win1 && b[0].obj == b[1].obj) {
+            if (b[1].key > b[0].key) win0 = false;
             else win1 = false;
         }
         // ASSIGN (:396-418): a winner's slot goes to the evicted owner (or becomes a hole), a loser stays
         if (lane == 0) {
-            if (win0) apply_winner(a, pi[0], ps[0], col0, prev[0], key[0]);
-            if (win1) apply_winner(a, pi[1], ps[1], col1, prev[1], key[1]);
+            if (win0) apply_winner(a, pi[0], ps[0], b[0].obj, b[0].prev, b[0].key);
+            if (win1) apply_winner(a, pi[1], ps[1], b[1].obj, b[1].prev, b[1].key);
         }
-        if (!win0) request(0, pi[0], ps[0]);  // (wave-uniform, rare) the loser bids again from its own row
-        else {
-            pi[0] = prev[0];
-            ps[0] = pst[0];
+        if (win0) {
+            pi[0] = b[0].prev;
+            ps[0] = b[0].pstart;
         }
-        if (!win1) request(1, pi[1], ps[1]);
-        else {
-            pi[1] = prev[1];
-            ps[1] = pst[1];
+        if (win1) {
+            pi[1] = b[1].prev;
+            ps[1] = b[1].pstart;
         }
         // push_all_left (:137-162) on two slots
         if (pi[0] == -1 && pi[1] != -1) {
             pi[0] = pi[1];
             ps[0] = ps[1];
-            e[0] = e[1];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                c[0][u] = c[1][u];
-                av[0][u] = av[1][u];
-            }
             pi[1] = -1;
         }
         K = (pi[0] != -1) + (pi[1] != -1);
-        if (K < 2 || nits >= max_iter) break;
+        const bool done = K == 0 || nits >= max_iter;
+        // the early request assumed "both bidders win, nobody moves"; otherwise (a scanned row, a lost bid, the
+        // end of a chain) request again
+        if (!done && (sp[0] != pi[0] || sp[1] != pi[1])) request_two(a, ed, pi[0], ps[0], pi[1], ps[1], tf);
+        if (bd_person >= 0) tail_build(a, bd_person, bd, eps, st);
+        stamp.light(6);
+        if (done) break;
     }
+#ifdef MISSLAP_TAIL_STAMP
+    if (lane == 0)
+        for (int k = 1; k <= 6; ++k) a.ctl->dbg[5 + k] += sacc[k];
+#endif
     if (lane == 0) {
         sU[0] = pi[0];
         sU[1] = pi[1];
@@ -222,120 +276,73 @@ __device__ __forceinline__ void tail_pair_mode(const TailArgs &a, const E &ed, i
     }
 }
 
-// ---- team mode: 3 <= K <= 16 ------------------------------------------------------------------------------------
-// Chain mode on every wavefront: wavefront w serves list slot w, keeps that slot's row in registers and requests the
-// row of its next occupant (the owner its bidder evicts inherits the slot, :409 -- true for 99.9 % of the bids) as
-// soon as the winning lane is known.  The bids of a round go to LDS; wavefront 0 runs RESOLVE / ASSIGN /
-// push_all_left on lanes = slots and publishes the new list; two barriers per round, both ordering LDS traffic
-// ONLY (s_waitcnt lgkmcnt(0); s_barrier), so that the row requests stay in flight across the resolve phase.
-// Two traps: (1) a wave-uniform row_ptr[person + 1] would be a SCALAR load, which shares lgkmcnt with LDS and would
-// make every barrier wait an L2 / HBM latency -- the row end is loaded through the vector path; (2) the winners'
-// records are stored by wavefront 0 before the second barrier and gathered by everybody after it (one CU, one
-// in-order vector L1), without waiting for the stores' acknowledgement.
+// ---- team mode: 3 <= K <= 16 -----------------------------------------------------------------------------------
+// Wavefront w serves list slots 2w and 2w + 1 (the two halves of its lines).  ONE barrier per round: the bids go to
+// LDS (double-buffered by round parity), and behind the barrier EVERY wavefront runs RESOLVE / ASSIGN / push_all_left
+// for the whole list redundantly on lanes = slots (the list lives in registers, replicated), so nobody waits for a
+// resolver and no second barrier publishes its result.  Every serving wavefront stores the records of ALL winners
+// itself (identical values from every wavefront): its own next gathers then follow its own stores in program order,
+// which is the only ordering a wavefront's in-order memory path gives for free -- and the barrier guarantees that
+// every wavefront has finished the gathers of the round before anybody stores.  The line of a slot's next occupant
+// (the owner its bidder evicts inherits the slot, :409) is requested as soon as the winning candidate is known.
 constexpr int kTeamMax = 16;
 __device__ __forceinline__ void tail_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <class E>
-__device__ __forceinline__ void tail_team_mode(const TailArgs &a, const E &ed, int *sU, int *sStart,
-                                               unsigned long long *sKey, int *sObj, int *sPrev, int *sPst, int &K,
+__device__ __forceinline__ void tail_team_mode(const TailArgs &a, const E &ed, int *sU, int *sStart, int &K,
                                                long long &nits, const long long max_iter, const double eps,
-                                               unsigned long long &edges, unsigned long long &bids, int &err) {
-    const int lane = threadIdx.x & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const double ninf = -__builtin_huge_val();
-    __shared__ int mU[2][kTeamMax], mS[2][kTeamMax], mK[2];  // the list and K, double-buffered by round parity
-    int pi, ps, c[4], e;
-    double av[4];
-    const int lane_zero = (int)__builtin_amdgcn_mbcnt_hi(0u, __builtin_amdgcn_mbcnt_lo(0u, 0u));  // 0, not uniform
-    auto request = [&](int person, int start) {  // first four 64-edge chunks of a row + its end (vector loads)
+                                               TailStats &st) {
+    const int lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    static_assert(kTeamMax <= 2 * (kTailMax / kWave) && kTeamMax <= kWave, "two list slots per wavefront");
+    __shared__ unsigned long long tKey[2][kTeamMax];
+    __shared__ int tObj[2][kTeamMax], tPrev[2][kTeamMax], tPst[2][kTeamMax];
+    const int n0 = 2 * wave;  // my slots: n0, n0 + 1
+    // the list, replicated in every wavefront: lane l holds slot l
+    int u = lane < K ? sU[min(lane, kTailMax - 1)] : -1;
+    int sx = lane < K ? sStart[min(lane, kTailMax - 1)] : 0;
+    int pi[2], ps[2];
+    auto my_slots = [&]() {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) ed.load_nt(start + u * kWave + lane, c[u], av[u]);
-        e = a.row_ptr[person + 1 + lane_zero];
+        for (int X = 0; X < 2; ++X) {
+            pi[X] = n0 + X < K ? __builtin_amdgcn_readlane(u, min(n0 + X, kWave - 1)) : -1;
+            ps[X] = n0 + X < K ? __builtin_amdgcn_readlane(sx, min(n0 + X, kWave - 1)) : 0;
+        }
     };
-    if ((int)threadIdx.x < kTeamMax) {
-        mU[0][threadIdx.x] = (int)threadIdx.x < K ? sU[threadIdx.x] : -1;
-        mS[0][threadIdx.x] = (int)threadIdx.x < K ? sStart[threadIdx.x] : 0;
-    }
-    pi = wave < K ? sU[wave] : -1;
-    ps = wave < K ? sStart[wave] : 0;
-    if (wave < K) request(pi, ps);
-    __syncthreads();
+    my_slots();
+    TwoFetch<E> tf;
+    tf.slot = cand_no_line();
+    if (n0 < K) request_two(a, ed, pi[0], ps[0], pi[1], ps[1], tf);
+    __syncthreads();  // (sU / sStart have been read by everybody)
     int par = 0;
     for (;;) {
-        int prev = -1, pst = 0;
-        if (wave < K) {  // wave-uniform: BID for my slot (slots < K are always occupied: the list is compact)
-            Top2 x;
-            x.v = ninf;
-            x.w = ninf;
-            x.g = -1;
-            int c1 = 0, o1 = -1, os1 = 0;
-            double a1 = 0.0;
-            PriceRec r[4];
-            int cc[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const bool ok = ps + u * kWave + lane < e;
-                cc[u] = ok ? c[u] : -1;
-                r[u] = a.rec[ok ? c[u] : 0];
-            }
-            auto update = [&](int cu, double au, const PriceRec &ru, int g) {
-                const bool ok = cu >= 0;
-                const double v = ok ? au - ru.price : ninf;        // vi = cost - p[j]   (:350)
-                const bool ge = ok & (v >= x.v);                   // :351
-                x.w = __builtin_fmax(x.w, __builtin_fmin(v, x.v)); // :353 / :357-358
-                x.v = __builtin_fmax(x.v, v);
-                x.g = ge ? g : x.g;
-                c1 = ge ? cu : c1;
-                a1 = ge ? au : a1;
-                o1 = ge ? ru.owner : o1;
-                os1 = ge ? ru.ostart : os1;
-            };
-#pragma unroll
-            for (int u = 0; u < 4; ++u) update(cc[u], av[u], r[u], ps + u * kWave + lane);
-            for (int base = ps + 4 * kWave; base < e; base += kWave) {  // rows longer than 256 edges
-                const int g = base + lane;
-                int cu;
-                double au;
-                ed.load_nt(min(g, e - 1), cu, au);
-                const PriceRec ru = a.rec[cu];
-                update(g < e ? cu : -1, au, ru, g);
-            }
-            const int len = e - ps;
-            const int hi = __double2hiint(x.v);
-            const int k = hi ^ ((hi >> 31) & 0x7fffffff);
-            const int kmax = wave_max_i32(k);
-            const unsigned long long cand = __ballot(k == kmax);
-            const bool fast = __popcll(cand) == 1;  // wave-uniform
-            int src;
-            Top2 t2;
-            if (fast) {
-                src = __ffsll((long long)cand) - 1;
-            } else {
-                const int g_mine = x.g;
-                t2 = top2_wave_reduce(x);
-                src = __ffsll((long long)__ballot(g_mine == t2.g)) - 1;
-            }
-            prev = __builtin_amdgcn_readlane(o1, src);
-            pst = __builtin_amdgcn_readlane(os1, src);
-            const int col = __builtin_amdgcn_readlane(c1, src);
-            request(prev, pst);  // the owner my bidder evicts if it wins (prev == -1: a valid, unused address)
-            const double W = fast ? wave_max_f64(lane == src ? x.w : x.v) : t2.w;
-            const double cost = readlane_f64(a1, src);
-            const double bid = (cost - W) + eps;  // bbest = costbest - wi + eps   (:360)
-            if (!(bid >= 0.0)) err |= kErrNegativeBid;
-            edges += (unsigned long long)len;
-            bids += 1;
+        int sp[2] = {-2, -2};  // persons whose lines were requested early (-2: nothing requested)
+        CandBuildArgs bd;
+        int bd_person = -1;
+        if (n0 < K) {  // wave-uniform: BID for my slots (slots < K are always occupied: the list is compact)
+            CandBid b[2];
+            bid_two(a, ed, pi, ps, tf, eps, b, bd, bd_person, st, [&](const CandBid(&w)[2]) {
+                sp[0] = pi[0] >= 0 ? w[0].prev : -1;
+                sp[1] = pi[1] >= 0 ? w[1].prev : -1;
+                request_two(a, ed, sp[0], 0, sp[1], 0, tf);  // the owners my bidders evict if they win
+            });
             if (lane == 0) {
-                sKey[wave] = bid_to_key(bid);
-                sObj[wave] = col;
-                sPrev[wave] = prev;
-                sPst[wave] = pst;
+#pragma unroll
+                for (int X = 0; X < 2; ++X)
+                    if (pi[X] >= 0) {
+                        tKey[par][n0 + X] = b[X].key;
+                        tObj[par][n0 + X] = b[X].obj;
+                        tPrev[par][n0 + X] = b[X].prev;
+                        tPst[par][n0 + X] = b[X].pstart;
+                    }
             }
         }
-        tail_barrier_lds();  // the bids are in LDS; row requests stay in flight
-        if (wave == 0) {     // RESOLVE / ASSIGN / push_all_left on lanes = slots
+        tail_barrier_lds();  // the bids are in LDS and every gather of the round is done; requests stay in flight
+        {  // RESOLVE / ASSIGN / push_all_left on lanes = slots, in every wavefront
             const bool act = lane < K;
-            const unsigned long long lkey = act ? sKey[lane] : 0ull;
-            const int lobj = act ? sObj[lane] : (-2 - lane);
+            const int ls = min(lane, kTeamMax - 1);
+            const unsigned long long lkey = act ? tKey[par][ls] : 0ull;
+            const int lobj = act ? tObj[par][ls] : (-2 - lane);
+            const int lprev = act ? tPrev[par][ls] : -1, lpst = act ? tPst[par][ls] : 0;
             bool lose = false;
             for (int m = 0; m < K; ++m) {  // :375-385, all pairs via readlane
                 const int om = __builtin_amdgcn_readlane(lobj, m);
@@ -345,13 +352,10 @@ __device__ __forceinline__ void tail_team_mode(const TailArgs &a, const E &ed, i
                     lose |= same && (km > lkey || (km == lkey && m < lane));
                 }
             }
-            const int me = act ? mU[par][lane] : -1;
-            const int mst = act ? mS[par][lane] : 0;
             const bool won = act && !lose;
-            const int lprev = sPrev[lane], lpst = sPst[lane];
-            if (won) apply_winner(a, me, mst, lobj, lprev, lkey);  // :396-418
-            int u = won ? lprev : me;  // the evicted owner inherits the slot (:409) / hole (:412) / a loser stays
-            int st = won ? lpst : mst;
+            if (won && n0 < K) apply_winner(a, u, sx, lobj, lprev, lkey);  // :396-418 (serving wavefronts only)
+            u = won ? lprev : u;  // the evicted owner inherits the slot (:409) / hole (:412) / a loser stays
+            sx = won ? lpst : sx;
             const unsigned long long kmask = (1ull << K) - 1ull;
             const unsigned long long holes = __ballot(act && u == -1) & kmask;
             const int Kn = K - __popcll(holes);
@@ -360,42 +364,34 @@ __device__ __forceinline__ void tail_team_mode(const TailArgs &a, const E &ed, i
             unsigned long long mv = ~holes & ~lmask & kmask;  // persons right of K'
             while (hl) {  // wave-uniform, rare: k-th hole <- k-th mover (:137-162)
                 const int hk = __ffsll((long long)hl) - 1, mk = __ffsll((long long)mv) - 1;
-                const int mu = __builtin_amdgcn_readlane(u, mk), ms = __builtin_amdgcn_readlane(st, mk);
+                const int mu = __builtin_amdgcn_readlane(u, mk), ms = __builtin_amdgcn_readlane(sx, mk);
                 if (lane == hk) {
                     u = mu;
-                    st = ms;
+                    sx = ms;
                 }
                 hl &= hl - 1;
                 mv &= mv - 1;
             }
-            if (lane < kTeamMax) {
-                mU[par ^ 1][lane] = lane < Kn ? u : -1;
-                mS[par ^ 1][lane] = st;
-            }
-            if (lane == 0) mK[par ^ 1] = Kn;
+            if (lane >= Kn) u = -1;
+            K = Kn;
         }
-        tail_barrier_lds();  // the new list is in LDS, the winners' records have been issued
         par ^= 1;
-        const int Kold = K;
-        K = mK[par];
         nits += 1;
-        if (wave < Kold) {  // my slot's new occupant: usually exactly the row requested above
-            const int np = wave < kTeamMax ? mU[par][wave] : -1, ns = wave < kTeamMax ? mS[par][wave] : 0;
-            if (np >= 0 && !(prev >= 0 && np == prev && ns == pst)) request(np, ns);  // lost, or moved by push_all_left
-            pi = np;
-            ps = ns;
-        }
-        if (K <= 2 || nits >= max_iter) break;
+        my_slots();  // my slots' new occupants: usually exactly the persons whose lines were requested early
+        const bool done = K <= 2 || nits >= max_iter;
+        if (!done && n0 < K && (sp[0] != pi[0] || sp[1] != pi[1]))
+            request_two(a, ed, pi[0], ps[0], pi[1], ps[1], tf);  // a scanned row, a lost bid, a moved person
+        if (bd_person >= 0) tail_build(a, bd_person, bd, eps, st);
+        if (done) break;
     }
-    __syncthreads();
-    if (threadIdx.x < kTeamMax) {
-        sU[threadIdx.x] = mU[par][threadIdx.x];
-        sStart[threadIdx.x] = mS[par][threadIdx.x];
+    if (wave == 0 && lane < kTeamMax) {
+        sU[lane] = u;
+        sStart[lane] = sx;
     }
     __syncthreads();
 }
 
-template <class E, bool STAMP>
+template <class E>
 __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
     __shared__ int sU[kTailMax];
     __shared__ unsigned long long sKey[kTailMax];
@@ -409,7 +405,7 @@ __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
     __shared__ unsigned long long hKey[kHashSize];
     __shared__ int hPos[kHashSize];
     __shared__ int sCnt[3][kTailMax / kWave];
-    __shared__ int sK;
+    __shared__ int sK, sMissCnt;
     __shared__ long long sNits;
 
     Ctl *ctl = a.ctl;
@@ -429,133 +425,115 @@ __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
         hPos[h] = kPosNone;
     }
     const double eps = (double)a.eps;
-    unsigned long long edges = 0, bids = 0;
-    int err = 0;
-    unsigned long long st[5] = {0, 0, 0, 0, 0}, t_prev = 0;
-    unsigned long long st2[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_prev2 = 0;
-    auto stamp = [&](int k) {
-        if (STAMP && wave == 0) {
-            const unsigned long long t = __builtin_amdgcn_s_memtime();
-            st[k] += t - t_prev;
-            t_prev = t;
-        }
-    };
+    TailStats st;
+    st.edges = st.bids = st.hits = st.hit_edges = st.builds = 0ull;
+    st.err = 0;
+    st.hint = 0.0;
+    if (t == 0) sMissCnt = 0;
     __syncthreads();
-    if (STAMP) t_prev = __builtin_amdgcn_s_memtime();
 
+    // per-mode accounting (always on: two s_memrealtime reads per mode entry, 100 MHz ticks), Ctl::dbg:
+    //   [0..2] rounds in solo / team / block mode, [3..5] ticks, [6..8] bids, [9..11] line hits (wavefront 0's own)
+    unsigned long long md[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto mode_begin = [&](int m) {
+        md[3 + m] -= __builtin_amdgcn_s_memrealtime();
+        md[m] -= (unsigned long long)nits;
+        md[6 + m] -= st.bids;
+        md[9 + m] -= st.hits;
+    };
+    auto mode_end = [&](int m) {
+        md[3 + m] += __builtin_amdgcn_s_memrealtime();
+        md[m] += (unsigned long long)nits;
+        md[6 + m] += st.bids;
+        md[9 + m] += st.hits;
+    };
     for (;;) {
-        if (K >= 3 && K <= kTeamMax && !STAMP) {
+        if (K <= 2) {
+            // ---- solo mode: wavefront 0 runs the rest of the phase alone, see tail_solo_mode
+            if (wave == 0) {
+                mode_begin(0);
+                tail_solo_mode(a, ed, sU, sStart, K, nits, max_iter, eps, st);
+                mode_end(0);
+                if (lane == 0) {
+                    sK = K;
+                    sNits = nits;
+                }
+            }
+            __syncthreads();
+            K = sK;
+            nits = sNits;
+            break;  // K == 0 or nits == max_iter
+        }
+        if (K <= kTeamMax) {
             // ---- team mode: every wavefront, until K <= 2 (or max_iter), see tail_team_mode
-            tail_team_mode(a, ed, sU, sStart, sKey, sObj, sPrev, sPst, K, nits, max_iter, eps, edges, bids, err);
+            mode_begin(1);
+            tail_team_mode(a, ed, sU, sStart, K, nits, max_iter, eps, st);
+            mode_end(1);
             if (K == 0 || nits >= max_iter) break;
             continue;
         }
-        if (K == 2 && !STAMP) {
-            // ---- pair mode: wavefront 0 runs the rounds alone until K < 2 (or max_iter), see tail_pair_mode
-            if (wave == 0) {
-                tail_pair_mode(a, ed, sU, sStart, K, nits, max_iter, eps, edges, bids, err);
-                if (lane == 0) {
-                    sK = K;
-                    sNits = nits;
-                }
-            }
-            __syncthreads();
-            K = sK;
-            nits = sNits;
-            if (K == 0 || nits >= max_iter) break;
-            continue;  // K == 1: chain mode
-        }
-        // ---- BID: one wavefront per bidder ---------------------------------------------------
-        if (K == 1) {
-            // ---- chain mode: one bidder per round until the phase ends (K never grows).  Wavefront 0 runs
-            // the rounds alone, without barriers and without LDS; the other wavefronts wait at the barrier
-            // below.  Round r+1's bidder is the owner evicted in round r, and its row start came with the
-            // price record, so the only dependent global accesses per round are: the row (edges), the
-            // price records of its columns, and row_ptr[i+1] in parallel with the edges.
-            if (wave == 0) {
-                int i = sU[0];
-                int s = sStart[0];
-                RowPrefetch pf;
-                pf.row_ptr = a.row_ptr;
-                pf.issue(ed, nullptr, i, s, lane);  // the first bidder's own row (row end = row_ptr[i + 1])
-                pf.advance();
-                for (;;) {
-                    unsigned long long key;
-                    int obj, prev, pstart, e;
-                    if (STAMP) {
-                        CycleStamp cs{st2, &t_prev2, true};
-                        cs(15);
-                        cs(0);
-                        wave_bid_rec(ed, a.rec, s, a.row_ptr + i + 1, eps, key, obj, prev, pstart, e, err, cs, &pf);
-                    } else {
-                        wave_bid_rec(ed, a.rec, s, a.row_ptr + i + 1, eps, key, obj, prev, pstart, e, err, NoStamp(), &pf);
-                    }
-                    pf.advance();
-                    edges += (unsigned long long)(e - s);
-                    bids += 1;
-                    nits += 1;
-                    // ASSIGN (:396-418): the single bidder always wins
-                    if (lane == 0) apply_winner(a, i, s, obj, prev, key);
-                    if (STAMP) {
-                        CycleStamp cs{st2, &t_prev2, true};
-                        cs(5);
-                    }
-                    if (prev == -1) {  // nobody evicted: everybody is assigned
-                        K = 0;
-                        if (lane == 0) sU[0] = -1;
-                        break;
-                    }
-                    i = prev;  // the evicted owner inherits the slot (:409) and bids next
-                    s = pstart;
-                    if (nits >= max_iter) {
+        // ---- block mode, BID in two passes.  Pass A: the lines, two list slots per wavefront (one per 32-lane
+        // half, one gather serves both); a hit goes straight to LDS, a miss is queued.  Pass B: the queued persons,
+        // one wavefront each, by a full scan of their rows (+ line rebuild).
+        mode_begin(2);
+        {
+            const RecSource src{a.rec};
+            for (int base = 0; base < K; base += 2 * nwaves) {
+                const int n0 = base + 2 * wave;
+                const int nme = n0 + (lane >> 5);
+                const int pme = nme < K ? sU[min(nme, kTailMax - 1)] : -1;
+                int2 slot = cand_no_line();
+                if (E::kCand && a.cand != nullptr)
+                    slot = a.cand[(size_t)max(pme, 0) * kCandLanes + (lane & (kCandLanes - 1))];
+                CandBid b[2];
+                b[0].hit = b[1].hit = false;
+                if (E::kCand) cand_eval2(slot, n0 < K, n0 + 1 < K, src, eps, b, st.err, NoEarly());
+#pragma unroll
+                for (int X = 0; X < 2; ++X) {
+                    const int n = n0 + X;
+                    if (n >= K) continue;  // wave-uniform
+                    if (b[X].hit) {
                         if (lane == 0) {
-                            sU[0] = i;
-                            sStart[0] = s;
+                            sKey[n] = b[X].key;
+                            sObj[n] = b[X].obj;
+                            // owner at the start of the round == what the assignment phase reads (:401): the record
+                            // of obj is only rewritten by this round's winner of obj, after every bid has been made.
+                            sPrev[n] = b[X].prev;
+                            sPst[n] = b[X].pstart;
                         }
-                        break;
+                        st.hits += 1;
+                        st.hit_edges += (unsigned long long)b[X].len;
+                        st.edges += (unsigned long long)b[X].len;
+                        st.bids += 1;
+                    } else if (lane == 0) {
+                        sList[atomicAdd(&sMissCnt, 1)] = n;
                     }
-                }
-                if (lane == 0) {
-                    sK = K;
-                    sNits = nits;
                 }
             }
             __syncthreads();
-            K = sK;
-            nits = sNits;
-            break;
+            const int nmiss = sMissCnt;
+            for (int m = wave; m < nmiss; m += nwaves) {
+                const int n = __builtin_amdgcn_readfirstlane(sList[m]);
+                const int i = __builtin_amdgcn_readfirstlane(sU[n]);
+                const int s0 = __builtin_amdgcn_readfirstlane(sStart[n]);
+                const typename E::Raw none[4] = {};
+                const int ev = a.row_ptr[i + 1 + lane_zero()];
+                CandBid bm;
+                CandBuildArgs ba;
+                wave_bid_full<E, RecSource, true, false>(ed, src, s0, ev, none, eps, bm, ba, st.err);
+                ba.want = ba.want && a.cand != nullptr;
+                if (lane == 0) {
+                    sKey[n] = bm.key;
+                    sObj[n] = bm.obj;
+                    sPrev[n] = bm.prev;
+                    sPst[n] = bm.pstart;
+                }
+                st.edges += (unsigned long long)bm.len;
+                st.bids += 1;
+                if (ba.want) tail_build(a, i, ba, eps, st);
+            }
         }
-        for (int n = wave; n < K; n += nwaves) {
-            const int i = sU[n];
-            const int s = sStart[n];
-            unsigned long long key;
-            int obj, prev, pstart, e;
-            if (STAMP) {
-                CycleStamp cs{st2, &t_prev2, wave == 0};
-                cs(15);  // (re)arm
-                cs(0);   // row pointers landed
-                wave_bid_rec(ed, a.rec, s, a.row_ptr + i + 1, eps, key, obj, prev, pstart, e, err, cs);
-            } else {
-                wave_bid_rec(ed, a.rec, s, a.row_ptr + i + 1, eps, key, obj, prev, pstart, e, err);
-            }
-            if (lane == 0) {
-                sKey[n] = key;
-                sObj[n] = obj;
-                // owner at the start of the round == what the assignment phase reads (:401): the record of
-                // obj is only rewritten by this round's winner of obj, after every bid has been made.
-                sPrev[n] = prev;
-                sPst[n] = pstart;
-            }
-            if (STAMP) {
-                CycleStamp cs{st2, &t_prev2, wave == 0};
-                cs(5);  // LDS writes
-            }
-            edges += (unsigned long long)(e - s);
-            bids += 1;
-        }
-        stamp(0);
         __syncthreads();
-        stamp(1);
 
         if (K <= kWave) {
             // ---- fast path: the whole rest of the round in wavefront 0, no LDS atomics ------------
@@ -573,10 +551,10 @@ __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
                     }
                 }
                 int u = act ? sU[lane] : -1;
-                int st = act ? sStart[lane] : 0;  // row start travelling with the slot's person
+                int sx = act ? sStart[lane] : 0;  // row start travelling with the slot's person
                 if (act && !lose) {
-                    u = apply_winner(a, u, st, obj, sPrev[lane], key);
-                    st = sPst[lane];
+                    u = apply_winner(a, u, sx, obj, sPrev[lane], key);
+                    sx = sPst[lane];
                 }
                 // push_all_left with ballots
                 const unsigned long long kmask = (K >= 64) ? ~0ull : ((1ull << K) - 1ull);
@@ -587,7 +565,7 @@ __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
                 if (hl == 0ull) {  // wave-uniform: nothing to move (no hole, or only holes at the end)
                     if (act) {
                         sU[lane] = (lane < Kn) ? u : -1;
-                        sStart[lane] = st;
+                        sStart[lane] = sx;
                     }
                 } else {
                     const unsigned long long mv = ~holes & ~lmask & kmask;  // persons right of K'
@@ -599,20 +577,23 @@ __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
                     if (is_mv) {
                         const int dst = sList[__popcll(mv & lanemask_lt())];
                         sU[dst] = u;
-                        sStart[dst] = st;
+                        sStart[dst] = sx;
                     }
                     if (act) {
                         if (lane >= Kn) sU[lane] = -1;
                         else if (!is_hl) {
                             sU[lane] = u;
-                            sStart[lane] = st;
+                            sStart[lane] = sx;
                         }
                     }
                 }
-                if (lane == 0) sK = Kn;
+                if (lane == 0) {
+                    sK = Kn;
+                    sMissCnt = 0;
+                }
             }
         } else {
-            // ---- general path (64 < K <= 1024): LDS hash table keyed by object ---------------------
+            // ---- general path (64 < K <= 512): LDS hash table keyed by object ---------------------
             const bool act = t < K;
             unsigned long long key = 0ull;
             int obj = -1, h = 0;
@@ -638,10 +619,10 @@ __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
                 hPos[h] = kPosNone;
             }
             int u = act ? sU[t] : -1;
-            int st = act ? sStart[t] : 0;
+            int sx = act ? sStart[t] : 0;
             if (win) {
-                u = apply_winner(a, u, st, obj, sPrev[t], key);
-                st = sPst[t];
+                u = apply_winner(a, u, sx, obj, sPrev[t], key);
+                sx = sPst[t];
             }
             const bool hole = act && u == -1;
             const unsigned long long bh = __ballot(hole);
@@ -667,38 +648,44 @@ __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
             __syncthreads();
             if (is_mv) {
                 sU[sList[pm]] = u;
-                sStart[sList[pm]] = st;
+                sStart[sList[pm]] = sx;
             }
             if (act) {
                 if (t >= Kn) sU[t] = -1;
                 else if (!is_hl) {
                     sU[t] = u;
-                    sStart[t] = st;
+                    sStart[t] = sx;
                 }
             }
-            if (t == 0) sK = Kn;
+            if (t == 0) {
+                sK = Kn;
+                sMissCnt = 0;
+            }
         }
-        stamp(2);
         __syncthreads();
-        stamp(3);
         K = sK;
         nits += 1;
+        mode_end(2);
         if (K == 0 || nits >= max_iter) break;
     }
-    if (STAMP && t == 0) {
-        for (int k = 0; k < 4; ++k) atomicAdd(&ctl->dbg[k], st[k]);
-        for (int k = 0; k < 6; ++k) atomicAdd(&ctl->dbg[4 + k], st2[k]);
-        atomicAdd(&ctl->dbg[10], bids);  // bids made by wavefront 0
-    }
+    if (t == 0)
+        for (int k = 0; k < 12; ++k) ctl->dbg[k] += md[k];
 
     if (t < K0) a.U[t] = sU[t];
     if (lane == 0) {
-        if (edges) {
-            atomicAdd(&ctl->edges, edges);
-            atomicAdd(&ctl->tail_edges, edges);
-            atomicAdd(&ctl->bids, bids);
+        if (st.bids) {
+            atomicAdd(&ctl->edges, st.edges);
+            atomicAdd(&ctl->tail_edges, st.edges);
+            atomicAdd(&ctl->bids, st.bids);
+            if (st.hits) {
+                atomicAdd(&ctl->cand_hits, st.hits);
+                atomicAdd(&ctl->cand_edges, st.hit_edges);
+            }
+            atomicAdd(&ctl->dbg[12], st.bids);  // the tail's own totals: bids, line hits, line builds
+            atomicAdd(&ctl->dbg[13], st.hits);
+            atomicAdd(&ctl->dbg[14], st.builds);
         }
-        if (err) atomicOr(&ctl->err, err);
+        if (st.err) atomicOr(&ctl->err, st.err);
     }
     if (t == 0) {
         ctl->K = K;

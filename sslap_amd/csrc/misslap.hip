@@ -111,6 +111,8 @@ struct misslap_solver {
     int *row_ptr = nullptr;
     double *price = nullptr;
     PriceRec *rec = nullptr;
+    int2 *cand = nullptr;  // candidate lines, 256 B per person (8 B/edge layout only)
+    bool warm_lines = true;  // stream the lines into the Infinity Cache before every tail launch
     int *p2o = nullptr, *o2p = nullptr, *U = nullptr;
     unsigned long long *bid_key = nullptr;
     int *bid_obj = nullptr;
@@ -150,7 +152,6 @@ struct misslap_solver {
     int rank = 0, world = 1;
     int shard_min_K = 0;  // multi-GPU: only rounds with K >= this are sharded and exchanged
     bool profile = false;
-    bool stamp = false;  // profile == 2: stamped (diagnostic) tail kernel
     int K_ub = 0;  // host-side upper bound of K (K never grows inside a phase)
     bool K_exact = false;  // K_ub was read from the device and no round has been enqueued since
     bool phase_fresh = true;  // no round of the current eps-phase has been enqueued yet
@@ -195,6 +196,7 @@ RoundArgs round_args(misslap_solver *h) {
     a.eps = h->eps;
     a.launch_idx = 0;
     a.gather_max_K = h->tiled_ok ? h->tiled_min_K : 0;
+    a.cand = h->cand;
     return a;
 }
 
@@ -386,6 +388,7 @@ int launch_tail(misslap_solver *h) {
     a.p2o = h->p2o;
     a.o2p = h->o2p;
     a.U = h->U;
+    a.cand = h->cand;
     a.thr = h->thr;
     a.eps = h->eps;
     ProfRec *pr = nullptr;
@@ -394,14 +397,15 @@ int launch_tail(misslap_solver *h) {
         if (!pr) return fail(MISSLAP_ERR_HIP, "hipEventCreate failed");
         HIP_TRY(hipEventRecord(pr->start, h->stream));
     }
+    if (h->cand && h->warm_lines)
+        hipLaunchKernelGGL(k_warm_lines, dim3(kMaxGridBlocks), dim3(256), 0, h->stream,
+                           reinterpret_cast<const int4 *>(h->cand), (long long)h->n_rows * (kCandLanes / 2), h->nmatch);
     if (h->f32) {
         EdgesF32 ed{h->edges32};
-        if (h->stamp) hipLaunchKernelGGL((k_tail<EdgesF32, true>), dim3(1), dim3(kTailMax), 0, h->stream, a, ed);
-        else hipLaunchKernelGGL((k_tail<EdgesF32, false>), dim3(1), dim3(kTailMax), 0, h->stream, a, ed);
+        hipLaunchKernelGGL(k_tail<EdgesF32>, dim3(1), dim3(kTailMax), 0, h->stream, a, ed);
     } else {
         EdgesF64 ed{h->col, h->val64};
-        if (h->stamp) hipLaunchKernelGGL((k_tail<EdgesF64, true>), dim3(1), dim3(kTailMax), 0, h->stream, a, ed);
-        else hipLaunchKernelGGL((k_tail<EdgesF64, false>), dim3(1), dim3(kTailMax), 0, h->stream, a, ed);
+        hipLaunchKernelGGL(k_tail<EdgesF64>, dim3(1), dim3(kTailMax), 0, h->stream, a, ed);
     }
     if (pr) HIP_TRY(hipEventRecord(pr->stop, h->stream));
     // the tail keeps only the price records current: rebuild price / o2p / p2o from them
@@ -443,7 +447,7 @@ void free_all(misslap_solver *h) {
     (void)hipSetDevice(h->device);
     void *ptrs[] = {h->edges32, h->col,     h->val64,     h->row_ptr,    h->price,   h->p2o,     h->o2p,
                     h->U,       h->bid_key, h->bid_obj,   h->best_key,   h->best_pos, h->cnt,    h->hole_list,
-                    h->mover_list, h->ctl,  h->contrib,   h->nmatch,     h->launch_edges, h->tiled, h->tcol, h->seg, h->seg4, h->rec, h->part_v, h->part_w, h->part_g};
+                    h->mover_list, h->ctl,  h->contrib,   h->nmatch,     h->launch_edges, h->tiled, h->tcol, h->seg, h->seg4, h->rec, h->part_v, h->part_w, h->part_g, h->cand};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_ctl) (void)hipHostFree(h->h_ctl);
@@ -611,6 +615,8 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
     if ((rc = dev_alloc(&h->price, Mpad))) return rc;
     HIP_TRY(hipMemsetAsync(h->price, 0, sizeof(double) * Mpad, h->stream));
     if ((rc = dev_alloc(&h->rec, M))) return rc;
+    if (h->f32 && !opt->reserved[4])  // candidate lines (reserved[4] != 0: off, A/B timing and parity tests)
+        if ((rc = dev_alloc(&h->cand, N * (size_t)kCandLanes))) return rc;
     if ((rc = dev_alloc(&h->p2o, N))) return rc;
     if ((rc = dev_alloc(&h->o2p, M))) return rc;
     if ((rc = dev_alloc(&h->U, N))) return rc;
@@ -630,12 +636,13 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
         if ((rc = dev_alloc(&h->launch_edges, (size_t)h->launch_edges_cap))) return rc;
         HIP_TRY(hipMemsetAsync(h->launch_edges, 0, sizeof(unsigned long long) * h->launch_edges_cap, h->stream));
     }
+    h->warm_lines = opt->reserved[5] == 0;
     h->shard_min_K = h->tiled_ok ? h->tiled_min_K : (int)std::max<size_t>((N * 3) / 10, 8192);
     if (opt->reserved[3] > 0) h->shard_min_K = opt->reserved[3];
     if (opt->reserved[3] < 0) h->shard_min_K = 0;  // every grid round sharded + exchanged
     h->max_iter = opt->max_iter < 1 ? 1 : opt->max_iter;  // the loop body runs before the first test (:271-275)
     hipLaunchKernelGGL(k_init_state, dim3(blocks_for((long long)(N > M ? N : M), 256)), dim3(256), 0, h->stream,
-                       h->ctl, h->price, h->rec, h->p2o, h->o2p, h->U, h->best_key, h->best_pos, h->n_rows, h->n_cols,
+                       h->ctl, h->price, h->rec, h->p2o, h->o2p, h->U, h->best_key, h->best_pos, h->cand, h->n_rows, h->n_cols,
                        (long long)h->max_iter);
     HIP_TRY(hipGetLastError());
     // eps schedule, fp32 exactly as the generated C of the reference
@@ -679,7 +686,6 @@ int new_handle(misslap_solver **out, const misslap_options *opt, misslap_solver 
     h->rank = opt->shard_world > 0 ? opt->shard_rank : 0;
     h->profile = opt->profile != 0;
     h->profile_all = opt->profile >= 2;
-    h->stamp = opt->profile == 2;
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;
         return fail(MISSLAP_ERR_HIP, "hipStreamCreate failed");
@@ -995,7 +1001,13 @@ MISSLAP_API int misslap_finish(misslap_solver *h, int32_t *person_to_object_out,
     meta->tiled_active = h->tiled_ok ? (h->scan2d ? 2 : 1) : 0;
     meta->tiled_min_K = h->tiled_min_K;
     meta->shard_edges = c.shard_edges;
-    for (int k = 0; k < 11; ++k) meta->reserved_d[k] = (double)c.dbg[k];  // stamped tail build only
+    for (int k = 0; k < 6; ++k) meta->reserved_d[k] = (double)c.dbg[k];  // tail: rounds / 10-ns ticks per mode
+    for (int k = 0; k < 3; ++k) meta->reserved_d[6 + k] = (double)c.dbg[12 + k];  // tail: bids, line hits, builds
+#ifdef MISSLAP_TAIL_STAMP
+    for (int k = 0; k < 6; ++k) meta->reserved_d[k] = (double)c.dbg[6 + k];  // diagnostic build: solo-round segments (cycles)
+#endif
+    meta->cand_hits = c.cand_hits;
+    meta->cand_edges = c.cand_edges;
     if (h->profile && h->prof_used) {
         std::vector<unsigned long long> le((size_t)h->launch_idx);
         if (h->launch_idx)

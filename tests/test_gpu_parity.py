@@ -10,8 +10,8 @@ from sslap_amd import AuctionSolver, auction_solve, from_sparse, synth
 
 pytestmark = pytest.mark.gpu
 
-# tail_threshold variants: library default, grid kernels only, tiny tail, widest tail
-THRESHOLDS = [None, 0, 16, 1024]
+# tail_threshold variants: library default, grid kernels only, tiny tail, widest tail (= the tail workgroup)
+THRESHOLDS = [None, 0, 16, 512]
 
 
 def _solve_gpu(entry, loc, val, spec, kw, monkeypatch, thr):

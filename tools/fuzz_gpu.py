@@ -23,7 +23,7 @@ for seed in range(first, first + count):
     loc, val = synth.gen_sparse(n, m, density, seed=900 + seed, integer_values=ints)
     kw = dict(problem=prob, cardinality_check=False, max_iter=int(r.choice([10**8, 10**8, 10**8, 3000, 211, 17])),
               eps_start=float(r.choice([0.0, 0.0, 1.0, 0.01])))
-    gpu = dict(tail_threshold=[None, 0, 3, 17, 40, 200, 1024][seed % 7], tiled_min_k=[None, None, 1, -1][seed % 4],
+    gpu = dict(tail_threshold=[None, 0, 3, 17, 40, 200, 512][seed % 7], tiled_min_k=[None, None, 1, -1][seed % 4],
                rounds_per_sync=[None, 1, 5][seed % 3])
     gpu = {k: v for k, v in gpu.items() if v is not None}
     o = orc.from_sparse(loc, val.copy(), **kw)

@@ -1,0 +1,250 @@
+/*
+ * tools/sim/auction_sim.c -- ANALYSIS TOOLING (CPU only; neither product nor oracle).
+ *
+ * A fast sequential model of the reference's Jacobi auction (same rounds, same tie rules as
+ * oracle/auction_oracle.c, but with an O(#winners) assignment phase) that carries experiment hooks the
+ * checker must not: a per-person candidate-cache model and a histogram of round sizes.  Its own `its` /
+ * sha256(sol) are compared with the golden fixture by tools/sim/run_sim.py, so a model that drifts from
+ * the reference is noticed.
+ *
+ * Candidate cache model: a person keeps up to C of its edges (col, cost) plus a bound tau such that every
+ * edge NOT in the cache had value (cost - price) <= tau when the cache was built.  Prices only rise, so
+ * the bound holds forever.  A later bid is answered from the cache alone ("hit") iff, at current prices,
+ * the cached best value v1 > tau and the cached second-best v2 >= tau: then no uncached edge can be the
+ * best (ties excluded by the strict test) and none can exceed the second best.
+ *   policy 0: cache = the C largest values, tau = the (C+1)-th largest (exact top-C)
+ *   policy 1: cache = all edges with value >= t for a threshold t found by a bounded bisection between the
+ *             row's minimum and second-best value so that the count lands in [C/2, C]; tau = t
+ *             (what a wavefront can build with a handful of ballots)
+ *
+ * usage: auction_sim <input.bin> C policy build_thr use_thr
+ *   input.bin: int64 nnz, int32 maximize, int32 loc[nnz][2], double val[nnz]
+ *   build_thr: caches are (re)built on a miss in rounds with K <= build_thr
+ *   use_thr:   hits / misses are counted in rounds with K <= use_thr
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+static int cmp_desc(const void *a, const void *b) {
+    double x = *(const double *)a, y = *(const double *)b;
+    return x < y ? 1 : x > y ? -1 : 0;
+}
+
+int main(int argc, char **argv) {
+    if (argc < 6) {
+        fprintf(stderr, "usage: %s input.bin C policy build_thr use_thr\n", argv[0]);
+        return 2;
+    }
+    const int C = atoi(argv[2]), policy = atoi(argv[3]), build_thr = atoi(argv[4]), use_thr = atoi(argv[5]);
+    const int cmin = getenv("SIM_CMIN") ? atoi(getenv("SIM_CMIN")) : (C + 1) / 2;
+    FILE *f = fopen(argv[1], "rb");
+    if (!f) return 2;
+    int64_t nnz;
+    int32_t maximize;
+    if (fread(&nnz, 8, 1, f) != 1 || fread(&maximize, 4, 1, f) != 1) return 2;
+    int32_t *loc = malloc(sizeof(int32_t) * 2 * nnz);
+    double *val = malloc(sizeof(double) * nnz);
+    if (fread(loc, 8, nnz, f) != (size_t)nnz || fread(val, 8, nnz, f) != (size_t)nnz) return 2;
+    fclose(f);
+    int N = loc[2 * (nnz - 1)] + 1, M = 0;
+    for (int64_t k = 0; k < nnz; ++k)
+        if (loc[2 * k + 1] + 1 > M) M = loc[2 * k + 1] + 1;
+    int *row_ptr = calloc(N + 1, sizeof(int)), *col = malloc(sizeof(int) * nnz);
+    for (int64_t k = 0; k < nnz; ++k) {
+        row_ptr[loc[2 * k] + 1]++;
+        col[k] = loc[2 * k + 1];
+        if (!maximize) val[k] = -val[k];
+    }
+    for (int i = 0; i < N; ++i) row_ptr[i + 1] += row_ptr[i];
+    double maxabs = 0;
+    for (int64_t k = 0; k < nnz; ++k)
+        if (fabs(val[k]) > maxabs) maxabs = fabs(val[k]);
+    float eps = (float)((double)(float)maxabs / 2.0), target = (float)(1.0 / (double)N), theta = (float)0.15;
+    double *p = calloc(M, sizeof(double));
+    int *p2o = malloc(sizeof(int) * N), *o2p = malloc(sizeof(int) * M), *U = malloc(sizeof(int) * N);
+    int *pos = malloc(sizeof(int) * N);
+    for (int i = 0; i < N; ++i) p2o[i] = -1, U[i] = i, pos[i] = i;
+    for (int j = 0; j < M; ++j) o2p[j] = -1;
+    double *best_bid = malloc(sizeof(double) * M);
+    int *best_n = malloc(sizeof(int) * M);
+    for (int j = 0; j < M; ++j) best_bid[j] = -1.0, best_n[j] = -1;
+    int *bobj = malloc(sizeof(int) * N), *touched = malloc(sizeof(int) * N);
+    double *bbid = malloc(sizeof(double) * N);
+    /* cache */
+    int *c_col = malloc(sizeof(int) * (size_t)N * C);
+    double *c_cost = malloc(sizeof(double) * (size_t)N * C), *c_tau = malloc(sizeof(double) * N);
+    unsigned char *c_n = calloc(N, 1), *c_valid = calloc(N, 1);
+    double *tmpv = malloc(sizeof(double) * (size_t)(M < 1 << 20 ? 1 << 20 : M));
+    /* stats by mode: 0 chain (K=1), 1 pair, 2 team (3..16), 3 block (17..64), 4 (65..512), 5 (513..2048), 6 bigger */
+    int64_t rounds[7] = {0}, bids[7] = {0}, hits[7] = {0}, allhit[7] = {0}, bad = 0, builds = 0;
+    int64_t phase_rounds[7] = {0};
+    int64_t its = 0;
+    int K = N, nred = 0;
+    for (;;) {
+        const int mode = K == 1 ? 0 : K == 2 ? 1 : K <= 16 ? 2 : K <= 64 ? 3 : K <= 512 ? 4 : K <= 2048 ? 5 : 6;
+        const int use = K <= use_thr, build = K <= build_thr;
+        int round_hits = 0;
+        for (int n = 0; n < K; ++n) {
+            const int i = U[n], s = row_ptr[i], e = row_ptr[i + 1];
+            double vbest = -INFINITY, wi = -INFINITY, costbest = 0;
+            int jbest = 0;
+            for (int g = s; g < e; ++g) {
+                const double v = val[g] - p[col[g]];
+                if (v >= vbest || g == s) jbest = col[g], wi = vbest, vbest = v, costbest = val[g];
+                else if (v > wi) wi = v;
+            }
+            if (C > 0 && (use || build)) {
+                int hit = 0;
+                if (c_valid[i]) {
+                    double vc = -INFINITY, wc = -INFINITY;
+                    for (int k = 0; k < c_n[i]; ++k) {
+                        const double v = c_cost[(size_t)i * C + k] - p[c_col[(size_t)i * C + k]];
+                        if (v >= vc) wc = vc, vc = v;
+                        else if (v > wc) wc = v;
+                    }
+                    if (vc > c_tau[i] && wc >= c_tau[i]) {
+                        hit = 1;
+                        if (vc != vbest || wc != wi) bad++;
+                    }
+                }
+                if (use) {
+                    bids[mode]++;
+                    hits[mode] += hit;
+                    round_hits += hit;
+                }
+                if (!hit && build) {
+                    builds++;
+                    const int len = e - s;
+                    for (int g = s; g < e; ++g) tmpv[g - s] = val[g] - p[col[g]];
+                    double t;
+                    if (policy == 0) {
+                        qsort(tmpv, len, sizeof(double), cmp_desc);
+                        t = len > C ? tmpv[C] : -INFINITY; /* bound = (C+1)-th value; cache = values > bound ... */
+                        /* ties with the bound are left out of the cache (they are <= tau) */
+                    } else {
+                        /* bisection on the threshold: count(v >= t) in [C/2, C] */
+                        double lo = INFINITY, hi = wi; /* count(v >= hi) >= 2 */
+                        for (int k = 0; k < len; ++k)
+                            if (tmpv[k] < lo) lo = tmpv[k];
+                        t = hi;
+                        int cnt_hi = 0;
+                        for (int k = 0; k < len; ++k) cnt_hi += tmpv[k] >= hi;
+                        if (cnt_hi > C || !(lo < hi)) t = INFINITY; /* too many ties at the top: no cache */
+                        else if (len <= C) t = -INFINITY;
+                        else {
+                            for (int it = 0; it < 12; ++it) {
+                                const double mid = 0.5 * (lo + hi);
+                                int cnt = 0;
+                                for (int k = 0; k < len; ++k) cnt += tmpv[k] >= mid;
+                                if (cnt > C) lo = mid;
+                                else {
+                                    hi = mid;
+                                    t = mid;
+                                    if (cnt >= cmin) break;
+                                }
+                            }
+                        }
+                    }
+                    int cn = 0;
+                    if (t != INFINITY) {
+                        for (int g = s; g < e && cn < C; ++g) {
+                            const double v = val[g] - p[col[g]];
+                            if (policy == 0 ? v > t : v >= t) c_col[(size_t)i * C + cn] = col[g], c_cost[(size_t)i * C + cn] = val[g], cn++;
+                        }
+                        c_n[i] = (unsigned char)cn;
+                        c_tau[i] = t;
+                        c_valid[i] = 1;
+                    } else
+                        c_valid[i] = 0;
+                }
+            }
+            bobj[n] = jbest;
+            bbid[n] = (costbest - wi) + (double)eps;
+        }
+        if (use) {
+            rounds[mode]++;
+            allhit[mode] += round_hits == K;
+        }
+        phase_rounds[mode]++;
+        /* resolve */
+        int nt = 0;
+        for (int n = 0; n < K; ++n) {
+            const int j = bobj[n];
+            if (bbid[n] > best_bid[j]) {
+                if (best_n[j] == -1) touched[nt++] = j;
+                best_bid[j] = bbid[n];
+                best_n[j] = n;
+            }
+        }
+        /* assign */
+        int Kn = K;
+        for (int k = 0; k < nt; ++k) {
+            const int j = touched[k], n = best_n[j], i = U[n];
+            p[j] = best_bid[j];
+            const int prev = o2p[j];
+            if (prev != -1) p2o[prev] = -1, U[n] = prev;
+            else U[n] = -1, Kn--;
+            p2o[i] = j;
+            o2p[j] = i;
+            best_bid[j] = -1.0;
+            best_n[j] = -1;
+        }
+        /* push_all_left */
+        {
+            int r = Kn;
+            for (int l = 0; l < Kn; ++l)
+                if (U[l] == -1) {
+                    while (U[r] == -1) r++;
+                    U[l] = U[r];
+                    U[r] = -1;
+                }
+        }
+        K = Kn;
+        its++;
+        if (K == 0) {
+            /* eCE at target */
+            int ok = 1;
+            for (int i = 0; i < N && ok; ++i) {
+                const int j = p2o[i];
+                double cc = 0;
+                for (int g = row_ptr[i]; g < row_ptr[i + 1]; ++g)
+                    if (col[g] == j) cc = val[g];
+                const double lhs = cc - p[j] + 1e-7;
+                for (int g = row_ptr[i]; g < row_ptr[i + 1]; ++g)
+                    if (lhs < (val[g] - p[col[g]]) - (double)target) {
+                        ok = 0;
+                        break;
+                    }
+            }
+            if (ok || eps < target) break;
+            eps = eps * theta;
+            for (int i = 0; i < N; ++i) p2o[i] = -1, U[i] = i;
+            for (int j = 0; j < M; ++j) o2p[j] = -1;
+            K = N;
+            nred++;
+        }
+    }
+    /* FNV of sol for a cheap cross-check, plus its */
+    uint64_t h = 1469598103934665603ull;
+    for (int i = 0; i < N; ++i) h = (h ^ (uint64_t)(uint32_t)p2o[i]) * 1099511628211ull;
+    printf("{\"its\": %lld, \"nreductions\": %d, \"sol_fnv\": \"%016llx\", \"C\": %d, \"policy\": %d, \"build_thr\": %d, "
+           "\"use_thr\": %d, \"inconsistent\": %lld, \"builds\": %lld,\n \"modes\": [",
+           (long long)its, nred, (unsigned long long)h, C, policy, build_thr, use_thr, (long long)bad, (long long)builds);
+    const char *names[7] = {"K=1", "K=2", "K=3..16", "K=17..64", "K=65..512", "K=513..2048", "K>2048"};
+    for (int m = 0; m < 7; ++m)
+        printf("%s{\"mode\": \"%s\", \"rounds_all\": %lld, \"rounds\": %lld, \"bids\": %lld, \"hit_rate\": %.4f, "
+               "\"all_hit_rounds\": %.4f}",
+               m ? ",\n  " : "", names[m], (long long)phase_rounds[m], (long long)rounds[m], (long long)bids[m],
+               bids[m] ? (double)hits[m] / bids[m] : 0.0, rounds[m] ? (double)allhit[m] / rounds[m] : 0.0);
+    printf("]}\n");
+    /* sol to a file for the sha256 check */
+    if (argc > 6) {
+        FILE *o = fopen(argv[6], "wb");
+        fwrite(p2o, sizeof(int), N, o);
+        fclose(o);
+    }
+    return 0;
+}
