@@ -54,8 +54,7 @@ typedef struct misslap_options {
                                 [2]: full-scan engine: 0 / 1 k_bid_tiled (default), 2 k_scan2d + k_merge2d (experimental);
                                 [3]: multi-GPU shard threshold: 0 = default (the full-scan threshold, 0.3 N), > 0 = minimum K
                                      of a sharded round, < 0 = shard every grid round;
-                                [4]: 1 = no candidate lines (every bid scans its whole row; A/B timing, parity tests);
-                                [5]: 1 = do not stream the candidate lines into the Infinity Cache before a tail launch */
+                                [4]: 1 = no candidate lines (every bid scans its whole row; A/B timing, parity tests) */
 } misslap_options;
 
 /* Result block of misslap_finish: the reference's `meta` dict (auction_.pyx:264,:297-304)

@@ -27,7 +27,7 @@ _ENV_TILED = "MISSLAP_TILED_MIN_K"  # 0 default, < 0 never use the LDS-tiled bid
 
 def _options(problem, eps_start, max_iter, device=None, tail_threshold=None, profile=None, force_f64=False,
              input_on_device=False, shard=None, rounds_per_sync=None, tiled_min_k=None, tiled_shape=None, shard_min_k=None,
-             engine=None, cand=None, warm=None):
+             engine=None, cand=None):
     if problem not in ("min", "max"):
         # the reference treats every string other than 'min' as 'max' (auction_.pyx:236, :502)
         problem = "max" if problem != "min" else "min"
@@ -50,7 +50,6 @@ def _options(problem, eps_start, max_iter, device=None, tail_threshold=None, pro
     o.reserved[3] = int(os.environ.get("MISSLAP_SHARD_MIN_K", 0)) if shard_min_k is None else int(shard_min_k)
     # candidate lines (per-person exact bid shortcut, csrc/device_common.hpp): on by default, 0 = off (A/B runs)
     o.reserved[4] = (1 - int(os.environ.get("MISSLAP_CAND", 1))) if cand is None else (0 if cand else 1)
-    o.reserved[5] = (1 - int(os.environ.get("MISSLAP_WARM", 1))) if warm is None else (0 if warm else 1)
     return o
 
 

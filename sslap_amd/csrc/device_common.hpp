@@ -581,8 +581,51 @@ __device__ __forceinline__ void cand_eval2(int2 &slot, const bool act0, const bo
         out[X].key = bid_to_key(bid);
     }
 }
+// The same for ONE person (lanes 0..31 hold its line, `cls` = the lane is one of them and its slot is a candidate
+// slot, i.e. 1 <= lane <= kCandMax): the chain of single-bidder rounds is half of all rounds at C3 and two thirds
+// at C5, and a round is bound by the length of this dependent instruction sequence, not by memory.
+template <class Src, class Early, class S = NoStamp>
+__device__ __forceinline__ void cand_eval1(int2 &slot, const bool cls, const Src &src, const double eps, CandBid &out,
+                                           int &err, Early &&early, const S &stamp = S()) {
+    const int lane = lane_id();
+    const double ninf = -__builtin_huge_val();
+    stamp(1);  // (diagnostic builds: drains the memory counters) the line has landed
+    const bool is_cand = cls & (slot.x >= 0);
+    const PriceRec r = src.get(is_cand ? slot.x : 0);
+    stamp(2);  // the records have landed
+    const double cost = (double)__int_as_float(slot.y);
+    const double tau = readlane_f64(__hiloint2double(slot.y, slot.x), 0);
+    out.len = __builtin_amdgcn_readlane(slot.x, kCandLanes - 1);
+    const double v = is_cand ? cost - r.price : ninf;  // vi = cost - p[j]   (:350)
+    const int hi = __double2hiint(v);
+    const int k = hi ^ ((hi >> 31) & 0x7fffffff);  // signed order of k == order of the doubles' high words
+    const int km = __builtin_amdgcn_readlane(half_max_i32(k), 31);
+    const unsigned eq = (unsigned)(__ballot(k == km) & 0xffffffffull);
+    double V;
+    int G;
+    if (__popc(eq) == 1) {  // wave-uniform, the common case: the winner is known after one 32-bit reduction
+        G = __ffs((int)eq) - 1;
+        V = readlane_f64(v, G);
+    } else {
+        V = readlane_f64(half_max_f64(v), 31);
+        G = __builtin_amdgcn_readlane(half_max_i32((is_cand & (v == V)) ? lane : -1), 31);  // the LAST slot holding it
+    }
+    const int sl = max(G, 0);
+    out.obj = __builtin_amdgcn_readlane(slot.x, sl);
+    out.prev = __builtin_amdgcn_readlane(r.owner, sl);
+    out.pstart = __builtin_amdgcn_readlane(r.ostart, sl);
+    const double c1 = (double)__int_as_float(__builtin_amdgcn_readlane(slot.y, sl));
+    early(out);  // `slot` is dead from here on
+    stamp.light(3);
+    const double W = readlane_f64(half_max_f64(lane == G ? ninf : v), 31);  // second best, counting multiplicity
+    out.hit = (G >= 0) & (V > tau) & (W >= tau);
+    const double bid = (c1 - W) + eps;  // bbest = costbest - wi + eps   (:360)
+    if (out.hit && !(bid >= 0.0)) err |= kErrNegativeBid;
+    out.key = bid_to_key(bid);
+}
 struct NoEarly {
     __device__ __forceinline__ void operator()(const CandBid (&)[2]) const {}
+    __device__ __forceinline__ void operator()(const CandBid &) const {}
 };
 
 // What a full scan leaves behind for the (re)build of the person's line: column, cost and value of the lane's

@@ -77,20 +77,6 @@ __global__ __launch_bounds__(256) void k_sync_from_rec(const PriceRec *rec, doub
     }
 }
 
-// Before a tail launch: stream the candidate lines through the memory hierarchy once (51 MB at C3, a few
-// microseconds at HBM rate), so that the tail's dependent line reads are served by the 256 MiB Infinity Cache
-// (~550 cycles) instead of HBM (~900+).  The lines stay resident through the launch: the tail itself moves little
-// data.  Pure prefetch: nothing is computed; `sink` is never written (the test cannot succeed for real lines).
-__global__ __launch_bounds__(256) void k_warm_lines(const int4 *lines, long long n16, int *sink) {
-    int acc = 0;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < n16; k += stride) {
-        const int4 x = lines[k];
-        acc |= x.x & x.y & x.z & x.w;
-    }
-    if (acc == 0x7fffffff) *sink = acc;
-}
-
 // per-wavefront statistics, flushed once when the kernel ends
 struct TailStats {
     unsigned long long edges, bids, hits, hit_edges, builds;
@@ -187,6 +173,89 @@ __device__ __forceinline__ void bid_two(const TailArgs &a, const E &ed, const in
     }
 }
 
+// ---- chain mode: K == 1 --------------------------------------------------------------------------------------------
+// One bidder per round until the phase ends (K never grows): the bidder always wins (:375-385 has nothing to
+// resolve), the evicted owner inherits the only slot (:409) and bids next, and the chain ends when an unowned object
+// is won.  The owner and its row start come with the winning price record, so the only dependent memory accesses of
+// a round are the bidder's line and the records of its candidates; the next line is requested as soon as the winning
+// candidate is known.  Everything a round does not need (second list slot, resolve, push_all_left) is left out: a
+// round is bound by the length of its dependent instruction sequence.
+template <class E>
+__device__ __forceinline__ void tail_chain_mode(const TailArgs &a, const E &ed, int &pi, int &ps, int &K,
+                                                long long &nits, const long long max_iter, const double eps,
+                                                TailStats &st) {
+    const int lane = lane_id(), l32 = lane & (kCandLanes - 1);
+    const RecSource src{a.rec};
+    const bool cls = (lane >= 1) & (lane <= kCandMax);
+    const bool lines = E::kCand && a.cand != nullptr;
+    int2 slot = cand_no_line();
+    typename E::Raw row[4];  // 12 B/edge layout (no lines): the row, requested ahead
+    int ev = 0;
+    auto request = [&](int person, int start) {
+        if (E::kCand) {
+            if (lines) slot = a.cand[(size_t)max(person, 0) * kCandLanes + l32];
+        } else {
+            fetch_row<E>(a, ed, person, start, row, ev);
+        }
+    };
+    request(pi, ps);
+#ifdef MISSLAP_TAIL_STAMP
+    // diagnostic build: cycles per segment of a chain round -> Ctl::dbg[6..11]: [6] wait for the line, [7] record
+    // gather, [8] winner known + next line requested, [9] rest of the evaluation, [10] full scan of a missed person,
+    // [11] store / re-request / line rebuild
+    unsigned long long sacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sprev = __builtin_amdgcn_s_memtime();
+    const CycleStamp stamp{sacc, &sprev, true};
+#else
+    const NoStamp stamp;
+#endif
+    for (;;) {
+        CandBid b;
+        b.hit = false;
+        int sp = -2;  // the person whose line was requested early (-2: nothing requested)
+        if (E::kCand)
+            cand_eval1(slot, cls, src, eps, b, st.err, [&](const CandBid &w) {
+                sp = w.prev;
+                request(sp, 0);
+            }, stamp);
+        stamp.light(4);
+        CandBuildArgs bd;
+        bool build = false;
+        if (!b.hit) {  // wave-uniform
+            if (E::kCand) {
+                const typename E::Raw none[4] = {};
+                const int e = a.row_ptr[pi + 1];
+                wave_bid_full<E, RecSource, true, false>(ed, src, ps, e, none, eps, b, bd, st.err);
+            } else {
+                wave_bid_full<E, RecSource, true, true>(ed, src, ps, ev, row, eps, b, bd, st.err);
+            }
+            build = bd.want && lines;
+        } else {
+            st.hits += 1;
+            st.hit_edges += (unsigned long long)b.len;
+        }
+        stamp.light(5);
+        st.edges += (unsigned long long)b.len;
+        st.bids += 1;
+        nits += 1;
+        if (lane == 0) apply_winner(a, pi, ps, b.obj, b.prev, b.key);  // ASSIGN (:396-418)
+        const int built = pi;
+        pi = b.prev;  // the evicted owner inherits the slot (:409) and bids next; -1: everybody is assigned
+        ps = b.pstart;
+        K = pi != -1;
+        const bool done = K == 0 || nits >= max_iter;
+        if (!done && sp != pi) request(pi, ps);  // (a scanned row decided differently from its line)
+        if (build) tail_build(a, built, bd, eps, st);
+        stamp.light(6);
+        if (done) break;
+    }
+#ifdef MISSLAP_TAIL_STAMP
+    if (lane == 0) {
+        for (int k = 1; k <= 6; ++k) a.ctl->dbg[5 + k] += sacc[k];
+        a.ctl->dbg[15] += 1;
+    }
+#endif
+}
+
 // ---- solo mode: K <= 2 ---------------------------------------------------------------------------------------------
 // Wavefront 0 runs the rounds alone until the phase ends (K never grows), without barriers and without LDS.  The
 // reference's round is reproduced operation by operation: both bids use the prices of the previous round (records
@@ -206,10 +275,19 @@ __device__ __forceinline__ void tail_solo_mode(const TailArgs &a, const E &ed, i
     ps[0] = __builtin_amdgcn_readfirstlane(sStart[0]);
     pi[1] = K > 1 ? __builtin_amdgcn_readfirstlane(sU[1]) : -1;
     ps[1] = K > 1 ? __builtin_amdgcn_readfirstlane(sStart[1]) : 0;
+    if (K == 1) {
+        tail_chain_mode(a, ed, pi[0], ps[0], K, nits, max_iter, eps, st);
+        if (lane == 0) {
+            sU[0] = pi[0];
+            sU[1] = -1;
+            sStart[0] = ps[0];
+        }
+        return;
+    }
     TwoFetch<E> tf;
     tf.slot = cand_no_line();
     request_two(a, ed, pi[0], ps[0], pi[1], ps[1], tf);
-#ifdef MISSLAP_TAIL_STAMP
+#ifdef MISSLAP_TAIL_STAMP_SOLO
     // diagnostic build: cycles of wavefront 0 per segment of a solo round -> Ctl::dbg[6..11] (+ dbg[15] = rounds):
     // [6] wait for the line, [7] record gather, [8] winner known + next line requested, [9] rest of the line
     // evaluation, [10] full scans of missed persons, [11] resolve / stores / re-request / line rebuild
@@ -256,7 +334,7 @@ __device__ __forceinline__ void tail_solo_mode(const TailArgs &a, const E &ed, i
             pi[1] = -1;
         }
         K = (pi[0] != -1) + (pi[1] != -1);
-        const bool done = K == 0 || nits >= max_iter;
+        const bool done = K <= 1 || nits >= max_iter;
         // the early request assumed "both bidders win, nobody moves"; otherwise (a scanned row, a lost bid, the
         // end of a chain) request again
         if (!done && (sp[0] != pi[0] || sp[1] != pi[1])) request_two(a, ed, pi[0], ps[0], pi[1], ps[1], tf);
@@ -264,7 +342,8 @@ __device__ __forceinline__ void tail_solo_mode(const TailArgs &a, const E &ed, i
         stamp.light(6);
         if (done) break;
     }
-#ifdef MISSLAP_TAIL_STAMP
+    if (K == 1 && nits < max_iter) tail_chain_mode(a, ed, pi[0], ps[0], K, nits, max_iter, eps, st);
+#ifdef MISSLAP_TAIL_STAMP_SOLO
     if (lane == 0)
         for (int k = 1; k <= 6; ++k) a.ctl->dbg[5 + k] += sacc[k];
 #endif

@@ -112,7 +112,6 @@ struct misslap_solver {
     double *price = nullptr;
     PriceRec *rec = nullptr;
     int2 *cand = nullptr;  // candidate lines, 256 B per person (8 B/edge layout only)
-    bool warm_lines = true;  // stream the lines into the Infinity Cache before every tail launch
     int *p2o = nullptr, *o2p = nullptr, *U = nullptr;
     unsigned long long *bid_key = nullptr;
     int *bid_obj = nullptr;
@@ -397,9 +396,6 @@ int launch_tail(misslap_solver *h) {
         if (!pr) return fail(MISSLAP_ERR_HIP, "hipEventCreate failed");
         HIP_TRY(hipEventRecord(pr->start, h->stream));
     }
-    if (h->cand && h->warm_lines)
-        hipLaunchKernelGGL(k_warm_lines, dim3(kMaxGridBlocks), dim3(256), 0, h->stream,
-                           reinterpret_cast<const int4 *>(h->cand), (long long)h->n_rows * (kCandLanes / 2), h->nmatch);
     if (h->f32) {
         EdgesF32 ed{h->edges32};
         hipLaunchKernelGGL(k_tail<EdgesF32>, dim3(1), dim3(kTailMax), 0, h->stream, a, ed);
@@ -636,7 +632,6 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
         if ((rc = dev_alloc(&h->launch_edges, (size_t)h->launch_edges_cap))) return rc;
         HIP_TRY(hipMemsetAsync(h->launch_edges, 0, sizeof(unsigned long long) * h->launch_edges_cap, h->stream));
     }
-    h->warm_lines = opt->reserved[5] == 0;
     h->shard_min_K = h->tiled_ok ? h->tiled_min_K : (int)std::max<size_t>((N * 3) / 10, 8192);
     if (opt->reserved[3] > 0) h->shard_min_K = opt->reserved[3];
     if (opt->reserved[3] < 0) h->shard_min_K = 0;  // every grid round sharded + exchanged
@@ -1003,7 +998,7 @@ MISSLAP_API int misslap_finish(misslap_solver *h, int32_t *person_to_object_out,
     meta->shard_edges = c.shard_edges;
     for (int k = 0; k < 6; ++k) meta->reserved_d[k] = (double)c.dbg[k];  // tail: rounds / 10-ns ticks per mode
     for (int k = 0; k < 3; ++k) meta->reserved_d[6 + k] = (double)c.dbg[12 + k];  // tail: bids, line hits, builds
-#ifdef MISSLAP_TAIL_STAMP
+#if defined(MISSLAP_TAIL_STAMP) || defined(MISSLAP_TAIL_STAMP_SOLO)
     for (int k = 0; k < 6; ++k) meta->reserved_d[k] = (double)c.dbg[6 + k];  // diagnostic build: solo-round segments (cycles)
 #endif
     meta->cand_hits = c.cand_hits;
