@@ -27,25 +27,62 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); measured copy peak is ~6300
 
 
-def cpu_baseline(cfg, budget_rounds):
-    """Oracle (port of the reference, single thread like the reference) on the first `budget_rounds`
-    rounds of the workload."""
+def cpu_baseline(cfg, budget_rounds, whole):
+    """Oracle (port of the reference, single thread like the reference, faithful O(M) assignment walk) on the same
+    workload: the first `budget_rounds` rounds as the bounded sample, and -- `whole` -- the complete solve in the
+    same run (about 30-50 s at C3; the sample over-weights the big bandwidth-bound rounds of the first phase)."""
     from oracle import oracle as orc
     from sslap_amd import synth
     loc, val = synth.gen_config(cfg)
-    s = orc.from_sparse(loc, val, problem="max", max_iter=budget_rounds, cardinality_check=False)
+    s = orc.from_sparse(loc, val, problem="max", max_iter=10**8, cardinality_check=False)
     s.set_timing(True)
     t0 = time.perf_counter()
-    s.solve()
+    sample = None
+    rounds = 0
+    while True:
+        done = s.step()
+        rounds += 1
+        if rounds == budget_rounds or (done and sample is None):
+            m = s.raw_meta()  # (one O(nnz) pass for the eCE / objective fields: outside the clock)
+            t1 = time.perf_counter()
+            sample = (int(m.edges_scanned), t1 - t0, float(m.t_bid), rounds)
+            t0 += time.perf_counter() - t1
+            if not whole:
+                break
+        if done:
+            break
     dt = time.perf_counter() - t0
-    e = s.extra
-    return {
-        "value": round(e["edges_scanned"] / dt / 1e6, 2), "unit": "Medges/s", "cores": 1, "kind": "port",
-        "sample": f"first {budget_rounds} rounds of {cfg} (oracle/auction_oracle.c, faithful O(M) assignment "
-                  f"walk), {e['edges_scanned']} edges in {dt:.2f} s",
-        "bid_phase_only_medges_s": round(e["edges_scanned"] / max(e["t_bid"], 1e-9) / 1e6, 2),
+    e_s, dt_s, tbid_s, r_s = sample
+    out = {
+        "value": round(e_s / dt_s / 1e6, 2), "unit": "Medges/s", "cores": 1, "kind": "port",
+        "sample": f"first {r_s} rounds of {cfg} (oracle/auction_oracle.c, faithful O(M) assignment walk), "
+                  f"{e_s} edges in {dt_s:.2f} s",
+        "bid_phase_only_medges_s": round(e_s / max(tbid_s, 1e-9) / 1e6, 2),
         "host_cpu": _cpu_name(), "host_cores_available": os.cpu_count(),
     }
+    if whole:
+        m = s.raw_meta()
+        out.update(whole_solve_medges_s=round(int(m.edges_scanned) / dt / 1e6, 2), whole_solve_s=round(dt, 2),
+                   whole_solve_rounds=int(m.its), whole_solve_edges=int(m.edges_scanned))
+    return out
+
+
+def source_digest():
+    """sha256 over the kernel sources the library is built from: ties a committed PMC measurement to the code it was
+    taken on (the GPU box has no .git, so a commit hash alone could not be checked there)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "sslap_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+
+
+def gpu_tail_cand_edges(g):
+    """edges of rows answered by candidate lines inside the tail kernel (not part of the grid launches)"""
+    return int(g.get("tail_cand_edges", 0))
 
 
 def _cpu_name():
@@ -66,6 +103,7 @@ def main():
     ap.add_argument("--config", default="C3")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-rounds", type=int, default=100_000)
+    ap.add_argument("--cpu-sample-only", action="store_true", help="cpu_baseline: the bounded sample only")
     ap.add_argument("--tail-threshold", type=int, default=None)
     args = ap.parse_args()
 
@@ -178,14 +216,39 @@ def main():
         rk_ms, rk_edges, rk_launches = (til_ms, til_edges, til_launches) if tiled else (bid_ms, bid_edges, bid_launches)
         achieved = rk_edges * bpe / (rk_ms * 1e-3) / 1e9 if rk_ms > 0 else 0.0
         fs_achieved = fs_edges * bpe / (fs_ms * 1e-3) / 1e9 if fs_ms > 0 else 0.0
-        # HBM traffic of the roofline kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-        # on this same command, summarised by tools/pmc_summary.py with the gfx950 corrections)
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if tiled and os.path.exists(tpath):
-            tk = [v for k, v in json.load(open(tpath))["kernels"].items() if "k_bid_tiled" in k]
-            if tk:
-                traffic = round(tk[0]["read_avg"] + tk[0]["write_avg"])
+        # HBM traffic of the roofline kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on
+        # this same command, summarised by tools/pmc_summary.py with the gfx950 corrections).  The file names the
+        # kernel sources (sha256) and the commit it was measured on: any other code gets null, not a stale number.
+        traffic, traffic_meta = None, {}
+        tpath = os.path.join(ROOT, "profiles", f"r02_pmc_traffic_{args.config}.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            traffic_meta = dict(traffic_commit=tj.get("commit"), traffic_source_sha256=tj.get("source_sha256"),
+                                traffic_file=os.path.relpath(tpath, ROOT))
+            tk = [(k, v) for k, v in tj["kernels"].items() if rk_name in k and "merge" not in k]
+            if tk and tj.get("source_sha256") == source_digest():
+                traffic = round(tk[0][1]["read_avg"] + tk[0][1]["write_avg"])
+                traffic_meta["traffic_kernel"] = tk[0][0]
+            else:
+                traffic_meta["traffic_stale"] = True
+        # metric (ii) of SURVEY 8(d): throughput over ALL grid-kernel bid launches (full-scan engine + k_bid), from
+        # one extra, untimed solve with every bid launch bracketed by HIP events (profile level 3 costs host time,
+        # so it is kept out of the timed steps)
+        grid_all = None
+        if world == 1:
+            gpu_opts3 = dict(gpu_opts, profile=3)
+            s3 = AuctionSolver.from_device_pointers(d_loc.data_ptr(), d_val.data_ptr(), nnz, problem="max",
+                                                    max_iter=10**8, **gpu_opts3)
+            s3.solve()
+            g3 = s3.gpu
+            ms3 = g3["bid_ms"] + g3["tiled_ms"]
+            e3 = g3["bid_edges"] + g3["tiled_edges"]
+            grid_all = {"launches": g3["bid_launches"] + g3["tiled_launches"], "ms": round(ms3, 3), "edges": e3,
+                        "medges_s": round(e3 / (ms3 * 1e-3) / 1e6, 1) if ms3 else None,
+                        "GBs_algorithmic": round(e3 * bpe / (ms3 * 1e-3) / 1e9, 1) if ms3 else None,
+                        "edges_read": e3 - (g3["cand_edges"] - gpu_tail_cand_edges(g3)),
+                        "note": "one extra untimed solve, every bid launch timed (profile 3); edges = reference-"
+                                "equivalent row lengths of the bidders, edges_read = rows actually streamed"}
         out = {
             "metric": "Medges/s (bid-phase CSR nnz/s) + solve ms, N=200k d=0.1% sparse LAP",
             "value": round(edges_all / dt / 1e6, 2),
@@ -207,6 +270,10 @@ def main():
             "rounds": meta["its"], "eps_phases": meta["nreductions"] + 1,
             "grid_rounds": gpu["grid_rounds"], "tail_rounds": gpu["tail_rounds"],
             "edges_scanned_per_solve": gpu["edges_scanned"],
+            # reference-equivalent count (sum of the bidders' row lengths, the oracle's number); rows that a
+            # person's candidate line answered exactly are counted but not read:
+            "edges_read_per_solve": gpu["edges_scanned"] - gpu["cand_edges"],
+            "candidate_line_hit_rate": round(gpu["cand_hits"] / max(gpu["bids_made"], 1), 4),
             "sol_sha256": synth.sol_digest(sol), "obj_f64": gpu["obj_f64"],
             "bid_phase": {
                 "full_scan_kernel": rk_name,
@@ -225,6 +292,7 @@ def main():
                 # layout does not apply); its ~3000 small launches per solve are not bracketed by events
                 "k_bid_timed": {"launches": bid_launches, "ms": round(bid_ms, 3), "edges": bid_edges,
                                 "medges_s": round(bid_edges / (bid_ms * 1e-3) / 1e6, 1) if bid_ms else None},
+                "grid_all_launches": grid_all,
                 "k_tail": {"ms_per_solve": round(tail_ms / len(runs), 3), "rounds_per_solve": gpu["tail_rounds"],
                            "us_per_round": round(1e3 * tail_ms / len(runs) / max(gpu["tail_rounds"], 1), 3),
                            "medges_s": round(tail_edges / (tail_ms * 1e-3) / 1e6, 1) if tail_ms else None},
@@ -236,13 +304,15 @@ def main():
                 "algorithmic_bytes_per_edge": bpe,
                 "algorithmic_bytes_per_launch": round(rk_edges * bpe / max(rk_launches, 1)),
                 "traffic": traffic,
-                "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 PMC, bytes per launch, FETCH_SIZE x2 "
-                                  "gfx950 correction calibrated on known-size kernels)" if traffic else None,
+                "traffic_source": "rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction calibrated on known-size "
+                                  "kernels + WRITE_SIZE), bytes per launch" if traffic else None,
+                **traffic_meta,
             },
             "device": name.value.decode(), "compute_units": int(cus.value),
         }
         if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(args.config, args.cpu_rounds)
+            whole = not args.cpu_sample_only and args.config != "C5"  # (C5: ~20 min of oracle time)
+            out["cpu_baseline"] = cpu_baseline(args.config, args.cpu_rounds, whole)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

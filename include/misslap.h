@@ -54,7 +54,9 @@ typedef struct misslap_options {
                                 [2]: full-scan engine: 0 / 1 k_bid_tiled (default), 2 k_scan2d + k_merge2d (experimental);
                                 [3]: multi-GPU shard threshold: 0 = default (the full-scan threshold, 0.3 N), > 0 = minimum K
                                      of a sharded round, < 0 = shard every grid round;
-                                [4]: 1 = no candidate lines (every bid scans its whole row; A/B timing, parity tests) */
+                                [4]: 1 = no candidate lines (every bid scans its whole row; A/B timing, parity tests);
+                                [6]: > 0 lowers the entry limit of a handle (default 2^31 - 1: int32 row pointers), for
+                                     tests of that guard */
 } misslap_options;
 
 /* Result block of misslap_finish: the reference's `meta` dict (auction_.pyx:264,:297-304)
@@ -103,7 +105,9 @@ typedef struct misslap_meta {
     uint64_t cand_hits;          /* bids answered from the person's candidate line (exactly the same bid, no row scan) */
     uint64_t cand_edges;         /* edges of those bidders' rows: part of edges_scanned (reference-equivalent count),
                                     never read from memory */
-    double reserved_d[9];
+    double tail_stats[12];       /* tail kernel accounting: [0..2] rounds in chain+solo / team / block mode, [3..5] their
+                                    duration in 10-ns ticks, [6] bids, [7] bids answered by candidate lines, [8] line
+                                    (re)builds, [9] edges of the rows those lines answered, [10..11] reserved */
 } misslap_meta;
 
 /* Snapshot of the round state (tests / multi-GPU driver). */
@@ -136,7 +140,11 @@ int misslap_create(misslap_solver **out, int64_t nnz, const int32_t *loc, const 
  * mat: double[n_rows][n_cols] on the host; entries < 0 (and NaN) are invalid.  The scan / stream
  * compaction runs on the GPU.  *nnz_out receives the number of valid entries (for the
  * "Fewer than N valid values" guard of :559 the caller compares it with n_rows BEFORE solving;
- * create fails with MISSLAP_ERR_INVALID when a row is empty). */
+ * create fails with MISSLAP_ERR_INVALID when a row is empty, or when the matrix holds 2^31 - 1 or more valid
+ * entries -- they are counted in 64 bits on the device, *nnz_out is exact).
+ * options.input_on_device: `mat` (here) / `loc`, `val` (misslap_create) are device pointers.  The library then
+ * waits for the whole device (hipDeviceSynchronize) before reading them, so buffers still being produced on any
+ * stream of the caller are safe to pass. */
 int misslap_create_dense(misslap_solver **out, int64_t n_rows, int64_t n_cols, const double *mat,
                          const misslap_options *opt, int64_t *nnz_out);
 
@@ -190,10 +198,6 @@ int misslap_get_state(misslap_solver *h, double *prices, int32_t *unassigned, in
 /* Device properties of the GPU the handle runs on (name buffer >= 128 bytes). */
 int misslap_device_info(int32_t device, char *name, int32_t name_len, int32_t *compute_units,
                         int64_t *hbm_bytes);
-
-/* Diagnostics only: average duration (ms) of `reps` launches of an ablated full-scan bid kernel
- * (mode 0 complete, 1 no price gather, 2 no cross-lane reduction, 3 edge stream only); results discarded. */
-int misslap_debug_time_bid(misslap_solver *h, int32_t mode, int32_t reps, float *ms_avg);
 
 /* Feasibility guard of the front-end: maximum bipartite matching (Hopcroft-Karp) on the host, the reference's
  * c_hopcroft_solve / sslap.hopcroft_solve (feasibility_.pyx:95-283; called at auction_.pyx:562-566, :608-612).

@@ -48,16 +48,6 @@ typedef struct oracle_solver {
     uint64_t edges_scanned, bids_made;
     double t_bid, t_total;
     int time_phases;
-    /* optional trace of the bidders of small rounds (analysis tooling, tools/tail_reuse.py) */
-    int32_t *trace_buf;
-    int64_t trace_cap, trace_len;
-    int trace_thr;
-    /* analysis only (tools/cache_sim.py): would an exact per-person top-C candidate cache have answered this bid? */
-    int sim_C, sim_thr;
-    int *sim_col;
-    double *sim_cost, *sim_tau;
-    unsigned char *sim_valid;
-    int64_t sim_hit, sim_miss, sim_bad;
 } oracle_solver;
 
 static double now_s(void) {
@@ -183,10 +173,6 @@ static void bid_and_assign(oracle_solver *s) {
     int *person_to_object = s->person_to_object, *object_to_person = s->object_to_person;
     const double eps = (double)s->eps; /* float promoted in ':360' */
 
-    if (s->trace_buf && (int)num_bidders <= s->trace_thr && s->trace_len + (int64_t)num_bidders + 1 <= s->trace_cap) {
-        for (size_t n = 0; n < num_bidders; ++n) s->trace_buf[s->trace_len++] = unassigned_people[n];
-        s->trace_buf[s->trace_len++] = -1; /* round separator */
-    }
     double t0 = s->time_phases ? now_s() : 0.0;
     /* BIDDING PHASE :339-365 */
     for (size_t nbidder = 0; nbidder < num_bidders; ++nbidder) {
@@ -207,44 +193,6 @@ static void bid_and_assign(oracle_solver *s) {
                 costbest = cost;
             } else if (vi > wi) {
                 wi = vi;
-            }
-        }
-        if (s->sim_C > 0 && (int)num_bidders <= s->sim_thr) { /* analysis hook, changes nothing */
-            const int C = s->sim_C;
-            int hit = 0;
-            if (s->sim_valid[i]) {
-                double vc = -INFINITY, wc = -INFINITY;
-                for (int k = 0; k < C; ++k) {
-                    int j = s->sim_col[(size_t)i * C + k];
-                    if (j < 0) continue;
-                    double v = s->sim_cost[(size_t)i * C + k] - p[j];
-                    if (v >= vc) { wc = vc; vc = v; } else if (v > wc) wc = v;
-                }
-                const double tau = s->sim_tau[i];
-                if (vc > tau && wc >= tau) {
-                    hit = 1;
-                    if (vc != vbest || wc != wi) s->sim_bad += 1;
-                }
-            }
-            if (hit) s->sim_hit += 1;
-            else { /* rebuild: the C largest current values + the (C+1)-th as bound */
-                s->sim_miss += 1;
-                double topv[64]; int topk[64]; int nt = 0;
-                for (size_t idx = 0; idx < num_objects; ++idx) {
-                    double v = val[start + idx] - p[flat_j[start + idx]];
-                    int pos;
-                    if (nt < C + 1) pos = nt++;
-                    else if (v <= topv[C]) continue;
-                    else pos = C;
-                    while (pos > 0 && topv[pos - 1] < v) { topv[pos] = topv[pos - 1]; topk[pos] = topk[pos - 1]; --pos; }
-                    topv[pos] = v; topk[pos] = (int)idx;
-                }
-                for (int k = 0; k < C; ++k) {
-                    if (k < nt && k < C) { s->sim_col[(size_t)i * C + k] = flat_j[start + topk[k]]; s->sim_cost[(size_t)i * C + k] = val[start + topk[k]]; }
-                    else s->sim_col[(size_t)i * C + k] = -1;
-                }
-                s->sim_tau[i] = nt > C ? topv[C] : -INFINITY;
-                s->sim_valid[i] = 1;
             }
         }
         double bbest = costbest - wi + eps; /* :360 (left-to-right) */
@@ -421,29 +369,6 @@ ORACLE_API void oracle_get_meta(const oracle_solver *s, oracle_meta *m) {
 }
 
 ORACLE_API void oracle_set_timing(oracle_solver *s, int on) { s->time_phases = on; }
-ORACLE_API void oracle_set_trace(oracle_solver *s, int32_t *buf, int64_t cap, int thr) {
-    s->trace_buf = buf;
-    s->trace_cap = cap;
-    s->trace_len = 0;
-    s->trace_thr = thr;
-}
-ORACLE_API int64_t oracle_trace_len(const oracle_solver *s) { return s->trace_len; }
-
-/* analysis only: simulate an exact top-C candidate cache for the bids of rounds with K <= thr (C <= 62) */
-ORACLE_API void oracle_set_cache_sim(oracle_solver *s, int C, int thr) {
-    s->sim_C = C;
-    s->sim_thr = thr;
-    s->sim_col = (int *)malloc(sizeof(int) * (size_t)s->num_rows * C);
-    s->sim_cost = (double *)malloc(sizeof(double) * (size_t)s->num_rows * C);
-    s->sim_tau = (double *)malloc(sizeof(double) * (size_t)s->num_rows);
-    s->sim_valid = (unsigned char *)calloc((size_t)s->num_rows, 1);
-    s->sim_hit = s->sim_miss = s->sim_bad = 0;
-}
-ORACLE_API void oracle_get_cache_sim(const oracle_solver *s, int64_t *hit, int64_t *miss, int64_t *bad) {
-    *hit = s->sim_hit;
-    *miss = s->sim_miss;
-    *bad = s->sim_bad;
-}
 ORACLE_API const int *oracle_person_to_object(const oracle_solver *s) { return s->person_to_object; }
 ORACLE_API const int *oracle_object_to_person(const oracle_solver *s) { return s->object_to_person; }
 ORACLE_API const double *oracle_prices(const oracle_solver *s) { return s->p; }

@@ -36,7 +36,7 @@ class Meta(C.Structure):
         ("tiled_active", C.c_int32), ("tiled_min_K", C.c_int32),
         ("merge_launches", C.c_int64), ("merge_ms", C.c_double),
         ("shard_edges", C.c_uint64), ("cand_hits", C.c_uint64), ("cand_edges", C.c_uint64),
-        ("reserved_d", C.c_double * 9),
+        ("tail_stats", C.c_double * 12),
     ]
 
 
@@ -70,13 +70,37 @@ SYMBOLS = {
     "misslap_set_stream": (C.c_int, [_VP, _VP]),
     "misslap_get_state": (C.c_int, [_VP, _VP, _VP, _VP, _VP]),
     "misslap_device_info": (C.c_int, [C.c_int32, C.c_char_p, C.c_int32, _I32P, C.POINTER(C.c_int64)]),
-    "misslap_debug_time_bid": (C.c_int, [_VP, C.c_int32, C.c_int32, C.POINTER(C.c_float)]),
     "misslap_hopcroft_karp": (C.c_int, [_VP, C.c_int64, C.c_int32, C.c_int32, _I32P, _VP, _VP]),
     "misslap_last_error": (C.c_char_p, []),
     "misslap_abi_version": (C.c_int, []),
 }
 
 _LIB = None
+
+
+def _preload_hip_runtime():
+    """One HIP runtime per process, whatever the import order.
+
+    libmisslap.so names its runtime by SONAME (libamdhip64.so.7) and the dynamic linker binds that to a copy the
+    process has ALREADY loaded.  A PyTorch-ROCm wheel ships a private copy and loads it by path, so "libmisslap
+    first, torch later" would end with two runtimes, the second of which cannot open the GPU (measured on the GPU
+    box: torch then reports "No HIP GPUs are available").  Therefore: if a torch wheel with a bundled runtime is
+    INSTALLED, its copy is loaded here by path -- torch itself is not imported -- and both libmisslap.so and a later
+    `import torch` bind to it; without torch the system ROCm runtime is used.  Covered in both orders by
+    tests/test_gpu_parity.py::test_hip_runtime_is_shared_in_either_import_order."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return  # torch's runtime is already in the process
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    for d in (spec.submodule_search_locations if spec and spec.submodule_search_locations else ()):
+        cand = os.path.join(d, "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            return
 
 
 def load():
@@ -87,14 +111,7 @@ def load():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -m sslap_amd.build` "
                 "(hipcc --offload-arch=gfx950).  sslap_amd has no CPU fallback.")
-        try:
-            # One HIP runtime per process: the PyTorch-ROCm wheel bundles its own libamdhip64.so.7 /
-            # libhsa-runtime64 and a second copy (the system one libmisslap would otherwise pull in)
-            # cannot open the GPU again.  Importing torch first makes the dynamic linker resolve
-            # libmisslap's libamdhip64.so.7 dependency to the copy torch already loaded.
-            import torch  # noqa: F401
-        except ImportError:
-            pass
+        _preload_hip_runtime()
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             f = getattr(lib, name)
@@ -103,6 +120,18 @@ def load():
             raise RuntimeError("libmisslap.so ABI version mismatch")
         _LIB = lib
     return _LIB
+
+
+def load_diag():
+    """The diagnostics build (libmisslap_diag.so, include/misslap_diag.h): tools/ only.  Select it for the whole
+    process with MISSLAP_LIB=<path> BEFORE the first load(); this only binds the extra entry point."""
+    lib = load()
+    if not hasattr(lib, "misslap_debug_time_bid"):
+        raise RuntimeError("not a diagnostics build: run `python -m sslap_amd.build diag` and set "
+                           "MISSLAP_LIB=sslap_amd/libmisslap_diag.so")
+    f = lib.misslap_debug_time_bid
+    f.restype, f.argtypes = C.c_int, [_VP, C.c_int32, C.c_int32, C.POINTER(C.c_float)]
+    return lib
 
 
 def check(rc):

@@ -27,7 +27,7 @@ _ENV_TILED = "MISSLAP_TILED_MIN_K"  # 0 default, < 0 never use the LDS-tiled bid
 
 def _options(problem, eps_start, max_iter, device=None, tail_threshold=None, profile=None, force_f64=False,
              input_on_device=False, shard=None, rounds_per_sync=None, tiled_min_k=None, tiled_shape=None, shard_min_k=None,
-             engine=None, cand=None):
+             engine=None, cand=None, nnz_limit=None):
     if problem not in ("min", "max"):
         # the reference treats every string other than 'min' as 'max' (auction_.pyx:236, :502)
         problem = "max" if problem != "min" else "min"
@@ -50,6 +50,7 @@ def _options(problem, eps_start, max_iter, device=None, tail_threshold=None, pro
     o.reserved[3] = int(os.environ.get("MISSLAP_SHARD_MIN_K", 0)) if shard_min_k is None else int(shard_min_k)
     # candidate lines (per-person exact bid shortcut, csrc/device_common.hpp): on by default, 0 = off (A/B runs)
     o.reserved[4] = (1 - int(os.environ.get("MISSLAP_CAND", 1))) if cand is None else (0 if cand else 1)
+    o.reserved[6] = 0 if nnz_limit is None else int(nnz_limit)  # tests of the int32 row-pointer guard
     return o
 
 
@@ -171,11 +172,12 @@ class AuctionSolver:
                  start_eps_f32=float(m.start_eps), tail_edges=int(m.tail_edges), shard_edges=int(m.shard_edges),
                  tiled_active=int(m.tiled_active), tiled_min_K=int(m.tiled_min_K),
                  cand_hits=int(m.cand_hits), cand_edges=int(m.cand_edges))
-        d = [float(x) for x in m.reserved_d]
+        d = [float(x) for x in m.tail_stats]
         g["tail_modes"] = {name: dict(rounds=int(d[k]), ms=round(d[3 + k] * 1e-5, 3),
                                       us_per_round=round(d[3 + k] * 1e-2 / d[k], 3) if d[k] else None)
                            for k, name in enumerate(("solo", "team", "block"))}
         g["tail_cand"] = dict(bids=int(d[6]), hits=int(d[7]), builds=int(d[8]))
+        g["tail_cand_edges"] = int(d[9])
         g["tail_raw"] = d[:6]  # (diagnostic MISSLAP_TAIL_STAMP builds: cycles per segment of a solo round)
         if m.profiled:
             g.update(bid_launches=int(m.bid_launches), bid_ms=float(m.bid_ms), bid_edges=int(m.bid_edges),

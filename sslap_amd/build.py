@@ -6,6 +6,7 @@ import subprocess
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libmisslap.so")
+LIB_DIAG = os.path.join(PKG, "libmisslap_diag.so")  # diagnostics build (-DMISSLAP_DIAG), tools/ only
 SOURCES = ["misslap.hip", "device_common.hpp", "kernels_round.hpp", "kernels_tail.hpp", "kernels_check.hpp", "kernels_debug.hpp", "kernels_tiled.hpp", "kernels_scan2d.hpp",
            "kernels_ingest.hpp", "host_matching.hpp", os.path.join("..", "..", "include", "misslap.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-honor-nans", "-std=c++17", "-shared", "-fPIC",
@@ -36,5 +37,15 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_diag(verbose=False):
+    """The same sources with -DMISSLAP_DIAG (ablation kernels + misslap_debug_time_bid, include/misslap_diag.h)."""
+    cmd = [hipcc()] + FLAGS + ["-DMISSLAP_DIAG", os.path.join(CSRC, "misslap.hip"), "-o", LIB_DIAG]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    return LIB_DIAG
+
+
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+    print(build_diag(verbose=True) if "diag" in sys.argv[1:] else build(force=True, verbose=True))

@@ -31,6 +31,7 @@ constexpr int kErrRowGap = 4;        // a row index is missing (empty row)
 constexpr int kErrNonFinite = 8;     // NaN / inf among the values
 constexpr int kErrColNegative = 16;  // negative row / column index
 constexpr int kErrLdsBase = 32;      // k_bid_tiled: the price buffers do not start at LDS address 0
+constexpr int kErrTooMany = 64;      // dense ingest: more valid entries than int32 row pointers can address
 
 // Device-resident control block: the scalar part of the reference's solver state.
 struct Ctl {
@@ -120,6 +121,19 @@ __device__ __forceinline__ unsigned long long bid_to_key(double bid) {
 }
 __device__ __forceinline__ double key_to_bid(unsigned long long key) {
     return __longlong_as_double((long long)(key - 1ull));
+}
+
+// Classification by bit pattern: the library is built with -fno-honor-nans, so a floating-point comparison must
+// never be what decides whether a NaN is present.
+// "v >= 0" of the reference's dense scan (auction_.pyx:549): +0 .. +inf and -0; false for negatives and every NaN
+__device__ __forceinline__ bool dense_entry_valid(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return b <= 0x7ff0000000000000ull || b == 0x8000000000000000ull;
+}
+// a bid that would break the bits-as-integer ordering of bid keys: negative (sign bit set) or NaN
+__device__ __forceinline__ bool bid_is_bad(double bid) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(bid);
+    return b > 0x7ff0000000000000ull;
 }
 
 __device__ __forceinline__ double shfl_xor_f64(double v, int off) {
@@ -282,7 +296,7 @@ __device__ __forceinline__ void wave_bid(const E &ed, const double *price, int s
     const double cost = readlane_f64(a1, src);
     stamp(4);
     const double bid = (cost - W) + eps;  // bbest = costbest - wi + eps   (:360)
-    if (!(bid >= 0.0)) err |= kErrNegativeBid;
+    if (bid_is_bad(bid)) err |= kErrNegativeBid;
     key = bid_to_key(bid);
     obj = col;
 }
@@ -423,7 +437,7 @@ __device__ __forceinline__ void wave_bid_rec(const E &ed, const PriceRec *rec, i
     const double cost = readlane_f64(a1, src);
     stamp(4);
     const double bid = (cost - W) + eps;  // bbest = costbest - wi + eps   (:360)
-    if (!(bid >= 0.0)) err |= kErrNegativeBid;
+    if (bid_is_bad(bid)) err |= kErrNegativeBid;
     key = bid_to_key(bid);
     obj = col;
 }
@@ -577,7 +591,7 @@ __device__ __forceinline__ void cand_eval2(int2 &slot, const bool act0, const bo
     for (int X = 0; X < 2; ++X) {
         out[X].hit = (G[X] >= 0) & (V[X] > tau[X]) & (W[X] >= tau[X]);
         const double bid = (c1[X] - W[X]) + eps;  // bbest = costbest - wi + eps   (:360)
-        if (out[X].hit && !(bid >= 0.0)) err |= kErrNegativeBid;
+        if (out[X].hit && bid_is_bad(bid)) err |= kErrNegativeBid;
         out[X].key = bid_to_key(bid);
     }
 }
@@ -620,7 +634,7 @@ __device__ __forceinline__ void cand_eval1(int2 &slot, const bool cls, const Src
     const double W = readlane_f64(half_max_f64(lane == G ? ninf : v), 31);  // second best, counting multiplicity
     out.hit = (G >= 0) & (V > tau) & (W >= tau);
     const double bid = (c1 - W) + eps;  // bbest = costbest - wi + eps   (:360)
-    if (out.hit && !(bid >= 0.0)) err |= kErrNegativeBid;
+    if (out.hit && bid_is_bad(bid)) err |= kErrNegativeBid;
     out.key = bid_to_key(bid);
 }
 struct NoEarly {
@@ -791,7 +805,7 @@ __device__ __forceinline__ void wave_bid_full(const E &ed, const Src &src, int s
     out.len = e - s;
     const double cost = readlane_f64(a1, sl);
     const double bid = (cost - W) + eps;  // bbest = costbest - wi + eps   (:360)
-    if (!(bid >= 0.0)) err |= kErrNegativeBid;
+    if (bid_is_bad(bid)) err |= kErrNegativeBid;
     out.key = bid_to_key(bid);
     ba.want = E::kCand && e - s <= kCandRowMax;
     ba.len = e - s;

@@ -12,6 +12,7 @@ struct IngestStats {
     int err;          // kErr* bits
     int not_f32;      // some value is not exactly representable in fp32
     int pad;
+    long long dense_total;  // dense ingest: number of valid entries, counted in 64 bits
 };
 
 // cumulative_idxs (auction_.pyx:33-48) for the valid input class (rows ascending, no gaps): row_ptr[r] =
@@ -23,7 +24,10 @@ __global__ __launch_bounds__(256) void k_ingest_rows(const int *loc, long long n
     for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < nnz; g += stride) {
         const int r = loc[2 * g], c = loc[2 * g + 1];
         const int rp = g ? loc[2 * (g - 1)] : -1;
-        if (r < 0 || c < 0) err |= kErrColNegative;
+        if (r < 0 || c < 0) {  // malformed entry: reported, and nothing is derived from it (no row_ptr[-1] store)
+            err |= kErrColNegative;
+            continue;
+        }
         if (r < rp) err |= kErrRowsUnsorted;
         else if (r > rp) {
             if (r != rp + 1 || r >= n_rows) err |= kErrRowGap;
@@ -146,7 +150,7 @@ __global__ __launch_bounds__(256) void k_dense_count(const double *mat, int n_ro
     for (int r = blockIdx.x * 4 + wave; r < n_rows; r += gridDim.x * 4) {
         int cnt = 0;
         const double *row = mat + (size_t)r * n_cols;
-        for (int c = lane; c < n_cols; c += kWave) cnt += (row[c] >= 0);
+        for (int c = lane; c < n_cols; c += kWave) cnt += dense_entry_valid(row[c]);
         for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off);
         if (lane == 0) row_cnt[r] = cnt;
     }
@@ -156,7 +160,7 @@ __global__ __launch_bounds__(256) void k_dense_count(const double *mat, int n_ro
 __global__ __launch_bounds__(1024) void k_dense_scan(const int *row_cnt, int n_rows, int *row_ptr,
                                                      IngestStats *st) {
     __shared__ int s_w[16];
-    __shared__ int s_carry;
+    __shared__ long long s_carry;  // 64 bits: a dense input can hold more valid entries than an int32 can count
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     if (t == 0) s_carry = 0;
     __syncthreads();
@@ -174,13 +178,17 @@ __global__ __launch_bounds__(1024) void k_dense_scan(const int *row_cnt, int n_r
         __syncthreads();
         int wpre = 0;
         for (int w2 = 0; w2 < wave; ++w2) wpre += s_w[w2];
-        const int carry = s_carry;
-        if (i < n_rows) row_ptr[i] = carry + wpre + x - v;
+        const long long carry = s_carry;
+        if (i < n_rows) row_ptr[i] = (int)(carry + wpre + x - v);  // (garbage beyond 2^31: the host rejects the input)
         __syncthreads();
         if (t == 1023) s_carry = carry + wpre + x;
         __syncthreads();
     }
-    if (t == 0) row_ptr[n_rows] = s_carry;
+    if (t == 0) {
+        row_ptr[n_rows] = (int)s_carry;
+        st->dense_total = s_carry;
+        if (s_carry >= 0x7fffffffLL) atomicOr(&st->err, kErrTooMany);
+    }
     if (empty) atomicOr(&st->err, kErrRowGap);
 }
 // pass 3: ordered compaction of each row into (loc, val) COO, the reference's scan order
@@ -193,7 +201,8 @@ __global__ __launch_bounds__(256) void k_dense_fill(const double *mat, int n_row
         for (int base = 0; base < n_cols; base += kWave) {
             const int c = base + lane;
             const double v = (c < n_cols) ? row[c] : -1.0;
-            const bool ok = v >= 0;  // :549 (NaN fails the test like in the reference)
+            const bool ok = dense_entry_valid(v);  // :549 (NaN fails the test like in the reference); the same
+                                                   // predicate as k_dense_count, or the fill overruns its segment
             const unsigned long long b = __ballot(ok);
             if (ok) {
                 const long long o = out + __popcll(b & lanemask_lt());

@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void k_merge2d(RoundArgs a, Scan2dArgs sa) {
         }
         const int2 best = sa.tiled[G];  // every row has at least one entry
         const double bid = ((double)__int_as_float(best.y) - W) + eps;  // :360
-        if (!(bid >= 0.0)) err |= kErrNegativeBid;
+        if (bid_is_bad(bid)) err |= kErrNegativeBid;
         const unsigned long long key = bid_to_key(bid);
         a.bid_key[n] = key;
         a.bid_obj[n] = best.x;

@@ -251,7 +251,6 @@ __device__ __forceinline__ void tail_chain_mode(const TailArgs &a, const E &ed, 
 #ifdef MISSLAP_TAIL_STAMP
     if (lane == 0) {
         for (int k = 1; k <= 6; ++k) a.ctl->dbg[5 + k] += sacc[k];
-        a.ctl->dbg[15] += 1;
     }
 #endif
 }
@@ -512,19 +511,15 @@ __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
     __syncthreads();
 
     // per-mode accounting (always on: two s_memrealtime reads per mode entry, 100 MHz ticks), Ctl::dbg:
-    //   [0..2] rounds in solo / team / block mode, [3..5] ticks, [6..8] bids, [9..11] line hits (wavefront 0's own)
-    unsigned long long md[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    //   [0..2] rounds in chain + solo / team / block mode, [3..5] ticks
+    unsigned long long md[6] = {0, 0, 0, 0, 0, 0};
     auto mode_begin = [&](int m) {
         md[3 + m] -= __builtin_amdgcn_s_memrealtime();
         md[m] -= (unsigned long long)nits;
-        md[6 + m] -= st.bids;
-        md[9 + m] -= st.hits;
     };
     auto mode_end = [&](int m) {
         md[3 + m] += __builtin_amdgcn_s_memrealtime();
         md[m] += (unsigned long long)nits;
-        md[6 + m] += st.bids;
-        md[9 + m] += st.hits;
     };
     for (;;) {
         if (K <= 2) {
@@ -748,7 +743,7 @@ __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
         if (K == 0 || nits >= max_iter) break;
     }
     if (t == 0)
-        for (int k = 0; k < 12; ++k) ctl->dbg[k] += md[k];
+        for (int k = 0; k < 6; ++k) ctl->dbg[k] += md[k];
 
     if (t < K0) a.U[t] = sU[t];
     if (lane == 0) {
@@ -763,6 +758,7 @@ __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
             atomicAdd(&ctl->dbg[12], st.bids);  // the tail's own totals: bids, line hits, line builds
             atomicAdd(&ctl->dbg[13], st.hits);
             atomicAdd(&ctl->dbg[14], st.builds);
+            atomicAdd(&ctl->dbg[15], st.hit_edges);
         }
         if (st.err) atomicOr(&ctl->err, st.err);
     }

@@ -618,7 +618,7 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
         if (mine[j]) {
             const double cost = (double)__int_as_float(best[j].y);
             const double bid = (cost - W[j]) + eps;  // :360
-            if (!(bid >= 0.0)) err |= kErrNegativeBid;
+            if (bid_is_bad(bid)) err |= kErrNegativeBid;
             const unsigned long long key = bid_to_key(bid);
             const int pos = p0 + j * kTileGroups + group;
             a.bid_key[pos] = key;

@@ -20,7 +20,10 @@
 #include "../../include/misslap.h"
 #include "device_common.hpp"
 #include "kernels_check.hpp"
+#ifdef MISSLAP_DIAG
+#include "../../include/misslap_diag.h"
 #include "kernels_debug.hpp"
+#endif
 #include "kernels_ingest.hpp"
 #include "kernels_round.hpp"
 #include "kernels_tail.hpp"
@@ -167,6 +170,24 @@ int dev_alloc(T **p, size_t n) {
     HIP_TRY(hipMalloc((void **)p, (n ? n : 1) * sizeof(T)));
     return MISSLAP_OK;
 }
+
+// Device temporaries of a constructor: freed when the scope is left, on every path.
+struct DevScratch {
+    std::vector<void *> ptrs;
+    DevScratch() = default;
+    DevScratch(const DevScratch &) = delete;
+    DevScratch &operator=(const DevScratch &) = delete;
+    ~DevScratch() {
+        for (void *p : ptrs)
+            if (p) (void)hipFree(p);
+    }
+    template <class T>
+    int alloc(T **p, size_t n) {
+        const int rc = dev_alloc(p, n);
+        if (rc == MISSLAP_OK) ptrs.push_back(*p);
+        return rc;
+    }
+};
 
 RoundArgs round_args(misslap_solver *h) {
     RoundArgs a;
@@ -462,8 +483,9 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
     if (last_row < 0) return fail(MISSLAP_ERR_INVALID, "negative row index");
     h->n_rows = last_row + 1;  // auction_.pyx:209 (rows are ascending, so the last one is the maximum)
     int rc;
+    DevScratch tmp;  // every temporary below: released on every return path
     IngestStats *d_st = nullptr;
-    if ((rc = dev_alloc(&d_st, 1))) return rc;
+    if ((rc = tmp.alloc(&d_st, 1))) return rc;
     HIP_TRY(hipMemsetAsync(d_st, 0, sizeof(IngestStats), h->stream));
     {
         const int init = -1;
@@ -478,7 +500,6 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
     IngestStats st;
     HIP_TRY(hipMemcpyAsync(&st, d_st, sizeof(st), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    (void)hipFree(d_st);
     if (st.err & kErrColNegative) return fail(MISSLAP_ERR_INVALID, "loc holds a negative row or column index");
     if (st.err & kErrRowsUnsorted)
         return fail(MISSLAP_ERR_INVALID, "loc rows must be sorted in ascending order (auction_.pyx:33-48 contract)");
@@ -486,6 +507,7 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
         return fail(MISSLAP_ERR_INVALID,
                     "every row 0..N-1 must have at least one entry (auction_.pyx:33-48 contract)");
     if (st.err & kErrNonFinite) return fail(MISSLAP_ERR_INVALID, "val holds a NaN or an infinity");
+    if (st.max_col >= 0x7ffffffe) return fail(MISSLAP_ERR_INVALID, "column index too large (max + 1 must fit an int32)");
     h->n_cols = st.max_col + 1;  // auction_.pyx:210
     if (h->thr < 0)  // library default, resolved now that the number of objects is known
         h->thr = (long long)h->n_cols > kTailBigCols ? kDefaultTailThresholdBig : kDefaultTailThreshold;
@@ -531,12 +553,12 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
             h->T = T;
             const int nchunks = (int)((L + kScanChunk - 1) / kScanChunk);
             int *cnt = nullptr, *len = nullptr, *lrel = nullptr, *start = nullptr, *sums = nullptr, *flag = nullptr;
-            if ((rc = dev_alloc(&cnt, (size_t)L))) return rc;
-            if ((rc = dev_alloc(&len, (size_t)L))) return rc;
-            if ((rc = dev_alloc(&lrel, (size_t)L))) return rc;
-            if ((rc = dev_alloc(&start, (size_t)L + 1))) return rc;
-            if ((rc = dev_alloc(&sums, (size_t)nchunks + 1))) return rc;
-            if ((rc = dev_alloc(&flag, 1))) return rc;
+            if ((rc = tmp.alloc(&cnt, (size_t)L))) return rc;
+            if ((rc = tmp.alloc(&len, (size_t)L))) return rc;
+            if ((rc = tmp.alloc(&lrel, (size_t)L))) return rc;
+            if ((rc = tmp.alloc(&start, (size_t)L + 1))) return rc;
+            if ((rc = tmp.alloc(&sums, (size_t)nchunks + 1))) return rc;
+            if ((rc = tmp.alloc(&flag, 1))) return rc;
             HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)L, h->stream));
             HIP_TRY(hipMemsetAsync(len, 0, sizeof(int) * (size_t)L, h->stream));
             HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), h->stream));
@@ -590,22 +612,20 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
                     if ((rc = dev_alloc(&h->part_g, (size_t)C2 * N))) return rc;
                     HIP_TRY(hipFuncSetAttribute((const void *)k_scan2d<1024, 3, 4>, at, (cols2 + 2) * (int)sizeof(double)));
                 } else {
-                    static bool attr_set = false;
-                    if (!attr_set) {
-#define X(I, TH, R, B, D, TC, LD, GL) \
-    HIP_TRY(hipFuncSetAttribute((const void *)k_bid_tiled<TH, R, B, D, TC, LD, 0, GL>, at, (int)tiled_lds_bytes(TC)));
+                    // per create, i.e. per device: the > 64 KB dynamic-LDS opt-in is a property of the function ON
+                    // the current device, so a process-wide "done" flag would leave a second device without it
+                    switch (h->tiled_shape) {
+#define X(I, TH, R, B, D, TC, LD, GL)                                                                               \
+    case I:                                                                                                          \
+        HIP_TRY(hipFuncSetAttribute((const void *)k_bid_tiled<TH, R, B, D, TC, LD, 0, GL>, at,                     \
+                                    (int)tiled_lds_bytes(TC)));                                                      \
+        break;
                         MISSLAP_FOR_TILED_SHAPES(X)
 #undef X
-                        attr_set = true;
                     }
                 }
             }
-            (void)hipFree(cnt);
-            (void)hipFree(len);
-            (void)hipFree(lrel);
-            (void)hipFree(start);
-            (void)hipFree(sums);
-            (void)hipFree(flag);
+            HIP_TRY(hipStreamSynchronize(h->stream));  // the temporaries are released at scope exit
         }
     }
     if ((rc = dev_alloc(&h->price, Mpad))) return rc;
@@ -656,6 +676,18 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
     h->K_exact = true;
     h->phase_fresh = true;
     HIP_TRY(hipStreamSynchronize(h->stream));
+    return MISSLAP_OK;
+}
+
+// entries a handle can hold: row pointers are int32 (options.reserved[6] > 0 lowers the limit: guard tests)
+int64_t nnz_limit(const misslap_options *opt) {
+    return opt->reserved[6] > 0 ? (int64_t)opt->reserved[6] : (int64_t)0x7fffffff;
+}
+
+// Device-resident inputs: the library works on a private non-blocking stream, which is not ordered behind the
+// stream(s) that produced the caller's buffers.  Wait for the whole device once, before anything reads them.
+int sync_device_inputs(const misslap_options *opt) {
+    if (opt->input_on_device) HIP_TRY(hipDeviceSynchronize());
     return MISSLAP_OK;
 }
 
@@ -736,11 +768,16 @@ MISSLAP_API int misslap_create(misslap_solver **out, int64_t nnz, const int32_t 
     const double t0 = now_ms();
     if (!loc || !val) return fail(MISSLAP_ERR_INVALID, "null loc / val");
     if (nnz <= 0) return fail(MISSLAP_ERR_INVALID, "empty problem (nnz = %lld)", (long long)nnz);
-    if (nnz >= (int64_t)0x7fffffff) return fail(MISSLAP_ERR_INVALID, "nnz must be < 2^31 (int32 row pointers)");
+    if (opt && nnz >= nnz_limit(opt))
+        return fail(MISSLAP_ERR_INVALID, "nnz must be < %lld (int32 row pointers)", (long long)nnz_limit(opt));
     misslap_solver *h = nullptr;
     int rc = new_handle(out, opt, &h);
     if (rc) return rc;
     h->nnz = nnz;
+    if ((rc = sync_device_inputs(opt))) {
+        free_all(h);
+        return rc;
+    }
     const int *d_loc = nullptr;
     const double *d_val = nullptr;
     int *own_loc = nullptr;
@@ -794,6 +831,7 @@ MISSLAP_API int misslap_create_dense(misslap_solver **out, int64_t n_rows, int64
         return code;
     };
     const size_t cells = (size_t)n_rows * (size_t)n_cols;
+    if ((rc = sync_device_inputs(opt))) return cleanup(rc);
     if ((rc = dev_alloc(&d_mat, cells))) return cleanup(rc);
     if ((rc = dev_alloc(&d_cnt, (size_t)n_rows))) return cleanup(rc);
     if ((rc = dev_alloc(&d_ptr, (size_t)n_rows + 1))) return cleanup(rc);
@@ -806,13 +844,16 @@ MISSLAP_API int misslap_create_dense(misslap_solver **out, int64_t n_rows, int64
     const int g4 = blocks_for(n_rows, 4);
     hipLaunchKernelGGL(k_dense_count, dim3(g4), dim3(256), 0, h->stream, d_mat, (int)n_rows, (int)n_cols, d_cnt);
     hipLaunchKernelGGL(k_dense_scan, dim3(1), dim3(1024), 0, h->stream, d_cnt, (int)n_rows, d_ptr, d_st);
-    int total = 0;
     IngestStats st;
-    if (hipMemcpyAsync(&total, d_ptr + n_rows, sizeof(int), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
-        hipMemcpyAsync(&st, d_st, sizeof(st), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+    if (hipMemcpyAsync(&st, d_st, sizeof(st), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
         hipStreamSynchronize(h->stream) != hipSuccess)
         return cleanup(fail(MISSLAP_ERR_HIP, "dense ingest failed: %s", hipGetErrorString(hipGetLastError())));
-    if (nnz_out) *nnz_out = total;
+    // the valid entries are counted in 64 bits on the device: a 70 000 x 70 000 matrix fits the GPU but not an int32
+    if (nnz_out) *nnz_out = (int64_t)st.dense_total;
+    if ((st.err & kErrTooMany) || st.dense_total >= nnz_limit(opt))
+        return cleanup(fail(MISSLAP_ERR_INVALID, "the matrix holds %lld valid entries; a solver handle takes fewer than %lld "
+                            "(int32 row pointers)", (long long)st.dense_total, (long long)nnz_limit(opt)));
+    const int total = (int)st.dense_total;
     if (total < n_rows)  // the caller raises the reference's ValueError (auction_.pyx:559-560)
         return cleanup(fail(MISSLAP_ERR_INVALID, "Fewer than %lld valid values provided for %lld rows.",
                             (long long)n_rows, (long long)n_rows));
@@ -996,10 +1037,10 @@ MISSLAP_API int misslap_finish(misslap_solver *h, int32_t *person_to_object_out,
     meta->tiled_active = h->tiled_ok ? (h->scan2d ? 2 : 1) : 0;
     meta->tiled_min_K = h->tiled_min_K;
     meta->shard_edges = c.shard_edges;
-    for (int k = 0; k < 6; ++k) meta->reserved_d[k] = (double)c.dbg[k];  // tail: rounds / 10-ns ticks per mode
-    for (int k = 0; k < 3; ++k) meta->reserved_d[6 + k] = (double)c.dbg[12 + k];  // tail: bids, line hits, builds
+    for (int k = 0; k < 6; ++k) meta->tail_stats[k] = (double)c.dbg[k];  // tail: rounds / 10-ns ticks per mode
+    for (int k = 0; k < 4; ++k) meta->tail_stats[6 + k] = (double)c.dbg[12 + k];  // bids, line hits, builds, hit edges
 #if defined(MISSLAP_TAIL_STAMP) || defined(MISSLAP_TAIL_STAMP_SOLO)
-    for (int k = 0; k < 6; ++k) meta->reserved_d[k] = (double)c.dbg[6 + k];  // diagnostic build: solo-round segments (cycles)
+    for (int k = 0; k < 6; ++k) meta->tail_stats[k] = (double)c.dbg[6 + k];  // diagnostic build: solo-round segments (cycles)
 #endif
     meta->cand_hits = c.cand_hits;
     meta->cand_edges = c.cand_edges;
@@ -1092,6 +1133,7 @@ MISSLAP_API int misslap_get_state(misslap_solver *h, double *prices, int32_t *un
     return MISSLAP_OK;
 }
 
+#ifdef MISSLAP_DIAG  // built into libmisslap_diag.so only (python -m sslap_amd.build diag), for tools/
 // Diagnostics: average duration (ms) of `reps` launches of an ablated full-scan bid kernel over the
 // current unassigned list (K == n_rows right after create).  mode: 0 complete, 1 no price gather,
 // 2 no cross-lane reduction, 3 edge stream only.  Results are discarded; solver state is untouched.
@@ -1176,3 +1218,4 @@ MISSLAP_API int misslap_debug_time_bid(misslap_solver *h, int32_t mode, int32_t 
     (void)hipEventDestroy(e1);
     return MISSLAP_OK;
 }
+#endif  // MISSLAP_DIAG

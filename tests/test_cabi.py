@@ -32,7 +32,7 @@ def test_struct_layouts_match_header():
     import subprocess
     import tempfile
     fields = {"misslap_options": ["max_iter", "tail_threshold", "rounds_per_sync"],
-              "misslap_meta": ["its", "obj_f64", "edges_scanned", "bid_ms", "tail_edges", "tiled_min_K", "merge_ms", "shard_edges", "reserved_d"],
+              "misslap_meta": ["its", "obj_f64", "edges_scanned", "bid_ms", "tail_edges", "tiled_min_K", "merge_ms", "shard_edges", "cand_hits", "tail_stats"],
               "misslap_status": ["K", "error_bits", "rounds_per_sync", "shard_min_K"]}
     prog = ['#include <stdio.h>', '#include <stddef.h>', '#include "misslap.h"', 'int main(void){']
     for s, fs in fields.items():

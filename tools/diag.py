@@ -20,13 +20,13 @@ if "--tiled-ablate" in sys.argv:
     for mode, nm in ((10, "complete"), (11, "no_fill"), (12, "no_lookup_no_arith"), (15, "lookup_no_arith"), (16, "arith_no_lookup"),
                      (13, "no_edge_loads"), (14, "no_barriers"), (10, "complete2")):
         ms = C.c_float()
-        _lib.check(_lib.load().misslap_debug_time_bid(s3._h, mode, 20, C.byref(ms)))
+        _lib.check(_lib.load_diag().misslap_debug_time_bid(s3._h, mode, 20, C.byref(ms)))
         out["tiled_" + nm + "_us"] = round(ms.value * 1e3, 1)
     print(json.dumps(out, indent=1))
     sys.exit(0)
 for mode in (0, 1, 2, 3, 0):
     ms = C.c_float()
-    _lib.check(_lib.load().misslap_debug_time_bid(s._h, mode, 20, C.byref(ms)))
+    _lib.check(_lib.load_diag().misslap_debug_time_bid(s._h, mode, 20, C.byref(ms)))
     out["bid_" + names[mode] + "_us"] = round(ms.value * 1e3, 1)
     out["bid_" + names[mode] + "_GBs"] = round(nnz * 8 / (ms.value * 1e-3) / 1e9, 1)
 # full-scan timing inside a real solve (HIP events), tiled vs gather kernel

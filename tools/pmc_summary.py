@@ -5,12 +5,20 @@ gfx950 corrections (MI355X_MICROARCH.md, HBM section): both counters are in KB; 
 the bytes of a coalesced streaming read -- calibrated here on kernels with a known byte count
 (k_ingest_vals reads nnz*8 B, k_build_edges_f32 reads nnz*16 B: both report exactly 1/2) -- so read bytes =
 FETCH_SIZE * 1024 * 2; WRITE_SIZE is exact (k_build_edges_f32 writes nnz*8 B).
+The output names the code it was measured on: sha256 of the kernel sources (bench.py::source_digest -- what
+bench.py can check on the GPU box) and the git commit of the working tree at summary time.
 usage: pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [nnz]
 """
 import collections
 import csv
 import json
+import os
+import subprocess
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import source_digest  # noqa: E402
 
 
 def load(path):
@@ -22,7 +30,13 @@ def load(path):
 
 fetch, write = load(sys.argv[1]), load(sys.argv[2])
 nnz = int(sys.argv[4]) if len(sys.argv) > 4 else 40179959
-out = {"units": "bytes per launch", "fetch_correction": 2.0, "kernels": {}}
+try:
+    commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "HEAD"], text=True).strip()
+    dirty = bool(subprocess.check_output(["git", "-C", ROOT, "status", "--porcelain", "sslap_amd/csrc"], text=True).strip())
+except Exception:
+    commit, dirty = None, None
+out = {"units": "bytes per launch", "fetch_correction": 2.0, "kernels": {}, "source_sha256": source_digest(),
+       "commit": commit, "commit_dirty_csrc": dirty}
 for k in sorted(set(fetch) | set(write)):
     f, w = fetch.get(k, [0.0]), write.get(k, [0.0])
     out["kernels"][k] = dict(

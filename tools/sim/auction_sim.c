@@ -17,6 +17,9 @@
  *             row's minimum and second-best value so that the count lands in [C/2, C]; tau = t
  *             (what a wavefront can build with a handful of ballots)
  *
+ * Bidder trace: with SIM_TRACE=<file> and SIM_TRACE_THR=<K> in the environment the persons bidding in rounds with
+ * at most K bidders are written as int32, rounds separated by -1 (tools/tail_reuse.py reads it).
+ *
  * usage: auction_sim <input.bin> C policy build_thr use_thr
  *   input.bin: int64 nnz, int32 maximize, int32 loc[nnz][2], double val[nnz]
  *   build_thr: caches are (re)built on a miss in rounds with K <= build_thr
@@ -83,7 +86,14 @@ int main(int argc, char **argv) {
     int64_t phase_rounds[7] = {0};
     int64_t its = 0;
     int K = N, nred = 0;
+    FILE *trace = getenv("SIM_TRACE") ? fopen(getenv("SIM_TRACE"), "wb") : NULL;
+    const int trace_thr = getenv("SIM_TRACE_THR") ? atoi(getenv("SIM_TRACE_THR")) : 256;
     for (;;) {
+        if (trace && K <= trace_thr) {
+            const int sep = -1;
+            fwrite(U, sizeof(int), K, trace);
+            fwrite(&sep, sizeof(int), 1, trace);
+        }
         const int mode = K == 1 ? 0 : K == 2 ? 1 : K <= 16 ? 2 : K <= 64 ? 3 : K <= 512 ? 4 : K <= 2048 ? 5 : 6;
         const int use = K <= use_thr, build = K <= build_thr;
         int round_hits = 0;
@@ -227,6 +237,7 @@ int main(int argc, char **argv) {
             nred++;
         }
     }
+    if (trace) fclose(trace);
     /* FNV of sol for a cheap cross-check, plus its */
     uint64_t h = 1469598103934665603ull;
     for (int i = 0; i < N; ++i) h = (h ^ (uint64_t)(uint32_t)p2o[i]) * 1099511628211ull;

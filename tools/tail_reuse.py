@@ -1,30 +1,24 @@
 #!/usr/bin/env python3
-"""Analysis tooling (CPU, oracle): reuse distance of bidders in the small rounds of a solve.
+"""Analysis tooling (CPU, tools/sim model): reuse distance of bidders in the small rounds of a solve.
 Answers: how many recently-bidding persons' rows must stay on chip for a given hit rate."""
-import ctypes as C
+import subprocess
 import sys
 import os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import oracle as orc
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
 from sslap_amd import synth
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "C2"
 thr = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-loc, val = synth.gen_config(cfg)
-s = orc.from_sparse(loc, val, problem="max", max_iter=10**8, cardinality_check=False)
-L = orc.lib()
-L.oracle_set_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
-L.oracle_trace_len.argtypes = [C.c_void_p]
-L.oracle_trace_len.restype = C.c_int64
-buf = np.empty(60_000_000, dtype=np.int32)
-L.oracle_set_trace(s._h, buf.ctypes.data, buf.size, thr)
-s.solve()
-n = L.oracle_trace_len(s._h)
-tr = buf[:n]
+# the trace comes from the analysis model tools/sim/auction_sim.c (checked against the golden fixture by run_sim.py)
+subprocess.check_call([sys.executable, os.path.join(HERE, "sim", "run_sim.py"), cfg, "0", "1", "0", "0"],
+                      env=dict(os.environ, SIM_TRACE=f"/tmp/sim_trace_{cfg}.bin", SIM_TRACE_THR=str(thr)))
+loc, _ = synth.gen_config(cfg)
+tr = np.fromfile(f"/tmp/sim_trace_{cfg}.bin", dtype=np.int32)
 rounds = int((tr == -1).sum())
 seq = tr[tr >= 0]
-print(f"{cfg}: its={s.meta['its']} small rounds={rounds} bids in them={seq.size}")
+print(f"{cfg}: small rounds={rounds} bids in them={seq.size}")
 # LRU stack distance via last-use timestamps + Fenwick tree
 N = int(loc[:, 0].max()) + 1
 last = np.full(N, -1, dtype=np.int64)

@@ -20,6 +20,6 @@ s = AuctionSolver.from_device_pointers(dl.data_ptr(), dv.data_ptr(), int(loc.sha
 out = []
 for m in modes:
     ms = C.c_float()
-    _lib.check(_lib.load().misslap_debug_time_bid(s._h, m, 40, C.byref(ms)))
+    _lib.check(_lib.load_diag().misslap_debug_time_bid(s._h, m, 40, C.byref(ms)))
     out.append(round(ms.value * 1e3, 1))
 print(json.dumps({"label": label, "cfg": cfg, "modes": modes, "us": out}), flush=True)
