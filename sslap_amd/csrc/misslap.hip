@@ -532,7 +532,8 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
     const int tiled_opt = opt->reserved[0];  // 0 default, < 0 never, > 0 minimum K for the full-scan engines
     const int engine = opt->reserved[2];     // 0 auto (2-D scan when applicable), 1 tiled kernel, 2 2-D scan
     size_t Mpad = M;
-    if (h->f32 && tiled_opt >= 0 && N >= 4096) {
+    const bool forced_engine = opt->reserved[2] != 0 && tiled_opt > 0;  // tests / tuning: any size
+    if (h->f32 && tiled_opt >= 0 && (N >= 4096 || forced_engine)) {
         // 2-D engine: C column slices that fit the LDS, R row blocks, R * C ~ 256 workgroups
         const int C2 = (int)std::max<size_t>(16, (M + kTileColsBig - 1) / kTileColsBig);
         const int R2 = std::max(1, 256 / C2);

@@ -40,6 +40,11 @@ def golden_trace():
 
 
 @pytest.fixture(scope="session")
+def golden_long():
+    return _load("long_cases")
+
+
+@pytest.fixture(scope="session")
 def golden_large():
     return _load("large_cases")[0]
 

@@ -45,9 +45,24 @@ def _full_double(n, density, seed):
     return loc, val
 
 
+def _dense(n, m, seed, integer_values):
+    """Every (i, j) present: rows of m edges (far longer than the 256 edges a wavefront keeps in registers and, at
+    m = 1500, than the 1024 of four passes).  Values as in synth.gen_sparse."""
+    ii, jj = np.meshgrid(np.arange(n, dtype=np.int32), np.arange(m, dtype=np.int32), indexing="ij")
+    loc = np.ascontiguousarray(np.stack([ii.ravel(), jj.ravel()], axis=1))
+    h = synth._stream(seed, 3, n * m)
+    if integer_values:
+        val = (1 + (h >> np.uint64(33)) % np.uint64(integer_values)).astype(np.float64)
+    else:
+        val = ((h >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / (1 << 24)) * np.float32(100.0)).astype(np.float64)
+    return loc, val
+
+
 def synth_inputs(spec):
     """spec: dict(kind=..., ...) -> (loc, val)."""
     kind = spec["kind"]
+    if kind == "dense":
+        return _dense(spec["n"], spec["m"], spec.get("seed", 1), spec.get("ints", 0))
     if kind == "sparse":
         loc, val = synth.gen_sparse(spec["n"], spec["m"], spec["density"], seed=spec.get("seed", 1),
                                     integer_values=spec.get("ints", 0))
@@ -115,6 +130,20 @@ TRACE_CASES = {
     "trace_rect100x150": (dict(kind="sparse", n=100, m=150, density=0.1), dict(problem="min")),
 }
 TRACE_ROUNDS = 80
+
+# long rows: dense inputs through the `mat=` / loc-val entries; full sol + meta, and 80-round traces
+LONG_CASES = {
+    "dense600_max_mat": (dict(kind="dense", n=600, m=600, seed=11), dict(problem="max"), "mat"),
+    "dense600_int7_max": (dict(kind="dense", n=600, m=600, seed=12, ints=7), dict(problem="max"), "locval"),
+    "dense400x700_min": (dict(kind="dense", n=400, m=700, seed=13), dict(problem="min"), "locval"),
+    "dense1500_min_mat": (dict(kind="dense", n=1500, m=1500, seed=14), dict(problem="min"), "mat"),
+    "dense1500_int50_max": (dict(kind="dense", n=1500, m=1500, seed=15, ints=50), dict(problem="max"), "locval"),
+}
+LONG_TRACE_CASES = {
+    "trace_dense600": (dict(kind="dense", n=600, m=600, seed=11), dict(problem="max")),
+    "trace_dense600_int7": (dict(kind="dense", n=600, m=600, seed=12, ints=7), dict(problem="max")),
+    "trace_dense1500": (dict(kind="dense", n=1500, m=1500, seed=14), dict(problem="min")),
+}
 
 # hash-only cases: the BASELINE.json configs (max_iter = 1e8)
 LARGE_CASES = {

@@ -15,7 +15,7 @@ Runs only in the build container (needs /root/reference and Cython):
 
 Nothing of the reference (source, bytecode, binaries) is written into the repo;
 only inputs/outputs are.  Usage:
-    python tests/golden/make_golden.py [small] [trace] [demo] [large] [C5] [matching]
+    python tests/golden/make_golden.py [small] [trace] [demo] [long] [large] [C5] [matching]
 """
 import json
 import os
@@ -120,6 +120,32 @@ def do_trace(ref_solve, versions):
     json.dump(manifest, open(os.path.join(HERE, "trace_cases.json"), "w"), indent=1, sort_keys=True)
 
 
+def do_long(ref_solve, versions):
+    """Long rows (> 256 and > 1024 edges): full solutions + meta, and 80-round traces, from the real reference."""
+    out = {}
+    manifest = {"versions": versions, "rounds": cases.TRACE_ROUNDS, "cases": {}, "traces": {}}
+    for name, (spec, kw, entry) in cases.LONG_CASES.items():
+        loc, val = cases.synth_inputs(spec)
+        ref, o, mutated, t_ref, t_orc = run_both(ref_solve, name, loc, val, kw, entry, spec)
+        out[name + "/sol"] = ref["sol"].astype(np.int32)
+        manifest["cases"][name] = dict(meta=meta_of(ref), input_sha256=synth.input_digest(loc, val),
+                                       val_mutated=mutated, obj_f64=o["extra"]["obj_f64"],
+                                       edges_scanned=o["extra"]["edges_scanned"])
+        print(f"long {name}: its={ref['meta']['its']} nred={ref['meta']['nreductions']} ok ({t_ref:.1f}s ref)")
+    for name, (spec, kw) in cases.LONG_TRACE_CASES.items():
+        loc, val = cases.synth_inputs(spec)
+        sols, its = [], []
+        for r in range(1, cases.TRACE_ROUNDS + 1):
+            ref, o, _, _, _ = run_both(ref_solve, f"{name}@{r}", loc, val, dict(kw, max_iter=r), "locval", spec)
+            sols.append(ref["sol"].astype(np.int32))
+            its.append(ref["meta"]["its"])
+        out[name + "/p2o"] = np.stack(sols)
+        manifest["traces"][name] = dict(its=its, input_sha256=synth.input_digest(loc, val))
+        print(f"long trace {name}: {len(sols)} rounds ok")
+    np.savez_compressed(os.path.join(HERE, "long_cases.npz"), **out)
+    json.dump(manifest, open(os.path.join(HERE, "long_cases.json"), "w"), indent=1, sort_keys=True)
+
+
 def do_demo(ref_solve, versions):
     """The reference's own seeded demo inputs (examples/test_auction.py:7-46) and a small instance
     of its benchmark recipe (benchmarking.py:17-45).  np.random streams are not portable, so the
@@ -218,7 +244,7 @@ def do_matching(versions):
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["small", "trace", "demo", "large", "matching"]
+    what = sys.argv[1:] or ["small", "trace", "demo", "long", "large", "matching"]
     ref_solve, versions = load_reference()
     if "small" in what:
         do_small(ref_solve, versions)
@@ -226,6 +252,8 @@ if __name__ == "__main__":
         do_trace(ref_solve, versions)
     if "demo" in what:
         do_demo(ref_solve, versions)
+    if "long" in what:
+        do_long(ref_solve, versions)
     if "large" in what:
         do_large(ref_solve, versions, ["C1", "C1_min", "C2", "C4", "C3"])
     if "C5" in what:

@@ -559,3 +559,64 @@ def runtimes():
         outs[name] = line
         assert line.count("libamdhip64") == 1, (name, line)  # exactly one runtime mapped
     assert len({o.split("[")[0] for o in outs.values()}) == 1, outs  # the same answer in every process
+
+
+# ---- long rows: fixtures captured from the real reference ----------------------------------------
+LONG_THRESHOLDS = [None, 0, 2, 16, 64, 512]
+
+
+@pytest.mark.parametrize("thr", [None, 0, 16])
+@pytest.mark.parametrize("name", sorted(cases.LONG_CASES))
+def test_long_row_cases_match_reference(name, thr, golden_long, monkeypatch, gpu_lib):
+    manifest, arrays = golden_long
+    spec, kw, entry = cases.LONG_CASES[name]
+    loc, val = cases.synth_inputs(spec)
+    res, call = _solve_gpu(entry, loc, val.copy(), spec, kw, monkeypatch, thr)
+    g = manifest["cases"][name]
+    assert np.array_equal(res["sol"], arrays[name + "/sol"])
+    for k in cases.META_KEYS:
+        assert res["meta"][k] == g["meta"][k], k
+    assert res["meta"]["gpu"]["obj_f64"] == g["obj_f64"]
+    assert res["meta"]["gpu"]["edges_scanned"] == g["edges_scanned"]
+
+
+@pytest.mark.parametrize("thr", [None, 0, 512])
+@pytest.mark.parametrize("name", sorted(cases.LONG_TRACE_CASES))
+def test_long_row_round_trace_matches_reference(name, thr, golden_long, monkeypatch, gpu_lib):
+    """person_to_object after r = 1..80 rounds against the REFERENCE's own runs capped at r."""
+    manifest, arrays = golden_long
+    spec, kw = cases.LONG_TRACE_CASES[name]
+    loc, val = cases.synth_inputs(spec)
+    want, its = arrays[name + "/p2o"], manifest["traces"][name]["its"]
+    for r in range(1, manifest["rounds"] + 1):
+        res, _ = _solve_gpu("locval", loc, val.copy(), spec, dict(kw, max_iter=r), monkeypatch, thr)
+        assert res["meta"]["its"] == its[r - 1]
+        assert np.array_equal(res["sol"], want[r - 1]), f"round {r}"
+
+
+@pytest.mark.parametrize("engine", [0, 1])
+@pytest.mark.parametrize("thr", LONG_THRESHOLDS)
+@pytest.mark.parametrize("name", sorted(cases.LONG_TRACE_CASES))
+def test_long_row_full_state_round_by_round(name, thr, engine, gpu_lib):
+    """prices, U-list order, K, p2o, o2p after r rounds against the oracle capped at r, on rows of 600 and 1500
+    edges: the full scan's second and later 256-edge passes, rows too long for candidate lines, the tile-major
+    kernel's long-segment loop (engine 1: k_bid_tiled forced for every grid round), for every tail threshold."""
+    spec, kw = cases.LONG_TRACE_CASES[name]
+    loc, val = cases.synth_inputs(spec)
+    gpu = dict(tail_threshold=thr)
+    if engine:
+        gpu.update(tiled_min_k=1, engine=engine)
+    for r in [1, 2, 3, 4, 5, 7, 9, 12, 16, 20, 25, 30, 40, 50, 65, 80, 120, 200]:
+        o = orc.from_sparse(loc, val.copy(), max_iter=r, cardinality_check=False, **kw)
+        o.solve()
+        so = o.state()
+        g = from_sparse(loc, val.copy(), max_iter=r, cardinality_check=False, **kw, **gpu)
+        g.solve()
+        sg = g.state()
+        if engine:
+            assert g.gpu["tiled_active"] == engine
+        assert sg["its"] == so["its"] and sg["K"] == so["K"], r
+        assert np.array_equal(sg["U"], so["U"]), r
+        assert np.array_equal(sg["p"].view(np.uint64), so["p"].view(np.uint64)), r
+        assert np.array_equal(sg["p2o"], so["p2o"]) and np.array_equal(sg["o2p"], so["o2p"]), r
+        assert g.gpu["edges_scanned"] == o.extra["edges_scanned"], r

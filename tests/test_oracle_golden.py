@@ -70,6 +70,33 @@ def test_oracle_round_trace(name, golden_trace):
         assert np.array_equal(res["sol"], want[r - 1]), f"round {r}"
 
 
+@pytest.mark.parametrize("name", sorted(cases.LONG_CASES))
+def test_oracle_matches_reference_long_rows(name, golden_long):
+    """Rows of 600 / 700 / 1500 edges (dense inputs), captured from the real reference."""
+    manifest, arrays = golden_long
+    spec, kw, entry = cases.LONG_CASES[name]
+    res, loc, val, call = _run_oracle(spec, kw, entry)
+    g = manifest["cases"][name]
+    assert synth.input_digest(loc, val) == g["input_sha256"], "generator drifted"
+    assert np.array_equal(res["sol"], arrays[name + "/sol"])
+    for k in cases.META_KEYS:
+        assert res["meta"][k] == g["meta"][k], k
+    assert res["extra"]["obj_f64"] == g["obj_f64"] and res["extra"]["edges_scanned"] == g["edges_scanned"]
+
+
+@pytest.mark.parametrize("name", sorted(cases.LONG_TRACE_CASES))
+def test_oracle_round_trace_long_rows(name, golden_long):
+    manifest, arrays = golden_long
+    spec, kw = cases.LONG_TRACE_CASES[name]
+    loc, val = cases.synth_inputs(spec)
+    assert synth.input_digest(loc, val) == manifest["traces"][name]["input_sha256"]
+    want, its = arrays[name + "/p2o"], manifest["traces"][name]["its"]
+    for r in range(1, manifest["rounds"] + 1):
+        res = orc.auction_solve(loc=loc, val=val.copy(), cardinality_check=False, max_iter=r, **kw)
+        assert res["meta"]["its"] == its[r - 1]
+        assert np.array_equal(res["sol"], want[r - 1]), f"round {r}"
+
+
 @pytest.mark.parametrize("name", ["C1", "C1_min", "C4", "C2"])
 def test_oracle_matches_reference_large(name, golden_large):
     g = golden_large["cases"].get(name)
