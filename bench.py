@@ -13,7 +13,8 @@ Contract (one JSON line on rank 0):
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3] [--no-cpu] [--pmc-steps]
 For N > 1 launch with torch.distributed.run (one rank per GPU); persons of each round are sharded over
-the ranks, with RCCL all-reduces on the per-object best bids (sslap_amd/dist.py).
+the ranks, with RCCL all-reduces on the per-object best bids issued by the library itself
+(misslap_solve_sharded, include/misslap.h; sslap_amd/dist.py only creates the communicator).
 """
 import argparse
 import json
@@ -105,6 +106,10 @@ def main():
     ap.add_argument("--cpu-rounds", type=int, default=100_000)
     ap.add_argument("--cpu-sample-only", action="store_true", help="cpu_baseline: the bounded sample only")
     ap.add_argument("--tail-threshold", type=int, default=None)
+    ap.add_argument("--mode", choices=("sharded", "replicas"), default="sharded",
+                    help="N > 1: 'sharded' = ONE problem, persons of the big rounds sharded over the ranks, RCCL "
+                         "exchange (strong scaling; the default); 'replicas' = N independent problems, one per GPU, "
+                         "no collective (weak scaling: how independent LAPs -- the reference's typical use -- scale)")
     args = ap.parse_args()
 
     import numpy as np
@@ -129,6 +134,14 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend, rank=rank, world_size=world)
 
+    comm = None
+    replicas = world > 1 and args.mode == "replicas"
+    if world > 1 and not replicas:
+        from sslap_amd import dist as mdist
+        # RCCL communicator of the library (the 128-byte id travels through torch.distributed); with
+        # MISSLAP_DIST_BACKEND=gloo several ranks share one GPU and the exchange is staged through the host
+        comm = mdist.Comm.from_torch_distributed(local_rank) if backend == "nccl" else mdist.Comm.gloo_staged()
+
     def barrier():
         if world > 1:
             dist.barrier()
@@ -145,17 +158,14 @@ def main():
         gpu_opts["tail_threshold"] = args.tail_threshold
 
     def one_step():
-        if world == 1:
+        if world == 1 or replicas:
             s = AuctionSolver.from_device_pointers(d_loc.data_ptr(), d_val.data_ptr(), nnz, problem="max",
                                                    max_iter=10**8, **gpu_opts)
             sol = s.solve()
             return s, sol
-        from sslap_amd import dist as mdist
         s = AuctionSolver.from_device_pointers(d_loc.data_ptr(), d_val.data_ptr(), nnz, problem="max",
                                                max_iter=10**8, shard=(rank, world), **gpu_opts)
-        t_s = time.perf_counter()
-        sol = mdist.solve_sharded(s)
-        s.gpu["solve_ms"] = 1e3 * (time.perf_counter() - t_s)
+        sol = s.solve_sharded(comm)  # the exchange runs inside the library (misslap_solve_sharded)
         return s, sol
 
     for _ in range(args.warmup):
@@ -168,7 +178,15 @@ def main():
         runs.append((dict(s.meta), dict(s.gpu)))
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if replicas:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        e = torch.tensor([sum(g["edges_scanned"] for _, g in runs)], dtype=torch.int64, device="cuda")
+        dist.all_reduce(e, op=dist.ReduceOp.SUM)
+        edges_all = int(e.item())  # N independent solves: every rank's edges are unique work
+        fs_all_edges, fs_max_ms = None, None
+    elif world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -235,7 +253,7 @@ def main():
         # one extra, untimed solve with every bid launch bracketed by HIP events (profile level 3 costs host time,
         # so it is kept out of the timed steps)
         grid_all = None
-        if world == 1:
+        if world == 1 or replicas:
             gpu_opts3 = dict(gpu_opts, profile=3)
             s3 = AuctionSolver.from_device_pointers(d_loc.data_ptr(), d_val.data_ptr(), nnz, problem="max",
                                                     max_iter=10**8, **gpu_opts3)
@@ -256,7 +274,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": "weak" if replicas else "strong",
+            "mode": ("replicas: one independent solve per GPU, no collective" if replicas else
+                     "sharded: one problem, RCCL exchange in the big rounds" if world > 1 else "single GPU"),
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",

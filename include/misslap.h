@@ -189,6 +189,60 @@ int misslap_exchange_buffers(misslap_solver *h, void **best_key, void **best_pos
 /* Run all of the handle's GPU work on this hipStream_t (default: a private stream). */
 int misslap_set_stream(misslap_solver *h, void *hip_stream);
 
+/* ---- multi-GPU: the exchange step behind the C ABI (one process per GPU, persons of a round sharded over the
+ * ranks; the reference has no counterpart: it is single-threaded, auction_.pyx:6).
+ * A communicator provides the two collectives a sharded round needs -- all-reduce MAX over the int64 best-key buffer
+ * and all-reduce MIN over the int32 best-position buffer (misslap_exchange_buffers) -- issued on the solver's HIP
+ * stream between the round kernels, with no host read inside a round.
+ *   RCCL over xGMI:  rank 0 calls misslap_rccl_unique_id, the 128 bytes are handed to every rank by any means the
+ *                    application has (file, socket, MPI, torch.distributed object broadcast ...), every rank calls
+ *                    misslap_comm_init_rccl.  librccl.so.1 is opened at run time (dlopen).
+ *   custom:          caller-provided callbacks (another transport; the tests' gloo / in-process stand-ins).
+ * Every rank creates its handle on the same input with options.shard_rank / shard_world set and calls
+ * misslap_solve_sharded; every rank receives the same assignment. */
+typedef struct misslap_comm misslap_comm;
+#define MISSLAP_RCCL_ID_BYTES 128
+typedef struct misslap_comm_ops {
+    int32_t struct_size;
+    int32_t rank, world;
+    int32_t reserved;
+    void *ctx;
+    /* in-place all-reduce of `count` elements of a DEVICE buffer, ordered after the work already enqueued on
+     * `hip_stream` and before work enqueued afterwards; return 0 on success */
+    int (*allreduce_max_i64)(void *ctx, void *buf, int64_t count, void *hip_stream);
+    int (*allreduce_min_i32)(void *ctx, void *buf, int64_t count, void *hip_stream);
+} misslap_comm_ops;
+int misslap_rccl_unique_id(void *id_out /* MISSLAP_RCCL_ID_BYTES */);
+int misslap_comm_init_rccl(misslap_comm **out, const void *unique_id, int32_t rank, int32_t world, int32_t device);
+int misslap_comm_init_custom(misslap_comm **out, const misslap_comm_ops *ops);
+int misslap_comm_destroy(misslap_comm *comm);
+/* AuctionSolver.solve() (auction_.pyx:268-306) over all ranks of `comm` (NULL: no exchange, a single rank).  Only
+ * rounds with K >= status.shard_min_K are sharded and exchanged; all others are replicated. */
+int misslap_solve_sharded(misslap_solver *h, misslap_comm *comm, int32_t *person_to_object_out, misslap_meta *meta);
+
+/* The same loop over caller-provided round operations: what misslap_solve_sharded runs with the handle's own
+ * operations.  Exposed so that the loop -- shard / replicate decision, collective sequence, loop control -- can be
+ * driven without a GPU (tests/test_dist_gloo.py: numpy stand-ins for the round kernels, gloo for the exchange). */
+typedef struct misslap_round_ops {
+    int32_t struct_size;
+    int32_t tail_threshold;
+    int32_t shard_min_K;
+    int32_t rounds_per_sync;
+    int64_t max_iter;
+    void *ctx;
+    int (*status)(void *ctx, int64_t *K, int64_t *its); /* synchronise and read the round state */
+    int (*round_bid)(void *ctx);
+    int (*round_tiebreak)(void *ctx);
+    int (*round_apply)(void *ctx);
+    int (*run_tail)(void *ctx);
+    int (*phase_end)(void *ctx, int32_t *finished);
+    void *best_key;    /* int64[n_objects] exchange buffer (device memory for the GPU operations) */
+    void *best_pos;    /* int32[n_objects] */
+    int64_t n_objects;
+    void *stream;      /* handed to the communicator's callbacks */
+} misslap_round_ops;
+int misslap_drive_sharded(const misslap_round_ops *ops, misslap_comm *comm);
+
 /* ---- state copy-out for parity tests (all host buffers, any may be NULL):
  * prices double[M] (auction_.pyx:169), unassigned list int32[N] (first K valid, :199),
  * person_to_object int32[N] (:177), object_to_person int32[M] (:178). */

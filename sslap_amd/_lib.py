@@ -49,6 +49,27 @@ class Status(C.Structure):
     ]
 
 
+_AR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+
+
+class CommOps(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("rank", C.c_int32), ("world", C.c_int32), ("reserved", C.c_int32),
+                ("ctx", C.c_void_p), ("allreduce_max_i64", _AR), ("allreduce_min_i32", _AR)]
+
+
+_OP0 = C.CFUNCTYPE(C.c_int, C.c_void_p)
+_OP_STATUS = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64))
+_OP_PHASE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int32))
+
+
+class RoundOps(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("tail_threshold", C.c_int32), ("shard_min_K", C.c_int32),
+                ("rounds_per_sync", C.c_int32), ("max_iter", C.c_int64), ("ctx", C.c_void_p),
+                ("status", _OP_STATUS), ("round_bid", _OP0), ("round_tiebreak", _OP0), ("round_apply", _OP0),
+                ("run_tail", _OP0), ("phase_end", _OP_PHASE), ("best_key", C.c_void_p), ("best_pos", C.c_void_p),
+                ("n_objects", C.c_int64), ("stream", C.c_void_p)]
+
+
 # every symbol include/misslap.h declares: (name, restype, argtypes)
 _VP, _I32P = C.c_void_p, C.POINTER(C.c_int32)
 SYMBOLS = {
@@ -70,6 +91,12 @@ SYMBOLS = {
     "misslap_set_stream": (C.c_int, [_VP, _VP]),
     "misslap_get_state": (C.c_int, [_VP, _VP, _VP, _VP, _VP]),
     "misslap_device_info": (C.c_int, [C.c_int32, C.c_char_p, C.c_int32, _I32P, C.POINTER(C.c_int64)]),
+    "misslap_rccl_unique_id": (C.c_int, [_VP]),
+    "misslap_comm_init_rccl": (C.c_int, [C.POINTER(_VP), _VP, C.c_int32, C.c_int32, C.c_int32]),
+    "misslap_comm_init_custom": (C.c_int, [C.POINTER(_VP), C.POINTER(CommOps)]),
+    "misslap_comm_destroy": (C.c_int, [_VP]),
+    "misslap_solve_sharded": (C.c_int, [_VP, _VP, _VP, C.POINTER(Meta)]),
+    "misslap_drive_sharded": (C.c_int, [C.POINTER(RoundOps), _VP]),
     "misslap_hopcroft_karp": (C.c_int, [_VP, C.c_int64, C.c_int32, C.c_int32, _I32P, _VP, _VP]),
     "misslap_last_error": (C.c_char_p, []),
     "misslap_abi_version": (C.c_int, []),

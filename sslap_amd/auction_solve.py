@@ -156,6 +156,17 @@ class AuctionSolver:
         self._fill_meta(meta)
         return sol
 
+    def solve_sharded(self, comm=None):
+        """The same solve over the ranks of a communicator (sslap_amd.dist.Comm): persons of the big rounds sharded,
+        per-object arg-max exchanged on the solver's stream inside the library (misslap_solve_sharded)."""
+        lib = _lib.load()
+        sol = np.empty(self.num_rows, dtype=np.int32)
+        meta = _lib.Meta()
+        _lib.check(lib.misslap_solve_sharded(self._h, comm._c if comm is not None else None, sol.ctypes.data,
+                                             C.byref(meta)))
+        self._fill_meta(meta)
+        return sol
+
     def _fill_meta(self, m):
         # auction_.pyx:297-304
         self.meta["eCE"] = int(m.eCE)

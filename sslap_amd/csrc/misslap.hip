@@ -28,6 +28,7 @@
 #include "kernels_round.hpp"
 #include "kernels_tail.hpp"
 #include "host_matching.hpp"
+#include "host_comm.hpp"
 #include "kernels_tiled.hpp"
 #include "kernels_scan2d.hpp"
 
@@ -1115,6 +1116,106 @@ MISSLAP_API int misslap_solve(misslap_solver *h, int32_t *person_to_object_out, 
         int fin = 0;
         if ((rc = misslap_phase_end(h, &fin))) return rc;
     }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->solve_ms += now_ms() - t0;
+    return misslap_finish(h, person_to_object_out, meta);
+}
+
+// ---- multi-GPU: communicators and the sharded solve (host_comm.hpp) ------------------------------------------------
+MISSLAP_API int misslap_rccl_unique_id(void *id_out) {
+    if (!id_out) return fail(MISSLAP_ERR_INVALID, "null argument");
+    RcclApi &api = rccl_api();
+    if (!api.error.empty()) return fail(MISSLAP_ERR_HIP, "%s", api.error.c_str());
+    RcclApi::UniqueId id;
+    const int rc = api.GetUniqueId(&id);
+    if (rc) return fail(MISSLAP_ERR_HIP, "ncclGetUniqueId failed: %s", api.GetErrorString(rc));
+    std::memcpy(id_out, &id, sizeof(id));
+    return MISSLAP_OK;
+}
+
+MISSLAP_API int misslap_comm_init_rccl(misslap_comm **out, const void *unique_id, int32_t rank, int32_t world,
+                                       int32_t device) {
+    if (!out || !unique_id || world < 1 || rank < 0 || rank >= world) return fail(MISSLAP_ERR_INVALID, "bad argument");
+    RcclApi &api = rccl_api();
+    if (!api.error.empty()) return fail(MISSLAP_ERR_HIP, "%s", api.error.c_str());
+    HIP_TRY(hipSetDevice(device));
+    RcclApi::UniqueId id;
+    std::memcpy(&id, unique_id, sizeof(id));
+    misslap_comm *c = new misslap_comm();
+    c->rank = rank;
+    c->world = world;
+    c->device = device;
+    const int rc = api.CommInitRank(&c->nccl_comm, world, id, rank);
+    if (rc) {
+        delete c;
+        return fail(MISSLAP_ERR_HIP, "ncclCommInitRank failed: %s", api.GetErrorString(rc));
+    }
+    *out = c;
+    return MISSLAP_OK;
+}
+
+MISSLAP_API int misslap_comm_init_custom(misslap_comm **out, const misslap_comm_ops *ops) {
+    if (!out || !ops || ops->struct_size != (int32_t)sizeof(misslap_comm_ops) || !ops->allreduce_max_i64 ||
+        !ops->allreduce_min_i32 || ops->world < 1 || ops->rank < 0 || ops->rank >= ops->world)
+        return fail(MISSLAP_ERR_INVALID, "bad misslap_comm_ops");
+    misslap_comm *c = new misslap_comm();
+    c->rank = ops->rank;
+    c->world = ops->world;
+    c->ops = *ops;
+    c->custom = true;
+    *out = c;
+    return MISSLAP_OK;
+}
+
+MISSLAP_API int misslap_comm_destroy(misslap_comm *c) {
+    if (!c) return MISSLAP_OK;
+    if (!c->custom && c->nccl_comm) (void)rccl_api().CommDestroy(c->nccl_comm);
+    delete c;
+    return MISSLAP_OK;
+}
+
+MISSLAP_API int misslap_drive_sharded(const misslap_round_ops *ops, misslap_comm *comm) {
+    if (!ops || ops->struct_size != (int32_t)sizeof(misslap_round_ops) || !ops->status || !ops->round_bid ||
+        !ops->round_tiebreak || !ops->round_apply || !ops->run_tail || !ops->phase_end)
+        return fail(MISSLAP_ERR_INVALID, "bad misslap_round_ops");
+    return drive_sharded(ops, comm, fail);
+}
+
+MISSLAP_API int misslap_solve_sharded(misslap_solver *h, misslap_comm *comm, int32_t *person_to_object_out,
+                                      misslap_meta *meta) {
+    if (!h) return fail(MISSLAP_ERR_INVALID, "null handle");
+    if (comm && (comm->world != h->world || comm->rank != h->rank))
+        return fail(MISSLAP_ERR_INVALID, "communicator is rank %d of %d, the handle was created as shard %d of %d",
+                    comm->rank, comm->world, h->rank, h->world);
+    if (!comm && h->world != 1) return fail(MISSLAP_ERR_INVALID, "a handle of %d shards needs a communicator", h->world);
+    HIP_TRY(hipSetDevice(h->device));
+    const double t0 = now_ms();
+    misslap_round_ops o;
+    std::memset(&o, 0, sizeof(o));
+    o.struct_size = (int32_t)sizeof(o);
+    o.tail_threshold = h->thr;
+    o.shard_min_K = h->shard_min_K;
+    o.rounds_per_sync = h->rounds_per_sync;
+    o.max_iter = h->max_iter;
+    o.ctx = h;
+    o.status = [](void *x, int64_t *K, int64_t *its) {
+        misslap_solver *s = static_cast<misslap_solver *>(x);
+        const int rc = read_ctl(s);
+        *K = s->h_ctl->K;
+        *its = s->h_ctl->nits;
+        return rc;
+    };
+    o.round_bid = [](void *x) { return launch_bid(static_cast<misslap_solver *>(x)); };
+    o.round_tiebreak = [](void *x) { return launch_tiebreak(static_cast<misslap_solver *>(x)); };
+    o.round_apply = [](void *x) { return launch_apply(static_cast<misslap_solver *>(x)); };
+    o.run_tail = [](void *x) { return launch_tail(static_cast<misslap_solver *>(x)); };
+    o.phase_end = [](void *x, int32_t *fin) { return misslap_phase_end(static_cast<misslap_solver *>(x), fin); };
+    o.best_key = h->best_key;
+    o.best_pos = h->best_pos;
+    o.n_objects = h->n_cols;
+    o.stream = h->stream;
+    int rc = drive_sharded(&o, comm, fail);
+    if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->solve_ms += now_ms() - t0;
     return misslap_finish(h, person_to_object_out, meta);

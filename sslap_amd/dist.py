@@ -1,68 +1,120 @@
-"""Multi-GPU driver: persons of each round sharded over the ranks of one node, one process per GPU.
+"""Multi-GPU front-end: persons of each round sharded over the ranks of one node, one process per GPU.
 
-The path shards *within a round* (SURVEY.md section 8e): bidders are independent given the common price
-vector (Jacobi auction, reference auction_.pyx:339-365 reads prices that are only written at :397).  All
-solver state is replicated; rank r bids for the positions [K*r/W, K*(r+1)/W) of the unassigned list, and
-the only exchange step of a round is the per-object arg-max of the bids (auction_.pyx:375-385):
+The whole sharded solve -- shard / replicate decision per round, the two all-reduces of a sharded round, loop
+control -- runs inside libmisslap.so (`misslap_solve_sharded`, csrc/host_comm.hpp); this module only creates the
+communicator and calls it.  The path shards *within a round* (SURVEY.md section 8e): bidders are independent given
+the common price vector (Jacobi auction, reference auction_.pyx:339-365 reads prices that are only written at :397).
+All solver state is replicated; rank r bids for the positions [K*r/W, K*(r+1)/W) of the unassigned list, and the
+only exchange step of a round is the per-object arg-max of the bids (auction_.pyx:375-385):
 
-    round_bid       local bids + local per-object maximum (int64 keys = bid bits + 1)
-    all_reduce MAX  over best_key[M]          (RCCL over xGMI; `nccl` backend of torch.distributed)
-    round_tiebreak  positions of local bidders that hold the global maximum
-    all_reduce MIN  over best_pos[M]          (earliest list position wins equal bids, strict '>' of :379)
-    round_apply     assignment + list compaction, run redundantly -- and deterministically -- by every
-                    rank, which is what keeps the replicas identical (this *is* the price broadcast)
+    k_bid / k_bid_tiled   local bids + local per-object maximum (int64 keys = bid bits + 1)
+    all-reduce MAX        over best_key[M]     (RCCL over xGMI, on the solver's stream)
+    k_tiebreak            positions of local bidders that hold the global maximum
+    all-reduce MIN        over best_pos[M]     (earliest list position wins equal bids, strict '>' of :379)
+    k_apply + compaction  run redundantly -- and deterministically -- by every rank, which keeps the replicas
+                          identical (this *is* the price broadcast)
 
-Only the big rounds (K >= shard_min_K = 0.3 N: a handful per eps-phase, where the bid phase is a
-bandwidth-bound CSR scan) are sharded and exchanged.  All smaller rounds are replicated: every rank bids for
-every list position (grid kernels) or runs the persistent tail kernel (K <= tail threshold; > 98 % of all
-rounds), with no communication -- a dense all-reduce per small round would cost far more than the round, and
-the replicas stay bit-identical because every step is deterministic.  The driver is written against a small backend interface so that its control flow and
-collective sequence are covered by world_size-2 `gloo` tests on CPU tensors (tests/test_dist_gloo.py).
+Only the big rounds (K >= shard_min_K = 0.3 N: a handful per eps-phase, where the bid phase is a bandwidth-bound CSR
+scan) are sharded and exchanged.  All smaller rounds are replicated: every rank bids for every list position (grid
+kernels) or runs the persistent tail kernel (> 98 % of all rounds), with no communication.
+
+Communicators:
+    Comm.rccl(rank, world, device, share_id)   RCCL; `share_id(id_bytes_or_None) -> id_bytes` hands rank 0's
+                                               128-byte id to every rank (any transport the application has)
+    Comm.from_torch_distributed(device)        the same, the id travels through torch.distributed
+    Comm.custom(rank, world, max_cb, min_cb)   caller-provided all-reduces (ptr, count, stream) -- other transports
+    Comm.gloo_staged(rank, world)              rehearsal on ONE GPU: several ranks share cuda:0, the exchange is
+                                               staged through the host with gloo (RCCL needs a GPU per rank)
 """
-import torch
-import torch.distributed as dist
+import ctypes as C
+
+from . import _lib
+
+RCCL_ID_BYTES = 128
 
 
-class GpuBackend:
-    """One AuctionSolver handle (created with shard=(rank, world)) + torch views of its exchange buffers."""
+class Comm:
+    """Owner of a misslap_comm* (include/misslap.h)."""
 
-    def __init__(self, solver):
-        self.s = solver
-        key_ptr, pos_ptr, m = solver.exchange_buffers()
-        dev = torch.device("cuda", torch.cuda.current_device())
-        self.best_key = _alias(key_ptr, m, "<i8", dev)
-        self.best_pos = _alias(pos_ptr, m, "<i4", dev)
-        # all kernels of the handle go to torch's current stream so that they order with the collectives
-        solver.set_stream(torch.cuda.current_stream().cuda_stream)
-        self.thr = solver.tail_threshold
-        self.rounds_per_sync = solver.rounds_per_sync
-        self.shard_min_K = solver.shard_min_K
+    def __init__(self, handle, rank, world, keep=()):
+        self._c, self.rank, self.world, self._keep = handle, rank, world, keep
 
-    def status(self):
-        st = self.s.status()
-        return int(st.K), int(st.its)
+    def __del__(self):
+        c = getattr(self, "_c", None)
+        if c:
+            try:
+                _lib.load().misslap_comm_destroy(c)
+            except Exception:
+                pass
+            self._c = None
 
-    @property
-    def max_iter(self):
-        return int(self.s._opts.max_iter) if self.s._opts.max_iter >= 1 else 1
+    @staticmethod
+    def unique_id():
+        """Rank 0: a fresh RCCL id (128 bytes) to hand to every rank."""
+        buf = C.create_string_buffer(RCCL_ID_BYTES)
+        _lib.check(_lib.load().misslap_rccl_unique_id(buf))
+        return buf.raw
 
-    def round_bid(self):
-        self.s.round_bid()
+    @classmethod
+    def rccl(cls, rank, world, device, share_id):
+        uid = share_id(cls.unique_id() if rank == 0 else None)
+        h = C.c_void_p()
+        _lib.check(_lib.load().misslap_comm_init_rccl(C.byref(h), uid, int(rank), int(world), int(device)))
+        return cls(h, rank, world)
 
-    def round_tiebreak(self):
-        self.s.round_tiebreak()
+    @classmethod
+    def from_torch_distributed(cls, device, group=None):
+        """RCCL communicator for the ranks of an initialised torch.distributed group (any backend: it only carries
+        the 128-byte id; the solve's collectives are the library's own)."""
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
 
-    def round_apply(self):
-        self.s.round_apply()
+        def share(uid):
+            box = [uid]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            return box[0]
+        return cls.rccl(rank, world, device, share)
 
-    def run_tail(self):
-        self.s.run_tail()
+    @classmethod
+    def custom(cls, rank, world, allreduce_max_i64, allreduce_min_i32):
+        """`allreduce_*(ptr, count, stream)`: in-place all-reduce of a buffer of the round operations in use (device
+        memory for a GPU handle); exceptions are reported as a failed solve."""
+        def wrap(fn):
+            def cb(_ctx, ptr, count, stream):
+                try:
+                    fn(int(ptr), int(count), stream)
+                    return 0
+                except Exception:  # noqa: BLE001 -- must not propagate through the C frame
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            return _lib._AR(cb)
+        ops = _lib.CommOps()
+        ops.struct_size = C.sizeof(_lib.CommOps)
+        ops.rank, ops.world = int(rank), int(world)
+        ops.allreduce_max_i64, ops.allreduce_min_i32 = wrap(allreduce_max_i64), wrap(allreduce_min_i32)
+        h = C.c_void_p()
+        _lib.check(_lib.load().misslap_comm_init_custom(C.byref(h), C.byref(ops)))
+        return cls(h, rank, world, keep=(ops,))
 
-    def phase_end(self):
-        return self.s.phase_end()
+    @classmethod
+    def gloo_staged(cls, group=None):
+        """Several ranks on ONE GPU (rehearsal / tests): device buffers are staged through the host and reduced with
+        the gloo backend of torch.distributed."""
+        import torch
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
 
-    def finish(self):
-        return self.s.finish()
+        def staged(op, typestr):
+            def fn(ptr, count, _stream):
+                t = torch.as_tensor(_DevArray(ptr, count, typestr), device=torch.device("cuda", torch.cuda.current_device()))
+                torch.cuda.synchronize()  # the solver's stream has produced the buffer
+                h = t.cpu()
+                dist.all_reduce(h, op=op, group=group)
+                t.copy_(h)
+                torch.cuda.synchronize()  # ... and may read it again
+            return fn
+        return cls.custom(rank, world, staged(dist.ReduceOp.MAX, "<i8"), staged(dist.ReduceOp.MIN, "<i4"))
 
 
 class _DevArray:
@@ -71,46 +123,7 @@ class _DevArray:
                                          "version": 2, "strides": None}
 
 
-def _alias(ptr, n, typestr, dev):
-    """torch tensor aliasing library-owned device memory (no copy)."""
-    return torch.as_tensor(_DevArray(ptr, n, typestr), device=dev)
-
-
-def solve_sharded(solver_or_backend, group=None):
-    """AuctionSolver.solve() (reference auction_.pyx:268-306) over all ranks of `group`.
-
-    Every rank passes its own handle / backend built on the same input; every rank returns the same
-    person_to_object array.  Control decisions are taken from replicated state, so all ranks issue the
-    same sequence of collectives.
-    """
-    b = solver_or_backend if hasattr(solver_or_backend, "round_bid") and hasattr(solver_or_backend, "best_key") \
-        else GpuBackend(solver_or_backend)
-    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
-    while True:
-        while True:  # rounds of one eps-phase
-            K, its = b.status()
-            if K == 0 or its >= b.max_iter:
-                break
-            if K >= b.shard_min_K and K > b.thr:
-                # a big round: bidders sharded over the ranks, per-object arg-max exchanged (K is exact here,
-                # so the device-side decision "K >= shard_min_K" is the same on every rank)
-                b.round_bid()
-                if multi:
-                    dist.all_reduce(b.best_key, op=dist.ReduceOp.MAX, group=group)
-                b.round_tiebreak()
-                if multi:
-                    dist.all_reduce(b.best_pos, op=dist.ReduceOp.MIN, group=group)
-                b.round_apply()
-            elif K > b.thr:
-                # K never grows inside a phase: from here on every rank bids for everybody (replicated,
-                # deterministic), no exchange; several rounds per status read
-                for _ in range(b.rounds_per_sync):
-                    b.round_bid()
-                    b.round_tiebreak()
-                    b.round_apply()
-            else:
-                b.run_tail()
-        if b.phase_end():
-            break
-    sol = b.finish()
-    return sol
+def solve_sharded(solver, comm=None):
+    """AuctionSolver.solve() (reference auction_.pyx:268-306) over all ranks of `comm`.  Every rank passes its own
+    solver (created on the same input with shard=(rank, world)); every rank returns the same person_to_object."""
+    return solver.solve_sharded(comm)

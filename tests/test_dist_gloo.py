@@ -1,7 +1,10 @@
-"""CPU suite, part 3: the multi-GPU driver (sslap_amd/dist.py) with world_size 2 on the gloo backend.
-The per-rank compute is the numpy stand-in of tests/_numpy_backend.py; what is under test is the
-driver: shard ranges, MAX / MIN exchange sequence, replicated apply, loop control -- the result must be
-bit-identical to the single-process oracle, and both ranks must agree."""
+"""CPU suite, part 3: the sharded solve loop of the LIBRARY (misslap_drive_sharded, csrc/host_comm.hpp -- the loop
+misslap_solve_sharded runs on a GPU handle) with world_size 2 on the gloo backend.  The per-rank round operations
+are the numpy stand-ins of tests/_numpy_backend.py, handed to the C loop as callbacks; the exchange is a custom
+communicator whose callbacks all-reduce the (host) buffers with gloo.  Under test: shard ranges, MAX / MIN exchange
+sequence, replicated apply, loop control -- the result must be bit-identical to the single-process oracle, and
+both ranks must agree."""
+import ctypes as C
 import os
 import socket
 import sys
@@ -19,6 +22,57 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def drive_with_c_loop(b, comm):
+    """Run misslap_drive_sharded over a NumpyBackend (`b`) and a sslap_amd.dist.Comm (or None)."""
+    from sslap_amd import _lib
+    lib = _lib.load()
+    calls = []
+
+    def status(_ctx, K, its):
+        K[0], its[0] = b.status()
+        return 0
+
+    def op(fn):
+        def cb(_ctx):
+            calls.append(fn.__name__)
+            fn()
+            return 0
+        return _lib._OP0(cb)
+
+    def phase_end(_ctx, fin):
+        fin[0] = 1 if b.phase_end() else 0
+        return 0
+
+    o = _lib.RoundOps()
+    o.struct_size = C.sizeof(_lib.RoundOps)
+    o.tail_threshold, o.shard_min_K, o.rounds_per_sync, o.max_iter = b.thr, b.shard_min_K, b.rounds_per_sync, b.max_iter
+    keep = (_lib._OP_STATUS(status), op(b.round_bid), op(b.round_tiebreak), op(b.round_apply), op(b.run_tail),
+            _lib._OP_PHASE(phase_end))
+    o.status, o.round_bid, o.round_tiebreak, o.round_apply, o.run_tail, o.phase_end = keep
+    o.best_key, o.best_pos = b.best_key.data_ptr(), b.best_pos.data_ptr()
+    o.n_objects = b.M
+    _lib.check(lib.misslap_drive_sharded(C.byref(o), comm._c if comm is not None else None))
+    return b.finish(), calls
+
+
+def host_gloo_comm(rank, world, counter):
+    """Custom communicator over HOST buffers: the callbacks all-reduce them with gloo."""
+    import torch
+    import torch.distributed as dist
+    from sslap_amd.dist import Comm
+
+    def reduce(op, dtype, torch_dtype):
+        def fn(ptr, count, _stream):
+            arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(dtype)), (count,))
+            t = torch.from_numpy(arr)
+            assert t.dtype == torch_dtype
+            dist.all_reduce(t, op=op)
+            counter.append(op)
+        return fn
+    return Comm.custom(rank, world, reduce(dist.ReduceOp.MAX, C.c_int64, torch.int64),
+                       reduce(dist.ReduceOp.MIN, C.c_int32, torch.int32))
+
+
 def _worker(rank, world, port, spec, prob, max_iter, shard_min_K, out):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -26,14 +80,15 @@ def _worker(rank, world, port, spec, prob, max_iter, shard_min_K, out):
     import torch.distributed as dist
     import cases
     from _numpy_backend import NumpyBackend
-    from sslap_amd.dist import solve_sharded
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     loc, val = cases.synth_inputs(spec)
     b = NumpyBackend(loc, val, prob, rank, world, max_iter=max_iter, shard_min_K=shard_min_K)
-    sol = solve_sharded(b)
-    out.put((rank, sol.tolist(), b.its, b.nreductions, b.p.tobytes()))
+    exchanges = []
+    comm = host_gloo_comm(rank, world, exchanges)
+    sol, calls = drive_with_c_loop(b, comm)
+    out.put((rank, sol.tolist(), b.its, b.nreductions, b.p.tobytes(), len(exchanges), calls.count("round_bid")))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -46,7 +101,7 @@ def _worker(rank, world, port, spec, prob, max_iter, shard_min_K, out):
     (dict(kind="sparse", n=64, m=64, density=0.1), "max", 10**8, 20),           # big rounds sharded, rest replicated
     (dict(kind="sparse", n=60, m=60, density=0.15, ints=3), "min", 10**8, 30),
 ])
-def test_sharded_driver_world2_matches_oracle(spec, prob, max_iter, shard_min_K):
+def test_sharded_c_loop_world2_matches_oracle(spec, prob, max_iter, shard_min_K, built_lib):
     import cases
     from oracle import oracle as orc
     ctx = mp.get_context("spawn")
@@ -63,21 +118,37 @@ def test_sharded_driver_world2_matches_oracle(spec, prob, max_iter, shard_min_K)
     o = orc.from_sparse(loc, val.copy(), problem=prob, max_iter=max_iter, cardinality_check=False)
     sol = o.solve()
     st = o.state()
-    for rank, s, its, nred, pbytes in res:
+    for rank, s, its, nred, pbytes, n_exchanges, n_bids in res:
         assert s == sol.tolist(), f"rank {rank}"
         assert its == o.meta["its"] and nred == o.meta["nreductions"]
         assert pbytes == st["p"].tobytes()
+        assert n_exchanges % 2 == 0 and n_exchanges > 0          # MAX and MIN come in pairs ...
+        if shard_min_K == 0:
+            assert n_exchanges == 2 * n_bids                       # ... one pair per (sharded) round
+        else:
+            assert n_exchanges < 2 * n_bids                        # the small rounds are replicated, not exchanged
+    assert res[0][5] == res[1][5]                                  # both ranks issued the same collectives
 
 
-def test_single_process_driver_matches_oracle():
-    """world_size 1 (no process group): the driver alone."""
+def test_single_rank_c_loop_matches_oracle(built_lib):
+    """world_size 1, no communicator: the loop alone."""
     import cases
     from _numpy_backend import NumpyBackend
     from oracle import oracle as orc
-    from sslap_amd.dist import solve_sharded
     spec = dict(kind="sparse", n=80, m=80, density=0.1, ints=5)
     loc, val = cases.synth_inputs(spec)
     b = NumpyBackend(loc, val, "max", 0, 1)
-    sol = solve_sharded(b)
+    sol, calls = drive_with_c_loop(b, None)
     ref = orc.auction_solve(loc=loc, val=val.copy(), problem="max", cardinality_check=False)
     assert np.array_equal(sol, ref["sol"]) and b.its == ref["meta"]["its"]
+    assert calls.count("round_bid") == calls.count("round_apply") == ref["meta"]["its"]
+
+
+def test_comm_argument_validation(built_lib):
+    from sslap_amd import _lib
+    lib = _lib.load()
+    h = C.c_void_p()
+    ops = _lib.CommOps()
+    assert lib.misslap_comm_init_custom(C.byref(h), C.byref(ops)) == _lib.ERR_INVALID  # struct_size / callbacks unset
+    assert lib.misslap_drive_sharded(None, None) == _lib.ERR_INVALID
+    assert lib.misslap_comm_destroy(None) == _lib.MISSLAP_OK

@@ -203,16 +203,17 @@ def _dist_gpu_worker(rank, world, port, out):
     import torch
     import torch.distributed as dist
     from sslap_amd import from_sparse, synth
-    from sslap_amd.dist import solve_sharded
+    from sslap_amd.dist import Comm, solve_sharded
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm = Comm.gloo_staged()  # custom communicator: device buffers staged through the host, reduced with gloo
     res = []
     for n, dens, seed, ints, thr, smk in _DIST_GPU_CASES:
         loc, val = synth.gen_sparse(n, n, dens, seed=seed, integer_values=ints)
         s = from_sparse(loc, val, problem="max", cardinality_check=False, shard=(rank, world), tail_threshold=thr,
                         max_iter=10**8, shard_min_k=smk)
-        sol = solve_sharded(s)
+        sol = solve_sharded(s, comm)  # misslap_solve_sharded: the loop and the exchange calls are the library's
         res.append((sol.tolist(), s.meta["its"], s.meta["nreductions"], s.gpu["obj_f64"],
                     s.gpu["edges_scanned"], s.gpu["shard_edges"]))
     out.put((rank, res))
@@ -221,10 +222,10 @@ def _dist_gpu_worker(rank, world, port, out):
 
 
 def test_sharded_driver_two_ranks_one_gpu(gpu_lib):
-    """The real kernels behind the multi-GPU driver: two processes share cuda:0 and exchange the
-    best-bid buffers through gloo (RCCL itself needs one GPU per rank and is exercised by bench.py
-    --gpus N on a multi-GPU node).  Shard ranges, exchange buffers aliased as torch tensors, stream
-    hand-over, replicated apply and the replicated tail must reproduce the single-GPU / oracle result."""
+    """The real kernels behind the library's sharded solve (misslap_solve_sharded): two processes share cuda:0 and
+    exchange the best-bid buffers through a custom communicator (gloo, staged through the host; RCCL needs one GPU
+    per rank -- its world-1 smoke test is below).  Shard ranges, exchange on the solver's stream, replicated apply
+    and the replicated tail must reproduce the single-GPU / oracle result."""
     import socket
     import torch.multiprocessing as mp
     with socket.socket() as sk:
@@ -620,3 +621,23 @@ def test_long_row_full_state_round_by_round(name, thr, engine, gpu_lib):
         assert np.array_equal(sg["p"].view(np.uint64), so["p"].view(np.uint64)), r
         assert np.array_equal(sg["p2o"], so["p2o"]) and np.array_equal(sg["o2p"], so["o2p"]), r
         assert g.gpu["edges_scanned"] == o.extra["edges_scanned"], r
+
+
+def test_rccl_world1_smoke(gpu_lib):
+    """the RCCL path of the library executes -- librccl opened at run time, ncclGetUniqueId,
+    ncclCommInitRank (world 1), and ncclAllReduce MAX (int64) / MIN (int32) issued on the solver's stream between
+    k_bid, k_tiebreak and k_apply for EVERY grid round (shard_min_k = -1) -- and the solve still equals the oracle."""
+    from sslap_amd.dist import Comm, solve_sharded
+    comm = Comm.rccl(0, 1, 0, lambda uid: uid)
+    for n, dens, seed, ints, thr in ((1500, 0.02, 1, 0, 0), (30000, 0.002, 4, 0, None), (2000, 0.02, 5, 3, 8)):
+        loc, val = synth.gen_sparse(n, n, dens, seed=seed, integer_values=ints)
+        ref = orc.auction_solve(loc=loc, val=val.copy(), problem="max", cardinality_check=False, max_iter=10**8)
+        s = from_sparse(loc, val.copy(), problem="max", cardinality_check=False, max_iter=10**8, shard=(0, 1),
+                        tail_threshold=thr, shard_min_k=-1)
+        sol = solve_sharded(s, comm)
+        assert np.array_equal(sol, ref["sol"]) and s.meta["its"] == ref["meta"]["its"]
+        assert s.gpu["obj_f64"] == ref["extra"]["obj_f64"] and s.gpu["edges_scanned"] == ref["extra"]["edges_scanned"]
+    # a communicator that does not match the handle's shard is refused
+    s = from_sparse(loc, val.copy(), problem="max", cardinality_check=False, shard=(0, 2))
+    with pytest.raises(ValueError, match="communicator is rank 0 of 1"):
+        solve_sharded(s, comm)
