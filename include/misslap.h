@@ -50,7 +50,8 @@ typedef struct misslap_options {
     int32_t shard_world;     /* number of shards (1 = single GPU) */
     int32_t rounds_per_sync; /* grid rounds enqueued between host status reads; <= 0 = default */
     int32_t reserved[8];     /* [0]: LDS-tiled bid kernel: 0 = default threshold, < 0 = never, > 0 = minimum K;
-                                [1]: launch shape of k_bid_tiled (tuning knob, see misslap.hip:kTiledShapes);
+                                [1]: launch shape of k_bid_tiled: 0 = chosen by the library from the average segment
+                                     length, k + 1 = shape k of misslap.hip:kTiledShapes (tuning knob);
                                 [2]: full-scan engine: 0 / 1 k_bid_tiled (default), 2 k_scan2d + k_merge2d (experimental);
                                 [3]: multi-GPU shard threshold: 0 = default (the full-scan threshold, 0.3 N), > 0 = minimum K
                                      of a sharded round, < 0 = shard every grid round;

@@ -45,7 +45,9 @@ def _options(problem, eps_start, max_iter, device=None, tail_threshold=None, pro
     if shard is not None:
         o.shard_rank, o.shard_world = int(shard[0]), int(shard[1])
     o.reserved[0] = int(os.environ.get(_ENV_TILED, 0)) if tiled_min_k is None else int(tiled_min_k)
-    o.reserved[1] = int(os.environ.get("MISSLAP_TILED_SHAPE", 0)) if tiled_shape is None else int(tiled_shape)
+    # launch shape of k_bid_tiled: None / env unset = chosen by the library; k = shape k of misslap.hip:kTiledShapes
+    shape = os.environ.get("MISSLAP_TILED_SHAPE") if tiled_shape is None else tiled_shape
+    o.reserved[1] = 0 if shape is None else int(shape) + 1
     o.reserved[2] = int(os.environ.get("MISSLAP_ENGINE", 0)) if engine is None else int(engine)
     o.reserved[3] = int(os.environ.get("MISSLAP_SHARD_MIN_K", 0)) if shard_min_k is None else int(shard_min_k)
     # candidate lines (per-person exact bid shortcut, csrc/device_common.hpp): on by default, 0 = off (A/B runs)

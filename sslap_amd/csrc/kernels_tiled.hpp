@@ -266,6 +266,29 @@ __device__ __forceinline__ int group4_max_i32(int v) {
     return v;
 }
 
+__device__ __forceinline__ double group16_max_f64(double v) {
+    v = __builtin_fmax(v, dppf_f64<kDppXor1>(v));
+    v = __builtin_fmax(v, dppf_f64<kDppXor2>(v));
+    v = __builtin_fmax(v, dppf_f64<kDppHalfMirror>(v));
+    v = __builtin_fmax(v, dppf_f64<kDppMirror>(v));
+    return v;
+}
+__device__ __forceinline__ int group16_max_i32(int v) {
+    v = max(v, dppf_i32<kDppXor1>(v));
+    v = max(v, dppf_i32<kDppXor2>(v));
+    v = max(v, dppf_i32<kDppHalfMirror>(v));
+    v = max(v, dppf_i32<kDppMirror>(v));
+    return v;
+}
+template <int kGL>
+__device__ __forceinline__ double group_max_f64(double v) {
+    return kGL == 4 ? group4_max_f64(v) : kGL == 8 ? group8_max_f64(v) : group16_max_f64(v);
+}
+template <int kGL>
+__device__ __forceinline__ int group_max_i32(int v) {
+    return kGL == 4 ? group4_max_i32(v) : kGL == 8 ? group8_max_i32(v) : group16_max_i32(v);
+}
+
 struct TiledArgs {
     const unsigned *tpk; // tile-major edges, packed 6 B/edge (see k_tile_scatter); every segment starts at an even
                          // position, i.e. on a 12-byte record
@@ -296,7 +319,7 @@ struct TiledArgs {
 // 5 = price look-ups without the arithmetic, 6 = arithmetic without the look-ups.
 template <int kTileThreads, int kTileRows, int kTileBatch, int kTileDepth, int kTileCols, int kLoaders, int ABL = 0, int kGL = 4>
 __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledArgs ta) {
-    static_assert(kGL == 4 || kGL == 8, "lanes per person: 4 or 8");
+    static_assert(kGL == 4 || kGL == 8 || kGL == 16, "lanes per person: 4, 8 or 16 (one DPP row at most)");
     constexpr int kTileGroups = (kTileThreads - kLoaders * kWave) / kGL;  // kGL-lane groups; loader wavefronts own none
     // LDS (in doubles): buffer 0 at [0, kTileCols), the +inf slot at kTileCols, buffer 1 at [kBufDoubles, ...).
     // A price slot must fit the 16-bit field of a packed edge: 2 * kTileCols + 128 < 65536.
@@ -602,11 +625,11 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
     bool mine[kTileRows];
 #pragma unroll
     for (int j = 0; j < kTileRows; ++j) {
-        const double V = kGL == 4 ? group4_max_f64(sv[j]) : group8_max_f64(sv[j]);
+        const double V = group_max_f64<kGL>(sv[j]);
         const int gsel = sv[j] == V ? sg[j] : -1;
-        const int G = kGL == 4 ? group4_max_i32(gsel) : group8_max_i32(gsel);
+        const int G = group_max_i32<kGL>(gsel);
         const double wsel = sg[j] == G ? sw[j] : sv[j];
-        W[j] = kGL == 4 ? group4_max_f64(wsel) : group8_max_f64(wsel);
+        W[j] = group_max_f64<kGL>(wsel);
         mine[j] = person[j] >= 0 && sg[j] == G && G >= 0;  // exactly one lane of the group
         const int pj = max(person[j], 0);
         best[j].x = ta.tcol[max(G, 0)];                    // unconditional loads, used under `mine`

@@ -64,28 +64,31 @@ double now_ms() {
 }
 
 // Rounds with K <= threshold run in the tail kernel.  Break-even against a grid round (two launches: k_bid +
-// k_round_small), measured with tools/sweep_thr.py after every change of either side: C2 32 (249 ms; 64: 253),
-// C3 32..48 (707 ms; 64: 713; 24: 723), C5 64 (5.85 s; 48: 5.97; 96: 6.08) -- a grid round costs more when the
-// price table no longer fits L2.
-constexpr int kDefaultTailThreshold = 40;
-constexpr int kDefaultTailThresholdBig = 64;  // n_cols > kTailBigCols
+// k_round_small, ~12.5 us), measured with tools/sweep_thr.py after every change of either side.  Round 2 (candidate
+// lines, two-pass block mode): C3 24: 706 ms, 40: 669, 64: 656, 96: 642, 128: 643, 192: 652, 256: 656;
+// C5 40: 4.93 s, 64: 4.92, 128: 4.84, 256: 4.96 -- a grid round costs more when the price table no longer fits L2.
+constexpr int kDefaultTailThreshold = 96;
+constexpr int kDefaultTailThresholdBig = 128;  // n_cols > kTailBigCols
 constexpr long long kTailBigCols = 500000;
 constexpr int kDefaultRoundsPerSync = 16;
 constexpr int kRoundsPerSyncLargeK = 2;  // batch length while K > kRoundSmallMax
 constexpr int kMaxGridBlocks = 2048;  // 256 CUs x 8 resident 256-thread blocks
-constexpr int kNumTiledShapes = 8;
+constexpr int kNumTiledShapes = 10;
 // (shape 0 is the default: three loader wavefronts measured 1-2 % faster than one inside a solve)
 // launch shapes of k_bid_tiled: {threads, persons per lane group, persons in flight, loads per segment,
 // prices per LDS tile, loader wavefronts, lanes per person}; see kernels_tiled.hpp
 const int kTiledShapes[kNumTiledShapes][7] = {
     {1024, 4, 2, 2, kTileColsHalf, 3, 4}, {1024, 4, 2, 2, kTileColsHalf, 0, 4}, {1024, 4, 2, 3, kTileColsBig, 0, 4},
     {1024, 4, 2, 2, kTileColsHalf, 1, 4}, {1024, 8, 4, 1, kTileColsHalf, 1, 8}, {1024, 4, 1, 2, kTileColsHalf, 1, 4},
-    {1024, 4, 2, 3, kTileColsHalf, 1, 4}, {1024, 4, 2, 2, kTileColsHalf, 2, 4}};
+    {1024, 4, 2, 3, kTileColsHalf, 1, 4}, {1024, 4, 2, 2, kTileColsHalf, 2, 4},
+    // longer (person, tile) segments: 8 / 16 lanes per person, i.e. 32 / 64 edges per step without the leftover loop
+    {1024, 4, 2, 2, kTileColsHalf, 3, 8}, {1024, 4, 2, 2, kTileColsHalf, 3, 16}};
 #define MISSLAP_FOR_TILED_SHAPES(X)                                                                                  \
     X(0, 1024, 4, 2, 2, kTileColsHalf, 3, 4) X(1, 1024, 4, 2, 2, kTileColsHalf, 0, 4)                                \
     X(2, 1024, 4, 2, 3, kTileColsBig, 0, 4) X(3, 1024, 4, 2, 2, kTileColsHalf, 1, 4)                                 \
     X(4, 1024, 8, 4, 1, kTileColsHalf, 1, 8) X(5, 1024, 4, 1, 2, kTileColsHalf, 1, 4)                                \
-    X(6, 1024, 4, 2, 3, kTileColsHalf, 1, 4) X(7, 1024, 4, 2, 2, kTileColsHalf, 2, 4)
+    X(6, 1024, 4, 2, 3, kTileColsHalf, 1, 4) X(7, 1024, 4, 2, 2, kTileColsHalf, 2, 4)                                \
+    X(8, 1024, 4, 2, 2, kTileColsHalf, 3, 8) X(9, 1024, 4, 2, 2, kTileColsHalf, 3, 16)
 inline size_t tiled_lds_bytes(int tile_cols) {  // see the LDS map in k_bid_tiled; + statistics scratch
     const size_t doubles = tile_cols == kTileColsBig ? (size_t)tile_cols + 2 : 2 * (size_t)tile_cols + 128;
     return doubles * sizeof(double) + 16 * 12;
@@ -529,7 +532,9 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
     }
     const size_t N = (size_t)h->n_rows, M = (size_t)h->n_cols;
     // second, tile-major copy of the edges for the full-scan bid engines (8 B/edge layout, big rounds only)
-    h->tiled_shape = (opt->reserved[1] >= 0 && opt->reserved[1] < kNumTiledShapes) ? opt->reserved[1] : 0;
+    // launch shape: options.reserved[1] = k + 1 picks shape k (tuning); 0 = by the average (person, tile) segment length
+    const bool shape_auto = !(opt->reserved[1] >= 1 && opt->reserved[1] <= kNumTiledShapes);
+    h->tiled_shape = shape_auto ? 0 : opt->reserved[1] - 1;
     const int tiled_opt = opt->reserved[0];  // 0 default, < 0 never, > 0 minimum K for the full-scan engines
     const int engine = opt->reserved[2];     // 0 auto (2-D scan when applicable), 1 tiled kernel, 2 2-D scan
     size_t Mpad = M;
@@ -547,6 +552,13 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
         const bool want2d = engine == 2 && h->world == 1 && (forced || (double)nnz / ((double)N * C2) >= 4.0);
         const int tcols = want2d ? cols2 : kTiledShapes[h->tiled_shape][4];
         const int T = want2d ? C2 : (int)((M + tcols - 1) / tcols);
+        if (shape_auto && !want2d) {
+            // lanes per person by the average (person, tile) segment: a step covers 2 edges x 2 loads per lane without
+            // entering the leftover loop, whose every pass costs a memory latency (C3: 10 edges per segment -> 4
+            // lanes, C4: 20 -> 8 lanes, C2: 50 -> 16 lanes)
+            const double seg = (double)nnz / ((double)N * T);
+            h->tiled_shape = seg <= 14.0 ? 0 : seg <= 28.0 ? 8 : 9;
+        }
         const int rb = want2d ? rb2 : kTileRB;
         const long long nblk = ((long long)N + rb - 1) / rb;
         const long long L = nblk * T * rb;

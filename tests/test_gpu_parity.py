@@ -641,3 +641,29 @@ def test_rccl_world1_smoke(gpu_lib):
     s = from_sparse(loc, val.copy(), problem="max", cardinality_check=False, shard=(0, 2))
     with pytest.raises(ValueError, match="communicator is rank 0 of 1"):
         solve_sharded(s, comm)
+
+
+@pytest.mark.parametrize("shape", [0, 4, 8, 9])
+@pytest.mark.parametrize("spec,prob", [
+    (dict(kind="sparse", n=6000, m=40000, density=0.001), "max"),           # ~10 edges per (person, tile) segment
+    (dict(kind="sparse", n=5000, m=25000, density=0.004, ints=5), "min"),   # ~33 edges per segment, ties
+    (dict(kind="sparse", n=4200, m=12000, density=0.01), "max"),            # ~60 edges per segment
+])
+def test_tiled_kernel_shapes_round_by_round(spec, prob, shape, gpu_lib):
+    """Every lanes-per-person variant of k_bid_tiled (4 / 8 / 16 lanes: shapes 0, 4 / 8, 9) on short, medium and long
+    (person, tile) segments, forced for every grid round: full state vs the oracle."""
+    loc, val = cases.synth_inputs(spec)
+    for r in [1, 2, 3, 5, 8, 13, 30, 80]:
+        o = orc.from_sparse(loc, val.copy(), problem=prob, max_iter=r, cardinality_check=False)
+        o.solve()
+        so = o.state()
+        g = from_sparse(loc, val.copy(), problem=prob, max_iter=r, cardinality_check=False, tail_threshold=0,
+                        tiled_min_k=1, engine=1, tiled_shape=shape)
+        g.solve()
+        assert g.gpu["tiled_active"] == 1
+        sg = g.state()
+        assert sg["its"] == so["its"] and sg["K"] == so["K"], r
+        assert np.array_equal(sg["U"], so["U"]), r
+        assert np.array_equal(sg["p"].view(np.uint64), so["p"].view(np.uint64)), r
+        assert np.array_equal(sg["p2o"], so["p2o"]) and np.array_equal(sg["o2p"], so["o2p"]), r
+        assert g.gpu["edges_scanned"] == o.extra["edges_scanned"], r

@@ -31,4 +31,7 @@ print(json.dumps({
     "bids": g["bids_made"], "cand_hits": g["cand_hits"], "hit_rate": round(g["cand_hits"] / max(g["bids_made"], 1), 3),
     "edges_scanned": g["edges_scanned"], "cand_edges": g["cand_edges"],
     "fullscan_us": round(1e3 * g.get("fullscan_ms", 0) / max(g.get("fullscan_launches", 0), 1), 1),
+    "tiled": dict(launches=g.get("tiled_launches"), ms=round(g.get("tiled_ms", 0), 3), edges=g.get("tiled_edges"),
+                  frac=round(g.get("tiled_edges", 0) * 8 / max(g.get("tiled_ms", 0), 1e-9) / 1e6 / 8000, 4)),
+    "k_bid": dict(launches=g.get("bid_launches"), ms=round(g.get("bid_ms", 0), 3), edges=g.get("bid_edges")),
 }), flush=True)
