@@ -261,6 +261,12 @@ int misslap_device_info(int32_t device, char *name, int32_t name_len, int32_t *c
 int misslap_hopcroft_karp(const int32_t *loc, int64_t nnz, int32_t n_rows, int32_t n_cols, int32_t *size,
                           int32_t *left_pairings, int32_t *right_pairings);
 
+/* The same maximum matching computed on the GPU (BFS-layered, csrc/kernels_matching.hpp): equal cardinality -- the only
+ * thing that reaches the auction path (auction_.pyx:565, :611) -- but not necessarily the same pairings.  loc is a
+ * host array; *phases (may be NULL) receives the number of augmentation phases.  Needs a GPU. */
+int misslap_matching_gpu(const int32_t *loc, int64_t nnz, int32_t n_rows, int32_t n_cols, int32_t device, int32_t *size,
+                         int32_t *left_pairings, int32_t *right_pairings, int32_t *phases);
+
 const char *misslap_last_error(void);
 int misslap_abi_version(void);
 

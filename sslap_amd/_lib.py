@@ -98,6 +98,7 @@ SYMBOLS = {
     "misslap_solve_sharded": (C.c_int, [_VP, _VP, _VP, C.POINTER(Meta)]),
     "misslap_drive_sharded": (C.c_int, [C.POINTER(RoundOps), _VP]),
     "misslap_hopcroft_karp": (C.c_int, [_VP, C.c_int64, C.c_int32, C.c_int32, _I32P, _VP, _VP]),
+    "misslap_matching_gpu": (C.c_int, [_VP, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _I32P, _VP, _VP, _I32P]),
     "misslap_last_error": (C.c_char_p, []),
     "misslap_abi_version": (C.c_int, []),
 }

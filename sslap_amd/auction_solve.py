@@ -266,7 +266,10 @@ def _cardinality(loc, n_rows, n_cols):
     """Maximum-matching cardinality for the optional feasibility guard (reference: c_hopcroft_solve,
     feasibility_.pyx:95-225, called at auction_.pyx:562-566 / :608-612).  Only the cardinality reaches
     the auction path; the matching runs in the library (host C++ Hopcroft-Karp, SURVEY.md 8f #3)."""
-    from .check_feasible import cardinality
+    from .check_feasible import cardinality, matching_gpu
+    # large graphs: the BFS-layered GPU matcher (same cardinality); small ones are faster on the host
+    if loc.shape[0] >= int(os.environ.get("MISSLAP_MATCHING_GPU_MIN_NNZ", 2_000_000)):
+        return matching_gpu(loc, n_rows, n_cols)["size"]
     return cardinality(loc, n_rows, n_cols)
 
 

@@ -22,6 +22,21 @@ def _solve(loc, n_rows, n_cols):
     return dict(size=int(size.value), left_pairings=left, right_pairings=right)
 
 
+def matching_gpu(loc, n_rows, n_cols, device=None):
+    """Maximum matching on the GPU (misslap_matching_gpu: BFS-layered, one launch per layer).  Same cardinality as
+    `hopcroft_solve` / the reference; the pairings are a maximum matching, not necessarily the reference's."""
+    import os
+    loc = np.ascontiguousarray(loc, dtype=np.int32)
+    left = np.empty(n_rows, dtype=np.int32)
+    right = np.empty(n_cols, dtype=np.int32)
+    size, phases = C.c_int32(), C.c_int32()
+    dev = int(os.environ.get("MISSLAP_DEVICE", 0)) if device is None else int(device)
+    _lib.check(_lib.load().misslap_matching_gpu(loc.ctypes.data_as(C.c_void_p), int(loc.shape[0]), int(n_rows),
+                                                int(n_cols), dev, C.byref(size), left.ctypes.data_as(C.c_void_p),
+                                                right.ctypes.data_as(C.c_void_p), C.byref(phases)))
+    return dict(size=int(size.value), left_pairings=left, right_pairings=right, phases=int(phases.value))
+
+
 def cardinality(loc, n_rows, n_cols):
     """Size of a maximum matching of the graph `loc` (int[nnz, 2], rows ascending) -- what reaches the auction
     front-end (auction_.pyx:562-566, :608-612)."""

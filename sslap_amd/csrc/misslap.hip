@@ -29,6 +29,7 @@
 #include "kernels_tail.hpp"
 #include "host_matching.hpp"
 #include "host_comm.hpp"
+#include "kernels_matching.hpp"
 #include "kernels_tiled.hpp"
 #include "kernels_scan2d.hpp"
 
@@ -762,6 +763,93 @@ MISSLAP_API int misslap_hopcroft_karp(const int32_t *loc, int64_t nnz, int32_t n
     }
     return MISSLAP_OK;
 }
+// The same guard on the GPU (kernels_matching.hpp): BFS-layered maximum matching; the cardinality equals the host
+// version's (and the reference's), the pairings are a maximum matching but not necessarily the same one.
+MISSLAP_API int misslap_matching_gpu(const int32_t *loc, int64_t nnz, int32_t n_rows, int32_t n_cols, int32_t device,
+                                     int32_t *size, int32_t *left_pairings, int32_t *right_pairings, int32_t *phases) {
+    if (!size || nnz < 0 || n_rows < 0 || n_cols < 0 || (nnz > 0 && !loc)) return fail(MISSLAP_ERR_INVALID, "bad argument");
+    if (nnz >= (int64_t)0x7fffffff) return fail(MISSLAP_ERR_INVALID, "nnz must be < 2^31 (int32 row pointers)");
+    for (int64_t k = 0; k < nnz; ++k) {
+        const int32_t i = loc[2 * k], j = loc[2 * k + 1];
+        if (i < 0 || i >= n_rows || j < 0 || j >= n_cols)
+            return fail(MISSLAP_ERR_INVALID, "loc entry %lld = (%d, %d) outside %d x %d", (long long)k, i, j, n_rows, n_cols);
+        if (k && i < loc[2 * (k - 1)]) return fail(MISSLAP_ERR_INVALID, "loc rows must be sorted in ascending order");
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(MISSLAP_ERR_NO_DEVICE, "no HIP device available: misslap_matching_gpu has no CPU fallback "
+                    "(misslap_hopcroft_karp is the host matcher)");
+    if (device < 0 || device >= ndev) return fail(MISSLAP_ERR_INVALID, "device %d out of range", device);
+    HIP_TRY(hipSetDevice(device));
+    *size = 0;
+    if (phases) *phases = 0;
+    if (left_pairings) std::fill(left_pairings, left_pairings + n_rows, -1);
+    if (right_pairings) std::fill(right_pairings, right_pairings + n_cols, -1);
+    if (nnz == 0 || n_rows == 0) return MISSLAP_OK;
+    DevScratch tmp;
+    int rc;
+    int *d_loc = nullptr, *d_err = nullptr;
+    MatchArgs a{};
+    a.n_rows = n_rows;
+    a.n_cols = n_cols;
+    int *row_ptr = nullptr, *col = nullptr;
+    if ((rc = tmp.alloc(&d_loc, (size_t)nnz * 2))) return rc;
+    if ((rc = tmp.alloc(&row_ptr, (size_t)n_rows + 1))) return rc;
+    if ((rc = tmp.alloc(&col, (size_t)nnz))) return rc;
+    if ((rc = tmp.alloc(&a.match_row, (size_t)n_rows))) return rc;
+    if ((rc = tmp.alloc(&a.match_col, (size_t)n_cols))) return rc;
+    if ((rc = tmp.alloc(&a.level, (size_t)n_rows))) return rc;
+    if ((rc = tmp.alloc(&a.root, (size_t)n_rows))) return rc;
+    if ((rc = tmp.alloc(&a.pred_col, (size_t)n_cols))) return rc;
+    if ((rc = tmp.alloc(&a.end_of_root, (size_t)n_rows))) return rc;
+    if ((rc = tmp.alloc(&a.counters, 4))) return rc;
+    if ((rc = tmp.alloc(&d_err, 1))) return rc;
+    a.row_ptr = row_ptr;
+    a.col = col;
+    hipStream_t st = nullptr;  // the default stream: this entry point is synchronous
+    HIP_TRY(hipMemcpyAsync(d_loc, loc, sizeof(int) * 2 * (size_t)nnz, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(d_err, 0, sizeof(int), st));
+    const int gE = blocks_for(nnz, 256 * 4), gV = blocks_for(std::max(n_rows, n_cols), 256), gW = blocks_for(n_rows, 4);
+    hipLaunchKernelGGL(k_m_row_ptr, dim3(gE), dim3(256), 0, st, d_loc, (long long)nnz, n_rows, row_ptr, col, d_err);
+    hipLaunchKernelGGL(k_m_init, dim3(gV), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_m_greedy, dim3(gV), dim3(256), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    int nph = 0;
+    for (;;) {  // phases (:199-211)
+        HIP_TRY(hipMemsetAsync(a.counters, 0, 4 * sizeof(int), st));
+        hipLaunchKernelGGL(k_m_phase_init, dim3(gV), dim3(256), 0, st, a);
+        int cnt[4] = {0, 0, 0, 0};
+        bool augmented = false;
+        for (int L = 0; L <= n_rows; ++L) {
+            HIP_TRY(hipMemsetAsync(a.counters + 1, 0, sizeof(int), st));
+            hipLaunchKernelGGL(k_m_bfs_layer, dim3(gW), dim3(256), 0, st, a, L);
+            HIP_TRY(hipMemcpyAsync(cnt, a.counters, sizeof(cnt), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if (cnt[0] > 0) {  // this layer reached free columns: flip one shortest path per tree
+                hipLaunchKernelGGL(k_m_augment, dim3(blocks_for(n_rows, 256)), dim3(256), 0, st, a);
+                augmented = true;
+                break;
+            }
+            if (cnt[1] == 0) break;  // the layering is exhausted: no augmenting path is left
+        }
+        HIP_TRY(hipGetLastError());
+        if (!augmented) break;
+        ++nph;
+    }
+    HIP_TRY(hipMemsetAsync(a.counters + 2, 0, sizeof(int), st));
+    hipLaunchKernelGGL(k_m_count, dim3(blocks_for(n_rows, 256)), dim3(256), 0, st, a);
+    int out[4] = {0, 0, 0, 0}, err = 0;
+    HIP_TRY(hipMemcpyAsync(out, a.counters, sizeof(out), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&err, d_err, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (left_pairings) HIP_TRY(hipMemcpyAsync(left_pairings, a.match_row, sizeof(int) * (size_t)n_rows, hipMemcpyDeviceToHost, st));
+    if (right_pairings) HIP_TRY(hipMemcpyAsync(right_pairings, a.match_col, sizeof(int) * (size_t)n_cols, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (err) return fail(MISSLAP_ERR_INVALID, "loc rows must be sorted in ascending order");
+    *size = out[2];
+    if (phases) *phases = nph;
+    return MISSLAP_OK;
+}
+
 MISSLAP_API const char *misslap_last_error(void) { return g_err.c_str(); }
 
 MISSLAP_API int misslap_device_info(int32_t device, char *name, int32_t name_len, int32_t *compute_units,

@@ -77,3 +77,76 @@ def test_front_end_rejects_infeasible_input_with_the_reference_text(built_lib):
     assert card == 30
     with pytest.raises(ValueError, match=rf"Maximum matching possible only involves {card} out of {n_true} rows"):
         from_sparse(loc, val, problem="max", cardinality_check=True)
+
+
+# ---- the GPU matcher (misslap_matching_gpu, csrc/kernels_matching.hpp): same cardinality, any maximum matching ------
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(cases.MATCH_CASES))
+def test_gpu_matching_cardinality_matches_reference(name, golden_matching, gpu_lib):
+    from sslap_amd.check_feasible import matching_gpu
+    man, _ = golden_matching
+    spec, entry = cases.MATCH_CASES[name]
+    loc = cases.matching_graph(spec)
+    g = man["cases"][name]
+    res = matching_gpu(loc, g["n_rows"], g["n_cols"])
+    assert res["size"] == g["size"]  # the reference's cardinality (captured from sslap.hopcroft_solve)
+    _valid_matching(loc, res)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(6))
+def test_gpu_matching_equals_scipy_on_random_graphs(seed, gpu_lib):
+    from scipy.sparse import csr_matrix
+    from scipy.sparse.csgraph import maximum_bipartite_matching
+    from sslap_amd.check_feasible import matching_gpu
+    spec = dict(kind="thinned", n=4500 + 370 * seed, m=5000 + 500 * seed, density=0.0006, seed=20 + seed, keep_mod=2)
+    loc = cases.matching_graph(spec)
+    n, m = spec["n"], spec["m"]
+    res = matching_gpu(loc, n, m)
+    g = csr_matrix((np.ones(loc.shape[0], np.int8), (loc[:, 0], loc[:, 1])), shape=(n, m))
+    assert res["size"] == int((maximum_bipartite_matching(g, perm_type="column") >= 0).sum())
+    assert res["size"] == cardinality(loc, n, m)  # ... and the host Hopcroft-Karp
+    _valid_matching(loc, res)
+
+
+@pytest.mark.gpu
+def test_gpu_matching_at_200k_rows(gpu_lib):
+    """200 000 rows against scipy -- a planted perfect matching, an infeasible thinned graph
+    (many augmentation phases), a graph with empty rows, and a path graph (one long augmenting chain)."""
+    from scipy.sparse import csr_matrix
+    from scipy.sparse.csgraph import maximum_bipartite_matching
+    from sslap_amd.check_feasible import matching_gpu
+    n = 200_000
+    loc, _ = synth.gen_sparse(n, n, 0.00003, seed=5)  # ~7 edges per row, perfect matching planted
+    res = matching_gpu(loc, n, n)
+    assert res["size"] == n and sorted(res["left_pairings"].tolist()) == list(range(n))
+    thin = cases.matching_graph(dict(kind="thinned", n=n, m=n, density=0.00002, seed=9, keep_mod=2))
+    thin = thin[thin[:, 0] % 17 != 3]  # some rows lose all their edges
+    res = matching_gpu(thin, n, n)
+    g = csr_matrix((np.ones(thin.shape[0], np.int8), (thin[:, 0], thin[:, 1])), shape=(n, n))
+    want = int((maximum_bipartite_matching(g, perm_type="column") >= 0).sum())
+    assert res["size"] == want and want < n
+    left, right = res["left_pairings"], res["right_pairings"]
+    m_rows = np.nonzero(left >= 0)[0]
+    assert len(m_rows) == want and len(np.unique(left[m_rows])) == want and np.array_equal(right[left[m_rows]], m_rows)
+    key = set((thin[:, 0].astype(np.int64) * n + thin[:, 1]).tolist())
+    assert all(int(i) * n + int(left[i]) in key for i in m_rows[:: max(1, want // 5000)])
+    # path graph: row k -> columns k, k + 1 (the last row only k), every row shifted so that greedy gets it wrong
+    k = 20_000
+    i = np.repeat(np.arange(k, dtype=np.int32), 2)
+    j = np.stack([np.arange(1, k + 1, dtype=np.int32), np.arange(k, dtype=np.int32)], axis=1).reshape(-1)
+    path = np.stack([i, j], axis=1)
+    path = path[~((path[:, 0] == k - 1) & (path[:, 1] == k))]  # the last row keeps only column k - 1
+    res = matching_gpu(path, k, k + 1)
+    assert res["size"] == k
+
+
+@pytest.mark.gpu
+def test_front_end_uses_gpu_matcher_for_large_graphs(gpu_lib, monkeypatch):
+    monkeypatch.setenv("MISSLAP_MATCHING_GPU_MIN_NNZ", "1")
+    spec = dict(kind="narrow", n=50, m=50, density=0.1, seed=3, m_eff=30)
+    loc = cases.matching_graph(spec)
+    with pytest.raises(ValueError, match=r"Maximum matching possible only involves 30 out of 50 rows"):
+        from_sparse(loc, np.ones(loc.shape[0]), problem="max", cardinality_check=True)
+    loc, val = synth.gen_sparse(300, 300, 0.05, seed=2)
+    from_sparse(loc, val, problem="max", cardinality_check=True).solve()
