@@ -52,7 +52,8 @@ typedef struct misslap_options {
     int32_t reserved[8];     /* [0]: LDS-tiled bid kernel: 0 = default threshold, < 0 = never, > 0 = minimum K;
                                 [1]: launch shape of k_bid_tiled: 0 = chosen by the library from the average segment
                                      length, k + 1 = shape k of misslap.hip:kTiledShapes (tuning knob);
-                                [2]: full-scan engine: 0 / 1 k_bid_tiled (default), 2 k_scan2d + k_merge2d (experimental);
+                                [2]: != 0 together with [0] > 0: build the tile-major copy whatever the size and
+                                     density of the problem (tests);
                                 [3]: multi-GPU shard threshold: 0 = default (the full-scan threshold, 0.3 N), > 0 = minimum K
                                      of a sharded round, < 0 = shard every grid round;
                                 [4]: 1 = no candidate lines (every bid scans its whole row; A/B timing, parity tests);
@@ -96,10 +97,9 @@ typedef struct misslap_meta {
     int64_t tiled_launches;      /* launches of the LDS-tiled bid kernel (k_bid_tiled), no-ops included */
     double tiled_ms;
     uint64_t tiled_edges;
-    int32_t tiled_active;        /* full-scan engine for big rounds: 0 none (k_bid only), 1 k_bid_tiled,
-                                    2 k_scan2d + k_merge2d (the tiled_* counters then refer to k_scan2d) */
+    int32_t tiled_active;        /* full-scan engine for big rounds: 0 none (k_bid only), 1 k_bid_tiled */
     int32_t tiled_min_K;         /* rounds with K >= this use it */
-    int64_t merge_launches;      /* k_merge2d */
+    int64_t merge_launches;      /* (unused: the 2-D scan engine of round 1 was removed) */
     double merge_ms;
     uint64_t shard_edges;        /* multi-GPU: edges scanned in sharded rounds (this rank's share); the rest of
                                     edges_scanned is replicated work, identical on every rank */

@@ -235,72 +235,6 @@ __device__ __forceinline__ Top2 top2_wave_reduce(const Top2 &x) {
     return r;
 }
 
-// ---- the bid of one person, computed by one wavefront (auction_.pyx:339-365) ----------------------
-// Row [s, e) of the CSR.  Per lane: running (v = best value, g = its stored index, w = second
-// best value counting multiplicity) over its elements in ascending stored index, with the
-// reference's ">=" rule (a later equal value replaces the best, :351); the lane also remembers the
-// (col, cost) of its own best element.  Lanes are merged by top2_wave_reduce; the winning element's
-// (col, cost) is then read from the lane that owns it.  Returns bid key and the chosen object in
-// (key, obj), uniform over the wavefront.
-template <class E, class S = NoStamp>
-__device__ __forceinline__ void wave_bid(const E &ed, const double *price, int s, int e, double eps,
-                                         unsigned long long &key, int &obj, int &err, const S &stamp = S()) {
-    const int lane = threadIdx.x & (kWave - 1);
-    const double ninf = -__builtin_huge_val();
-    Top2 x;
-    x.v = ninf;
-    x.w = ninf;
-    x.g = -1;
-    int c1 = 0;
-    double a1 = 0.0;
-    for (int base = s; base < e; base += 4 * kWave) {
-        int c[4];
-        double a[4], pr[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) ed.load(min(base + u * kWave + lane, e - 1), c[u], a[u]);  // unconditional
-        stamp(1);  // edges landed
-#pragma unroll
-        for (int u = 0; u < 4; ++u) pr[u] = price[c[u]];
-        stamp(2);  // prices landed
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {  // branch-free: a masked-off element has value -inf and changes nothing
-            const int g = base + u * kWave + lane;
-            const bool ok = g < e;
-            const double v = ok ? a[u] - pr[u] : ninf;           // vi = cost - p[j]   (:350)
-            const bool ge = ok & (v >= x.v);                     // :351
-            x.w = __builtin_fmax(x.w, __builtin_fmin(v, x.v));    // :353 / :357-358
-            x.v = __builtin_fmax(x.v, v);
-            x.g = ge ? g : x.g;
-            c1 = ge ? c[u] : c1;
-            a1 = ge ? a[u] : a1;
-        }
-    }
-    // winner first (see wave_bid_rec): a single lane holding the largest high word holds the row's best
-    const int hi = __double2hiint(x.v);
-    const int k = hi ^ ((hi >> 31) & 0x7fffffff);
-    const int kmax = wave_max_i32(k);
-    const unsigned long long cand = __ballot(k == kmax);
-    int src;
-    double W;
-    if (__popcll(cand) == 1) {  // wave-uniform
-        src = __ffsll((long long)cand) - 1;
-        W = wave_max_f64(lane == src ? x.w : x.v);
-    } else {
-        const int g_mine = x.g;
-        const Top2 t2 = top2_wave_reduce(x);
-        src = __ffsll((long long)__ballot(g_mine == t2.g)) - 1;
-        W = t2.w;
-    }
-    stamp(3);  // reduction done
-    const int col = __builtin_amdgcn_readlane(c1, src);
-    const double cost = readlane_f64(a1, src);
-    stamp(4);
-    const double bid = (cost - W) + eps;  // bbest = costbest - wi + eps   (:360)
-    if (bid_is_bad(bid)) err |= kErrNegativeBid;
-    key = bid_to_key(bid);
-    obj = col;
-}
-
 // Per-object record used by the latency-bound tail kernel: one 16-byte gather brings the price AND the
 // current owner and the start of the owner's CSR row, so the next bidder of an eviction chain (the evicted
 // owner) and the address of its row are known without two further dependent loads (o2p, row_ptr).
@@ -310,137 +244,6 @@ struct __attribute__((aligned(16))) PriceRec {
     int owner;   // == o2p[j]
     int ostart;  // row_ptr[owner] (undefined when owner == -1)
 };
-
-// wave_bid with the record gather.  The row end (*e_ptr) may arrive after the edge loads have been issued:
-// the first four 64-edge chunks are loaded unconditionally (the edge arrays are padded) and masked with the
-// row end afterwards.  Ordering against the caller's own stores of the previous round (chain mode): the
-// records are gathered only after the edge loads have returned, the edge loads were issued after those
-// stores, and a wavefront's vector memory operations complete in issue order -- so the stores have been
-// written before any record is read (the same CU-level coherence the barrier-separated rounds rely on).
-// Chain mode (one bidder per round): the next bidder is the evicted owner and its row address comes with the
-// winning price record, so its first 256 edges and its row end can be requested as soon as the winning LANE is
-// known -- before the second-best reduction, the bid and the record store of the current round.
-struct NoRowPrefetch {
-    static constexpr bool kOn = false;
-    int c[4];
-    double a[4];
-    int e;
-    template <class E>
-    __device__ __forceinline__ void issue(const E &, const int *, int, int, int) {}
-};
-struct RowPrefetch {
-    static constexpr bool kOn = true;
-    int c[4], nc[4];    // this round's first four 64-edge chunks (already requested) / the next round's
-    double a[4], na[4];
-    int e, ne;          // row ends
-    const int *row_ptr;
-    template <class E>
-    __device__ __forceinline__ void issue(const E &ed, const int *, int prev_owner, int pstart_next, int lane) {
-        // prev_owner == -1 (nobody evicted, the chain ends): row_ptr[0] and a stale-but-valid row start are read
-        // and never used
-#pragma unroll
-        for (int u = 0; u < 4; ++u) ed.load_nt(pstart_next + u * kWave + lane, nc[u], na[u]);
-        ne = row_ptr[prev_owner + 1];
-    }
-    __device__ __forceinline__ void advance() {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            c[u] = nc[u];
-            a[u] = na[u];
-        }
-        e = ne;
-    }
-};
-
-template <class E, class S = NoStamp, class PF = NoRowPrefetch>
-__device__ __forceinline__ void wave_bid_rec(const E &ed, const PriceRec *rec, int s, const int *e_ptr, double eps,
-                                             unsigned long long &key, int &obj, int &prev, int &pstart,
-                                             int &row_end, int &err, const S &stamp = S(), PF *pf = nullptr) {
-    const int lane = threadIdx.x & (kWave - 1);
-    const double ninf = -__builtin_huge_val();
-    Top2 x;
-    x.v = ninf;
-    x.w = ninf;
-    x.g = -1;
-    int c1 = 0, o1 = -1, os1 = 0;
-    double a1 = 0.0;
-    int c[4];
-    double a[4];
-    int e;
-    if (PF::kOn) {  // requested during the previous round
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            c[u] = pf->c[u];
-            a[u] = pf->a[u];
-        }
-        e = pf->e;
-    } else {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) ed.load_nt(s + u * kWave + lane, c[u], a[u]);  // speculative: e not known yet
-        e = *e_ptr;
-    }
-    row_end = e;
-    for (int base = s; base < e; base += 4 * kWave) {
-        if (base != s) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) ed.load_nt(min(base + u * kWave + lane, e - 1), c[u], a[u]);
-        }
-        stamp(1);  // edges landed
-        PriceRec r[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const bool ok = base + u * kWave + lane < e;
-            if (!ok) c[u] = -1;
-            r[u] = rec[ok ? c[u] : 0];
-        }
-        stamp(2);  // records landed
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {  // branch-free: a masked-off element has value -inf and changes nothing
-            const bool ok = c[u] >= 0;
-            const double v = ok ? a[u] - r[u].price : ninf;  // vi = cost - p[j]   (:350)
-            const bool ge = ok & (v >= x.v);                 // :351
-            x.w = __builtin_fmax(x.w, __builtin_fmin(v, x.v));  // :353 / :357-358
-            x.v = __builtin_fmax(x.v, v);
-            x.g = ge ? base + u * kWave + lane : x.g;
-            c1 = ge ? c[u] : c1;
-            a1 = ge ? a[u] : a1;
-            o1 = ge ? r[u].owner : o1;
-            os1 = ge ? r[u].ostart : os1;
-        }
-    }
-    // Winner first: if exactly one lane holds the largest HIGH WORD of the per-lane best values, that lane
-    // holds the row's best element (no tie is possible), so one 32-bit wave maximum replaces the 64-bit value
-    // and index passes; only the second-best value still needs a 64-bit reduction.
-    const int hi = __double2hiint(x.v);
-    const int k = hi ^ ((hi >> 31) & 0x7fffffff);  // signed order of k == order of the doubles' high words
-    const int kmax = wave_max_i32(k);
-    const unsigned long long cand = __ballot(k == kmax);
-    int src;
-    double W;
-    if (__popcll(cand) == 1) {  // wave-uniform
-        src = __ffsll((long long)cand) - 1;
-        prev = __builtin_amdgcn_readlane(o1, src);
-        pstart = __builtin_amdgcn_readlane(os1, src);
-        if (PF::kOn) pf->issue(ed, e_ptr, prev, pstart, lane);
-        W = wave_max_f64(lane == src ? x.w : x.v);
-    } else {
-        const int g_mine = x.g;
-        const Top2 t2 = top2_wave_reduce(x);
-        src = __ffsll((long long)__ballot(g_mine == t2.g)) - 1;
-        W = t2.w;
-        prev = __builtin_amdgcn_readlane(o1, src);
-        pstart = __builtin_amdgcn_readlane(os1, src);
-        if (PF::kOn) pf->issue(ed, e_ptr, prev, pstart, lane);
-    }
-    stamp(3);
-    const int col = __builtin_amdgcn_readlane(c1, src);
-    const double cost = readlane_f64(a1, src);
-    stamp(4);
-    const double bid = (cost - W) + eps;  // bbest = costbest - wi + eps   (:360)
-    if (bid_is_bad(bid)) err |= kErrNegativeBid;
-    key = bid_to_key(bid);
-    obj = col;
-}
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
 __device__ __forceinline__ unsigned long long lanemask_lt() {
@@ -719,8 +522,13 @@ __device__ __forceinline__ void cand_build(int2 *cand, int person, const CandBui
     }
 }
 
-// The bid of one person by a FULL scan of its row [s, e) by one wavefront (auction_.pyx:339-365), as wave_bid /
-// wave_bid_rec; `ba` receives what the (re)build of the person's candidate line needs.  `e` may still be in flight
+// The bid of one person by a FULL scan of its row [s, e) by one wavefront (auction_.pyx:339-365):
+// Per lane a running (v = best value, g = its stored index, w = second best value counting multiplicity) over its
+// elements in ascending stored index, with the reference's ">=" rule (a later equal value replaces the best, :351);
+// the lane also remembers the (col, cost, owner) of its own best element.  Lanes are merged winner-first: if exactly
+// one lane holds the largest HIGH WORD of the per-lane best values, that lane holds the row's best element (no tie
+// is possible), so one 32-bit wave maximum replaces the 64-bit value and index passes (top2_wave_reduce otherwise);
+// the per-lane scan; `ba` receives what the (re)build of the person's candidate line needs.  `e` may still be in flight
 // when the function is entered: the first four chunks are requested before it is used (the edge arrays are padded).
 // kPre: the first four chunks were requested earlier and arrive in `pre`.  kNT: the row is read once and must not
 // evict the price records from L2 (tail kernel).
@@ -782,7 +590,7 @@ __device__ __forceinline__ void wave_bid_full(const E &ed, const Src &src, int s
         for (int u = 0; u < 4; ++u) load(min(base + u * kWave + lane, e - 1), c[u], a[u]);
         chunk(base, std::false_type{});
     }
-    // winner first (see wave_bid_rec)
+    // winner first
     const int hi = __double2hiint(x.v);
     const int k = hi ^ ((hi >> 31) & 0x7fffffff);
     const int kmax = wave_max_i32(k);

@@ -173,13 +173,6 @@ __global__ __launch_bounds__(1024) void k_scan_apply(const int *in, long long n,
     }
 }
 
-// segment table entry = {start (even), real length}
-__global__ __launch_bounds__(256) void k_pack_seg(const int *start, const int *len, long long n, int2 *seg) {
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride)
-        seg[k] = make_int2(start[k], len[k]);
-}
-
 // k_bid_tiled's segment table, 4 B per segment: start | (real length is odd).  Segments are laid out in table
 // order and padded to an even length, so the next entry's start gives the padded length; n + 1 entries.
 __global__ __launch_bounds__(256) void k_pack_seg4(const int *start, const int *len, long long n, int *seg4) {
@@ -188,8 +181,7 @@ __global__ __launch_bounds__(256) void k_pack_seg4(const int *start, const int *
         seg4[k] = start[k] | (k < n ? (len[k] & 1) : 0);
 }
 
-// pass 3: copy every edge to its tile-major position.  tcol == nullptr (k_scan2d): plain {col, fp32} entries.
-// Otherwise (k_bid_tiled) the copy is PACKED to 6 bytes per edge, two edges per 12-byte record
+// pass 3: copy every edge to its tile-major position.  The copy is PACKED to 6 bytes per edge, two edges per 12-byte record
 //   { u16 slot0, u16 slot1, f32 val0, f32 val1 }
 // where slot = (col - tile * cols) + (tile & 1) * buf_stride is the index of the edge's price inside the kernel's
 // LDS buffers (a look-up is `slot << 3`, no column arithmetic), and the real column goes to the parallel array

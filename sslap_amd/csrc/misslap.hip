@@ -31,7 +31,6 @@
 #include "host_comm.hpp"
 #include "kernels_matching.hpp"
 #include "kernels_tiled.hpp"
-#include "kernels_scan2d.hpp"
 
 using namespace misslap;
 
@@ -97,7 +96,7 @@ inline size_t tiled_lds_bytes(int tile_cols) {  // see the LDS map in k_bid_tile
 
 struct ProfRec {
     hipEvent_t start, stop;
-    int kind;        // 0 = k_bid, 1 = k_tail, 2 = k_bid_tiled / k_scan2d, 3 = k_merge2d
+    int kind;        // 0 = k_bid, 1 = k_tail, 2 = k_bid_tiled
     int fullscan;    // bid launch with K == n_rows
     int launch_idx;  // index into launch_edges (kind 0)
 };
@@ -135,17 +134,11 @@ struct misslap_solver {
     int2 *tiled = nullptr;
     int *seg4 = nullptr;  // k_bid_tiled's 4-byte segment table
     int *tcol = nullptr;  // real columns of the tile-major copy (k_bid_tiled stores LDS offsets in `tiled`)
-    int2 *seg = nullptr;
     int n_tiled = 0;  // entries of `tiled` including the padding entries
     int T = 0;
     bool tiled_ok = false;
     int tiled_min_K = 0;
     int tiled_shape = 0;  // index into kShapes of launch_bid_tiled
-    // 2-D full-scan engine (kernels_scan2d.hpp): row blocks x column slices, partial top-2s merged per bidder
-    bool scan2d = false;
-    int s2_C = 0, s2_R = 0, s2_rb = 0, s2_cols = 0;
-    double *part_v = nullptr, *part_w = nullptr;
-    int *part_g = nullptr;
     Ctl *h_ctl = nullptr;  // pinned mirror
     // scalar solver state (auction_.pyx:180-187)
     float eps = 0, target_eps = 0, theta = 0, start_eps = 0;
@@ -293,35 +286,6 @@ int launch_bid_tiled(misslap_solver *h) {
     return MISSLAP_OK;
 }
 
-int launch_bid_scan2d(misslap_solver *h) {
-    RoundArgs a = round_args(h);
-    Scan2dArgs sa{h->tiled, h->seg, h->s2_C, h->s2_rb, h->s2_cols, h->tiled_min_K, h->n_tiled,
-                  h->part_v, h->part_w, h->part_g};
-    ProfRec *pr = nullptr, *pm = nullptr;
-    if (h->profile) {
-        if (h->launch_idx >= h->launch_edges_cap)
-            return fail(MISSLAP_ERR_STATE, "profile buffer exhausted (%d bid launches)", h->launch_idx);
-        pr = prof_next(h, 2);
-        if (!pr) return fail(MISSLAP_ERR_HIP, "hipEventCreate failed");
-        pr->fullscan = h->phase_fresh;
-        pr->launch_idx = a.launch_idx = h->launch_idx++;
-        HIP_TRY(hipEventRecord(pr->start, h->stream));
-    }
-    const size_t lds = (size_t)(h->s2_cols + 2) * sizeof(double);
-    hipLaunchKernelGGL((k_scan2d<1024, 3, 4>), dim3((unsigned)(h->s2_R * h->s2_C)), dim3(1024), lds, h->stream, a, sa);
-    if (pr) HIP_TRY(hipEventRecord(pr->stop, h->stream));
-    if (h->profile) {
-        pm = prof_next(h, 3);
-        if (!pm) return fail(MISSLAP_ERR_HIP, "hipEventCreate failed");
-        pm->launch_idx = a.launch_idx;
-        HIP_TRY(hipEventRecord(pm->start, h->stream));
-    }
-    hipLaunchKernelGGL(k_merge2d, dim3(blocks_for(h->K_ub, 256)), dim3(256), 0, h->stream, a, sa);
-    if (pm) HIP_TRY(hipEventRecord(pm->stop, h->stream));
-    HIP_TRY(hipGetLastError());
-    return MISSLAP_OK;
-}
-
 // rounds with few bidders that are not sharded over GPUs: tiebreak, apply and compaction in one launch
 bool use_round_small(const misslap_solver *h) {
     return h->K_ub <= kRoundSmallMax && (h->world == 1 || h->K_ub < h->shard_min_K);
@@ -331,7 +295,7 @@ int launch_bid(misslap_solver *h) {
     // (not behind a full-scan engine launch: the engines always feed best_key, which k_round_small ignores)
     h->round_small = use_round_small(h) && !(h->tiled_ok && h->K_ub >= h->tiled_min_K);
     if (h->tiled_ok && h->K_ub >= h->tiled_min_K) {
-        int rc = h->scan2d ? launch_bid_scan2d(h) : launch_bid_tiled(h);  // no-op on the device when K < tiled_min_K
+        int rc = launch_bid_tiled(h);  // no-op on the device when K < tiled_min_K
         if (rc) return rc;
         if (h->K_exact) {  // the host has just read K: k_bid would be a no-op
             h->phase_fresh = false;
@@ -469,7 +433,7 @@ void free_all(misslap_solver *h) {
     (void)hipSetDevice(h->device);
     void *ptrs[] = {h->edges32, h->col,     h->val64,     h->row_ptr,    h->price,   h->p2o,     h->o2p,
                     h->U,       h->bid_key, h->bid_obj,   h->best_key,   h->best_pos, h->cnt,    h->hole_list,
-                    h->mover_list, h->ctl,  h->contrib,   h->nmatch,     h->launch_edges, h->tiled, h->tcol, h->seg, h->seg4, h->rec, h->part_v, h->part_w, h->part_g, h->cand};
+                    h->mover_list, h->ctl,  h->contrib,   h->nmatch,     h->launch_edges, h->tiled, h->tcol, h->seg4, h->rec, h->cand};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_ctl) (void)hipHostFree(h->h_ctl);
@@ -537,30 +501,20 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
     const bool shape_auto = !(opt->reserved[1] >= 1 && opt->reserved[1] <= kNumTiledShapes);
     h->tiled_shape = shape_auto ? 0 : opt->reserved[1] - 1;
     const int tiled_opt = opt->reserved[0];  // 0 default, < 0 never, > 0 minimum K for the full-scan engines
-    const int engine = opt->reserved[2];     // 0 auto (2-D scan when applicable), 1 tiled kernel, 2 2-D scan
     size_t Mpad = M;
     const bool forced_engine = opt->reserved[2] != 0 && tiled_opt > 0;  // tests / tuning: any size
     if (h->f32 && tiled_opt >= 0 && (N >= 4096 || forced_engine)) {
-        // 2-D engine: C column slices that fit the LDS, R row blocks, R * C ~ 256 workgroups
-        const int C2 = (int)std::max<size_t>(16, (M + kTileColsBig - 1) / kTileColsBig);
-        const int R2 = std::max(1, 256 / C2);
-        const int cols2 = (int)(((M + C2 - 1) / C2 + 127) / 128 * 128);
-        const int rb2 = (int)((N + R2 - 1) / R2);
-        const bool forced = engine != 0 && tiled_opt > 0;  // tests / tuning: skip the density heuristics
-        // the 2-D engine is correct but measured slower than k_bid_tiled at C3 (175 vs 135 us per full scan: one
-        // cross-lane reduction per (person, slice) segment costs more issue slots than the tile loop's refills),
-        // so it is opt-in (engine 2)
-        const bool want2d = engine == 2 && h->world == 1 && (forced || (double)nnz / ((double)N * C2) >= 4.0);
-        const int tcols = want2d ? cols2 : kTiledShapes[h->tiled_shape][4];
-        const int T = want2d ? C2 : (int)((M + tcols - 1) / tcols);
-        if (shape_auto && !want2d) {
+        const bool forced = forced_engine;  // tests / tuning: skip the density heuristics
+        const int tcols = kTiledShapes[h->tiled_shape][4];
+        const int T = (int)((M + tcols - 1) / tcols);
+        if (shape_auto) {
             // lanes per person by the average (person, tile) segment: a step covers 2 edges x 2 loads per lane without
             // entering the leftover loop, whose every pass costs a memory latency (C3: 10 edges per segment -> 4
             // lanes, C4: 20 -> 8 lanes, C2: 50 -> 16 lanes)
             const double seg = (double)nnz / ((double)N * T);
             h->tiled_shape = seg <= 14.0 ? 0 : seg <= 28.0 ? 8 : 9;
         }
-        const int rb = want2d ? rb2 : kTileRB;
+        const int rb = kTileRB;
         const long long nblk = ((long long)N + rb - 1) / rb;
         const long long L = nblk * T * rb;
         // both tables are addressed with 32-bit byte offsets (8 B per entry): < 2^29 entries each
@@ -589,25 +543,16 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
             if (!unsorted && total > 0 && total < 0x1ffffff0) {
                 h->n_tiled = total;
                 if ((rc = dev_alloc(&h->tiled, (size_t)total + 16))) return rc;
-                if (want2d) {
-                    if ((rc = dev_alloc(&h->seg, (size_t)L))) return rc;
-                } else {
-                    if ((rc = dev_alloc(&h->seg4, (size_t)L + 2))) return rc;
-                }
+                if ((rc = dev_alloc(&h->seg4, (size_t)L + 2))) return rc;
                 HIP_TRY(hipMemsetAsync(h->tiled, 0, sizeof(int2) * ((size_t)total + 16), h->stream));
-                if (!want2d) {
-                    if ((rc = dev_alloc(&h->tcol, (size_t)total + 16))) return rc;
-                    HIP_TRY(hipMemsetAsync(h->tcol, 0, sizeof(int) * ((size_t)total + 16), h->stream));
-                }
+                if ((rc = dev_alloc(&h->tcol, (size_t)total + 16))) return rc;
+                HIP_TRY(hipMemsetAsync(h->tcol, 0, sizeof(int) * ((size_t)total + 16), h->stream));
                 // k_bid_tiled: 6-byte packed edges holding price slots (buffer stride of the double-buffered shapes)
                 const int buf_stride = tcols == kTileColsBig ? 0 : tcols + 128;
                 hipLaunchKernelGGL(k_tile_scatter, dim3(blocks_for((long long)N, 4)), dim3(256), 0, h->stream,
                                    h->edges32, h->row_ptr, h->n_rows, T, tcols, rb, start, lrel, h->tiled,
-                                   want2d ? nullptr : h->tcol, buf_stride);
-                if (want2d)
-                    hipLaunchKernelGGL(k_pack_seg, dim3(blocks_for(L, 256)), dim3(256), 0, h->stream, start, len, L, h->seg);
-                else
-                    hipLaunchKernelGGL(k_pack_seg4, dim3(blocks_for(L + 1, 256)), dim3(256), 0, h->stream, start, len, L, h->seg4);
+                                   h->tcol, buf_stride);
+                hipLaunchKernelGGL(k_pack_seg4, dim3(blocks_for(L + 1, 256)), dim3(256), 0, h->stream, start, len, L, h->seg4);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipStreamSynchronize(h->stream));
                 h->tiled_ok = true;
@@ -616,17 +561,7 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
                 h->tiled_min_K = tiled_opt > 0 ? tiled_opt : (int)std::max<size_t>((N * 3) / 10, 8192);
                 Mpad = (size_t)T * tcols;  // whole tiles: the LDS fills need no bounds test
                 const hipFuncAttribute at = hipFuncAttributeMaxDynamicSharedMemorySize;
-                if (want2d) {
-                    h->scan2d = true;
-                    h->s2_C = C2;
-                    h->s2_R = R2;
-                    h->s2_rb = rb2;
-                    h->s2_cols = cols2;
-                    if ((rc = dev_alloc(&h->part_v, (size_t)C2 * N))) return rc;
-                    if ((rc = dev_alloc(&h->part_w, (size_t)C2 * N))) return rc;
-                    if ((rc = dev_alloc(&h->part_g, (size_t)C2 * N))) return rc;
-                    HIP_TRY(hipFuncSetAttribute((const void *)k_scan2d<1024, 3, 4>, at, (cols2 + 2) * (int)sizeof(double)));
-                } else {
+                {
                     // per create, i.e. per device: the > 64 KB dynamic-LDS opt-in is a property of the function ON
                     // the current device, so a process-wide "done" flag would leave a second device without it
                     switch (h->tiled_shape) {
@@ -1136,7 +1071,7 @@ MISSLAP_API int misslap_finish(misslap_solver *h, int32_t *person_to_object_out,
     meta->tail_edges = c.tail_edges;
     meta->bytes_per_edge = h->f32 ? 8 : 12;
     meta->profiled = h->profile ? 1 : 0;
-    meta->tiled_active = h->tiled_ok ? (h->scan2d ? 2 : 1) : 0;
+    meta->tiled_active = h->tiled_ok ? 1 : 0;
     meta->tiled_min_K = h->tiled_min_K;
     meta->shard_edges = c.shard_edges;
     for (int k = 0; k < 6; ++k) meta->tail_stats[k] = (double)c.dbg[k];  // tail: rounds / 10-ns ticks per mode

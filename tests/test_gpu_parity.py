@@ -264,10 +264,9 @@ def test_sharded_driver_two_ranks_one_gpu(gpu_lib):
     (dict(kind="sparse", n=5000, m=5000, density=0.01, ints=6), "max"),    # heavy ties, 1 tile
     (dict(kind="sparse", n=4500, m=33000, density=0.0012, ints=3), "min"), # ties across tiles
 ])
-@pytest.mark.parametrize("engine", [1, 2])
+@pytest.mark.parametrize("engine", [1])
 def test_tiled_bid_kernel_round_by_round(spec, prob, engine, gpu_lib):
-    """The full-scan engines -- k_bid_tiled (engine 1: prices tiled in LDS, tile loop) and k_scan2d +
-    k_merge2d (engine 2: row block x column slice, partial top-2s) -- forced for every grid round
+    """The full-scan engine k_bid_tiled (prices tiled in LDS, tile loop) forced for every grid round
     (tiled_min_k = 1, no tail kernel): full state vs the oracle after r rounds."""
     loc, val = cases.synth_inputs(spec)
     for r in [1, 2, 3, 5, 8, 13, 21, 40, 80, 200]:
@@ -289,7 +288,7 @@ def test_tiled_bid_kernel_round_by_round(spec, prob, engine, gpu_lib):
 def test_tiled_and_gather_kernels_agree_end_to_end(gpu_lib):
     loc, val = synth.gen_sparse(20000, 50000, 0.001, seed=4)
     ref = orc.auction_solve(loc=loc, val=val.copy(), problem="max", cardinality_check=False, max_iter=10**8)
-    for tk, eng in ((1, 1), (1, 2), (0, 0), (-1, 0)):  # always tiled / always 2-D / default / gather only
+    for tk, eng in ((1, 1), (0, 0), (-1, 0)):  # always tiled / default / gather only
         s = from_sparse(loc, val.copy(), problem="max", cardinality_check=False, max_iter=10**8, tiled_min_k=tk,
                         engine=eng)
         sol = s.solve()

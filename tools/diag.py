@@ -31,7 +31,7 @@ for mode in (0, 1, 2, 3, 0):
     out["bid_" + names[mode] + "_GBs"] = round(nnz * 8 / (ms.value * 1e-3) / 1e9, 1)
 # full-scan timing inside a real solve (HIP events), tiled vs gather kernel
 shapes = ["1024x4x2x2h_L3", "1024x4x2x2h_L0", "1024x4x2x3big", "1024x4x2x2h_L1", "1024x8x4x1h_L1_g8", "1024x4x1x2h_L1", "1024x4x2x3h_L1", "1024x4x2x2h_L2"]
-for tk, shape, eng, name in [(0, k, 1, "tiled_" + n) for k, n in enumerate(shapes)] + [(0, 0, 2, "scan2d"), (-1, 0, 0, "gather_only")]:
+for tk, shape, eng, name in [(0, k, 1, "tiled_" + n) for k, n in enumerate(shapes)] + [(-1, 0, 0, "gather_only")]:
     st = AuctionSolver.from_device_pointers(dl.data_ptr(), dv.data_ptr(), nnz, problem="max", max_iter=10**8,
                                             profile=3, tiled_min_k=tk, tiled_shape=shape, engine=eng)
     st.solve()
