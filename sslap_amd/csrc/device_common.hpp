@@ -333,17 +333,36 @@ struct PriceSource {
 // `early(out)` is called with obj / prev / pstart of both halves filled in: the owners of the winning objects are the
 // next bidders if the bids win,
 // so the caller can request their lines (into `slot` itself) before the rest of the round is computed.
+// the lane's record gather of a two-person line evaluation (split off so that a caller with several lines in flight
+// can issue all gathers before it evaluates any of them)
+template <class Src>
+__device__ __forceinline__ PriceRec cand_gather2(const int2 slot, const bool act0, const bool act1, const Src &src) {
+    const int lane = lane_id(), l32 = lane & (kCandLanes - 1);
+    const bool active = lane < kCandLanes ? act0 : act1;
+    const bool is_cand = active & (l32 >= 1) & (l32 <= kCandMax) & (slot.x >= 0);
+    return src.get(is_cand ? slot.x : 0);
+}
+template <class Early, class S = NoStamp>
+__device__ __forceinline__ void cand_eval2_r(int2 &slot, const PriceRec r, const bool act0, const bool act1,
+                                             const double eps, CandBid (&out)[2], int &err, Early &&early,
+                                             const S &stamp = S());
 template <class Src, class Early, class S = NoStamp>
 __device__ __forceinline__ void cand_eval2(int2 &slot, const bool act0, const bool act1, const Src &src,
                                            const double eps, CandBid (&out)[2], int &err, Early &&early,
                                            const S &stamp = S()) {
+    stamp(1);  // (diagnostic builds: drains the memory counters) the line has landed
+    const PriceRec r = cand_gather2(slot, act0, act1, src);
+    stamp(2);  // the records have landed
+    cand_eval2_r(slot, r, act0, act1, eps, out, err, early, stamp);
+}
+template <class Early, class S>
+__device__ __forceinline__ void cand_eval2_r(int2 &slot, const PriceRec r, const bool act0, const bool act1,
+                                             const double eps, CandBid (&out)[2], int &err, Early &&early,
+                                             const S &stamp) {
     const int lane = lane_id(), l32 = lane & (kCandLanes - 1);
     const double ninf = -__builtin_huge_val();
     const bool active = lane < kCandLanes ? act0 : act1;
-    stamp(1);  // (diagnostic builds: drains the memory counters) the line has landed
     const bool is_cand = active & (l32 >= 1) & (l32 <= kCandMax) & (slot.x >= 0);
-    const PriceRec r = src.get(is_cand ? slot.x : 0);
-    stamp(2);  // the records have landed
     const double cost = (double)__int_as_float(slot.y);
     double tau[2];
     tau[0] = readlane_f64(__hiloint2double(slot.y, slot.x), 0);

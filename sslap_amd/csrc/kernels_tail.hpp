@@ -355,15 +355,21 @@ __device__ __forceinline__ void tail_solo_mode(const TailArgs &a, const E &ed, i
 }
 
 // ---- team mode: 3 <= K <= 16 -----------------------------------------------------------------------------------
-// Wavefront w serves list slots 2w and 2w + 1 (the two halves of its lines).  ONE barrier per round: the bids go to
-// LDS (double-buffered by round parity), and behind the barrier EVERY wavefront runs RESOLVE / ASSIGN / push_all_left
-// for the whole list redundantly on lanes = slots (the list lives in registers, replicated), so nobody waits for a
-// resolver and no second barrier publishes its result.  Every serving wavefront stores the records of ALL winners
-// itself (identical values from every wavefront): its own next gathers then follow its own stores in program order,
-// which is the only ordering a wavefront's in-order memory path gives for free -- and the barrier guarantees that
-// every wavefront has finished the gathers of the round before anybody stores.  The line of a slot's next occupant
-// (the owner its bidder evicts inherits the slot, :409) is requested as soon as the winning candidate is known.
+// Wavefront w serves list slots 2w and 2w + 1 (the two halves of its lines).  ONE barrier per round: the bids AND the
+// bidders go to LDS (double-buffered by round parity), and behind the barrier EVERY wavefront finishes the round for
+// the whole list redundantly on lanes = slots, so nobody waits for a resolver and no second barrier publishes a
+// result.  Every serving wavefront stores the records of ALL winners itself (identical values from every wavefront):
+// its own next gathers then follow its own stores in program order, which is the only ordering a wavefront's
+// in-order memory path gives for free -- and the barrier guarantees that every wavefront has finished the gathers of
+// the round before anybody stores.
+// Almost every round is "clean": no object is bid on twice and no chain ends (no bidder wins an unowned object).
+// Then every bidder wins, every slot passes to the owner its bidder evicts (:409), the list keeps its length and
+// order, and a wavefront already knows its own next persons -- their lines were requested when the winning
+// candidates were known.  The clean test is one LDS compare-and-swap per slot (a private 64-entry table per
+// wavefront: an insert that meets its own object = a contested object) and one ballot; only an unclean round runs
+// RESOLVE (:375-385) / push_all_left (:137-162) in full.
 constexpr int kTeamMax = 16;
+constexpr int kTeamTab = 64;  // entries of a wavefront's private duplicate-detection table (<= 16 inserts)
 __device__ __forceinline__ void tail_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <class E>
@@ -373,29 +379,34 @@ __device__ __forceinline__ void tail_team_mode(const TailArgs &a, const E &ed, i
     const int lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     static_assert(kTeamMax <= 2 * (kTailMax / kWave) && kTeamMax <= kWave, "two list slots per wavefront");
     __shared__ unsigned long long tKey[2][kTeamMax];
-    __shared__ int tObj[2][kTeamMax], tPrev[2][kTeamMax], tPst[2][kTeamMax];
+    __shared__ int tObj[2][kTeamMax], tPrev[2][kTeamMax], tPst[2][kTeamMax], tU[2][kTeamMax], tS[2][kTeamMax];
+    __shared__ int wTab[kTailMax / kWave][kTeamTab];
     const int n0 = 2 * wave;  // my slots: n0, n0 + 1
-    // the list, replicated in every wavefront: lane l holds slot l
-    int u = lane < K ? sU[min(lane, kTailMax - 1)] : -1;
-    int sx = lane < K ? sStart[min(lane, kTailMax - 1)] : 0;
     int pi[2], ps[2];
-    auto my_slots = [&]() {
 #pragma unroll
-        for (int X = 0; X < 2; ++X) {
-            pi[X] = n0 + X < K ? __builtin_amdgcn_readlane(u, min(n0 + X, kWave - 1)) : -1;
-            ps[X] = n0 + X < K ? __builtin_amdgcn_readlane(sx, min(n0 + X, kWave - 1)) : 0;
-        }
-    };
-    my_slots();
+    for (int X = 0; X < 2; ++X) {
+        pi[X] = n0 + X < K ? __builtin_amdgcn_readfirstlane(sU[min(n0 + X, kTailMax - 1)]) : -1;
+        ps[X] = n0 + X < K ? __builtin_amdgcn_readfirstlane(sStart[min(n0 + X, kTailMax - 1)]) : 0;
+    }
+    wTab[wave][lane & (kTeamTab - 1)] = -1;
     TwoFetch<E> tf;
     tf.slot = cand_no_line();
     if (n0 < K) request_two(a, ed, pi[0], ps[0], pi[1], ps[1], tf);
     __syncthreads();  // (sU / sStart have been read by everybody)
+#ifdef MISSLAP_TAIL_STAMP_TEAM
+    // diagnostic build: cycles of wavefront 0 per segment of a team round -> Ctl::dbg[6..9]: [6] bids of my slots,
+    // [7] barrier, [8] clean test / resolve / assign, [9] re-request, line rebuild
+    unsigned long long sacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sprev = __builtin_amdgcn_s_memtime();
+    const CycleStamp stamp{sacc, &sprev, wave == 0};
+#else
+    const NoStamp stamp;
+#endif
     int par = 0;
     for (;;) {
         int sp[2] = {-2, -2};  // persons whose lines were requested early (-2: nothing requested)
         CandBuildArgs bd;
         int bd_person = -1;
+        stamp.light(0);
         if (n0 < K) {  // wave-uniform: BID for my slots (slots < K are always occupied: the list is compact)
             CandBid b[2];
             bid_two(a, ed, pi, ps, tf, eps, b, bd, bd_person, st, [&](const CandBid(&w)[2]) {
@@ -411,60 +422,113 @@ __device__ __forceinline__ void tail_team_mode(const TailArgs &a, const E &ed, i
                         tObj[par][n0 + X] = b[X].obj;
                         tPrev[par][n0 + X] = b[X].prev;
                         tPst[par][n0 + X] = b[X].pstart;
+                        tU[par][n0 + X] = pi[X];
+                        tS[par][n0 + X] = ps[X];
                     }
             }
         }
+        stamp.light(1);
         tail_barrier_lds();  // the bids are in LDS and every gather of the round is done; requests stay in flight
-        {  // RESOLVE / ASSIGN / push_all_left on lanes = slots, in every wavefront
+        stamp.light(2);
+        {
             const bool act = lane < K;
             const int ls = min(lane, kTeamMax - 1);
             const unsigned long long lkey = act ? tKey[par][ls] : 0ull;
             const int lobj = act ? tObj[par][ls] : (-2 - lane);
-            const int lprev = act ? tPrev[par][ls] : -1, lpst = act ? tPst[par][ls] : 0;
-            bool lose = false;
-            for (int m = 0; m < K; ++m) {  // :375-385, all pairs via readlane
-                const int om = __builtin_amdgcn_readlane(lobj, m);
-                const bool same = (om == lobj) && (m != lane);
-                if (__any(same)) {  // wave-uniform; two bidders on one object are the exception
-                    const unsigned long long km = readlane_u64(lkey, m);
-                    lose |= same && (km > lkey || (km == lkey && m < lane));
+            const int lprev = act ? tPrev[par][ls] : 0, lpst = act ? tPst[par][ls] : 0;
+            int u = act ? tU[par][ls] : -1;  // the list: lane l holds slot l
+            int sx = act ? tS[par][ls] : 0;
+            // clean round?  (a) no object bid on twice: one compare-and-swap per slot into my private table
+            int hs = 0;
+            bool dup = false;
+            if (act) {
+                hs = (int)(((unsigned)lobj * 2654435761u) >> 26) & (kTeamTab - 1);
+                for (;;) {
+                    const int old = atomicCAS(&wTab[wave][hs], -1, lobj);
+                    if (old == -1) break;
+                    if (old == lobj) {
+                        dup = true;
+                        break;
+                    }
+                    hs = (hs + 1) & (kTeamTab - 1);
                 }
             }
-            const bool won = act && !lose;
-            if (won && n0 < K) apply_winner(a, u, sx, lobj, lprev, lkey);  // :396-418 (serving wavefronts only)
-            u = won ? lprev : u;  // the evicted owner inherits the slot (:409) / hole (:412) / a loser stays
-            sx = won ? lpst : sx;
-            const unsigned long long kmask = (1ull << K) - 1ull;
-            const unsigned long long holes = __ballot(act && u == -1) & kmask;
-            const int Kn = K - __popcll(holes);
-            const unsigned long long lmask = (1ull << Kn) - 1ull;
-            unsigned long long hl = holes & lmask;            // empty slots left of K'
-            unsigned long long mv = ~holes & ~lmask & kmask;  // persons right of K'
-            while (hl) {  // wave-uniform, rare: k-th hole <- k-th mover (:137-162)
-                const int hk = __ffsll((long long)hl) - 1, mk = __ffsll((long long)mv) - 1;
-                const int mu = __builtin_amdgcn_readlane(u, mk), ms = __builtin_amdgcn_readlane(sx, mk);
-                if (lane == hk) {
-                    u = mu;
-                    sx = ms;
+            const bool contested = __any(dup);
+            if (act && !dup) wTab[wave][hs] = -1;  // (LDS operations of a wavefront complete in order)
+            // (b) no chain ends
+            const bool ends = __any(act && lprev == -1);
+#ifdef MISSLAP_TAIL_STAMP_TEAM
+            if (threadIdx.x == 0) sacc[5] += (!contested && !ends), sacc[6] += contested, sacc[7] += 1;
+#endif
+            if (!contested && !ends) {
+                // every bidder wins (:375-385 has nothing to resolve); ASSIGN (:396-418); the list keeps its shape
+                if (act && n0 < K) apply_winner(a, u, sx, lobj, lprev, lkey);
+#pragma unroll
+                for (int X = 0; X < 2; ++X) {
+                    const int w = __builtin_amdgcn_readlane(lprev, min(n0 + X, kWave - 1));
+                    const int ws = __builtin_amdgcn_readlane(lpst, min(n0 + X, kWave - 1));
+                    pi[X] = n0 + X < K ? w : -1;
+                    ps[X] = n0 + X < K ? ws : 0;
                 }
-                hl &= hl - 1;
-                mv &= mv - 1;
+            } else {
+                // RESOLVE / ASSIGN / push_all_left in full, on lanes = slots
+                bool lose = false;
+                for (int m = 0; m < K; ++m) {  // :375-385, all pairs via readlane
+                    const int om = __builtin_amdgcn_readlane(lobj, m);
+                    const bool same = (om == lobj) && (m != lane);
+                    if (__any(same)) {  // wave-uniform
+                        const unsigned long long km = readlane_u64(lkey, m);
+                        lose |= same && (km > lkey || (km == lkey && m < lane));
+                    }
+                }
+                const bool won = act && !lose;
+                if (won && n0 < K) apply_winner(a, u, sx, lobj, lprev, lkey);  // :396-418 (serving wavefronts only)
+                u = won ? lprev : u;  // the evicted owner inherits the slot (:409) / hole (:412) / a loser stays
+                sx = won ? lpst : sx;
+                const unsigned long long kmask = (1ull << K) - 1ull;
+                const unsigned long long holes = __ballot(act && u == -1) & kmask;
+                const int Kn = K - __popcll(holes);
+                const unsigned long long lmask = (1ull << Kn) - 1ull;
+                unsigned long long hl = holes & lmask;            // empty slots left of K'
+                unsigned long long mv = ~holes & ~lmask & kmask;  // persons right of K'
+                while (hl) {  // wave-uniform: k-th hole <- k-th mover (:137-162)
+                    const int hk = __ffsll((long long)hl) - 1, mk = __ffsll((long long)mv) - 1;
+                    const int mu = __builtin_amdgcn_readlane(u, mk), ms = __builtin_amdgcn_readlane(sx, mk);
+                    if (lane == hk) {
+                        u = mu;
+                        sx = ms;
+                    }
+                    hl &= hl - 1;
+                    mv &= mv - 1;
+                }
+                K = Kn;
+#pragma unroll
+                for (int X = 0; X < 2; ++X) {
+                    pi[X] = n0 + X < K ? __builtin_amdgcn_readlane(u, min(n0 + X, kWave - 1)) : -1;
+                    ps[X] = n0 + X < K ? __builtin_amdgcn_readlane(sx, min(n0 + X, kWave - 1)) : 0;
+                }
             }
-            if (lane >= Kn) u = -1;
-            K = Kn;
         }
+        stamp.light(3);
         par ^= 1;
         nits += 1;
-        my_slots();  // my slots' new occupants: usually exactly the persons whose lines were requested early
         const bool done = K <= 2 || nits >= max_iter;
+        // my slots' new occupants are usually exactly the persons whose lines were requested early; otherwise (a
+        // scanned row, a lost bid, a moved person) request now
         if (!done && n0 < K && (sp[0] != pi[0] || sp[1] != pi[1]))
-            request_two(a, ed, pi[0], ps[0], pi[1], ps[1], tf);  // a scanned row, a lost bid, a moved person
+            request_two(a, ed, pi[0], ps[0], pi[1], ps[1], tf);
         if (bd_person >= 0) tail_build(a, bd_person, bd, eps, st);
+        stamp.light(4);
         if (done) break;
     }
-    if (wave == 0 && lane < kTeamMax) {
-        sU[lane] = u;
-        sStart[lane] = sx;
+#ifdef MISSLAP_TAIL_STAMP_TEAM
+    if (threadIdx.x == 0)
+        for (int k = 1; k <= 6; ++k) a.ctl->dbg[5 + k] += sacc[k];
+#endif
+    // hand the list back: every wavefront writes its own slots
+    if (lane < 2 && n0 + lane < kTeamMax) {
+        sU[n0 + lane] = lane == 0 ? pi[0] : pi[1];
+        sStart[n0 + lane] = lane == 0 ? ps[0] : ps[1];
     }
     __syncthreads();
 }
@@ -552,35 +616,54 @@ __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
         mode_begin(2);
         {
             const RecSource src{a.rec};
-            for (int base = 0; base < K; base += 2 * nwaves) {
-                const int n0 = base + 2 * wave;
-                const int nme = n0 + (lane >> 5);
-                const int pme = nme < K ? sU[min(nme, kTailMax - 1)] : -1;
-                int2 slot = cand_no_line();
-                if (E::kCand && a.cand != nullptr)
-                    slot = a.cand[(size_t)max(pme, 0) * kCandLanes + (lane & (kCandLanes - 1))];
-                CandBid b[2];
-                b[0].hit = b[1].hit = false;
-                if (E::kCand) cand_eval2(slot, n0 < K, n0 + 1 < K, src, eps, b, st.err, NoEarly());
+            // kBlockDepth sweeps of 2 * nwaves slots are in flight together: all their lines are requested first,
+            // then all record gathers are issued (each as its line lands), then they are evaluated one after the
+            // other -- the two memory latencies are paid once per group of sweeps, not once per sweep
+            constexpr int kBlockDepth = 3;
+            for (int base = 0; base < K; base += kBlockDepth * 2 * nwaves) {
+                int2 sl[kBlockDepth];
+                PriceRec rr[kBlockDepth];
 #pragma unroll
-                for (int X = 0; X < 2; ++X) {
-                    const int n = n0 + X;
-                    if (n >= K) continue;  // wave-uniform
-                    if (b[X].hit) {
-                        if (lane == 0) {
-                            sKey[n] = b[X].key;
-                            sObj[n] = b[X].obj;
-                            // owner at the start of the round == what the assignment phase reads (:401): the record
-                            // of obj is only rewritten by this round's winner of obj, after every bid has been made.
-                            sPrev[n] = b[X].prev;
-                            sPst[n] = b[X].pstart;
+                for (int c = 0; c < kBlockDepth; ++c) {
+                    const int nme = base + c * 2 * nwaves + 2 * wave + (lane >> 5);
+                    const int pme = nme < K ? sU[min(nme, kTailMax - 1)] : -1;
+                    sl[c] = cand_no_line();
+                    if (E::kCand && a.cand != nullptr)
+                        sl[c] = a.cand[(size_t)max(pme, 0) * kCandLanes + (lane & (kCandLanes - 1))];
+                }
+#pragma unroll
+                for (int c = 0; c < kBlockDepth; ++c) {
+                    const int n0 = base + c * 2 * nwaves + 2 * wave;
+                    if (E::kCand) rr[c] = cand_gather2(sl[c], n0 < K, n0 + 1 < K, src);
+                }
+#pragma unroll
+                for (int c = 0; c < kBlockDepth; ++c) {
+                    const int n0 = base + c * 2 * nwaves + 2 * wave;
+                    if (n0 >= K) continue;  // wave-uniform
+                    CandBid b[2];
+                    b[0].hit = b[1].hit = false;
+                    if (E::kCand) cand_eval2_r(sl[c], rr[c], n0 < K, n0 + 1 < K, eps, b, st.err, NoEarly());
+#pragma unroll
+                    for (int X = 0; X < 2; ++X) {
+                        const int n = n0 + X;
+                        if (n >= K) continue;  // wave-uniform
+                        if (b[X].hit) {
+                            if (lane == 0) {
+                                sKey[n] = b[X].key;
+                                sObj[n] = b[X].obj;
+                                // owner at the start of the round == what the assignment phase reads (:401): the
+                                // record of obj is only rewritten by this round's winner of obj, after every bid
+                                // has been made.
+                                sPrev[n] = b[X].prev;
+                                sPst[n] = b[X].pstart;
+                            }
+                            st.hits += 1;
+                            st.hit_edges += (unsigned long long)b[X].len;
+                            st.edges += (unsigned long long)b[X].len;
+                            st.bids += 1;
+                        } else if (lane == 0) {
+                            sList[atomicAdd(&sMissCnt, 1)] = n;
                         }
-                        st.hits += 1;
-                        st.hit_edges += (unsigned long long)b[X].len;
-                        st.edges += (unsigned long long)b[X].len;
-                        st.bids += 1;
-                    } else if (lane == 0) {
-                        sList[atomicAdd(&sMissCnt, 1)] = n;
                     }
                 }
             }
@@ -615,13 +698,36 @@ __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
                 const bool act = lane < K;
                 const unsigned long long key = act ? sKey[lane] : 0ull;
                 const int obj = act ? sObj[lane] : (-2 - lane);
+                // RESOLVE (:375-385).  Two bidders on one object are the exception: every bidder inserts its object
+                // into the (empty) LDS hash table with one compare-and-swap; only if some insert meets its own object
+                // -- a contested object -- is the all-pairs loop run.  The table is emptied again right away.
                 bool lose = false;
-                for (int m = 0; m < K; ++m) {  // RESOLVE (:375-385): K <= 64 all-pairs via readlane
-                    const int om = __builtin_amdgcn_readlane(obj, m);
-                    const bool same = (om == obj) && (m != lane);
-                    if (__any(same)) {  // wave-uniform; two bidders on one object are the exception
-                        const unsigned long long km = readlane_u64(key, m);
-                        lose |= same && (km > key || (km == key && m < lane));
+                int hs = 0;
+                bool dup = false;
+                if (act) {
+                    hs = (int)(((unsigned)obj * 2654435761u) >> 21) & (kHashSize - 1);
+                    for (;;) {
+                        const int old = atomicCAS(&hObj[hs], -1, obj);
+                        if (old == -1) break;
+                        if (old == obj) {
+                            dup = true;
+                            break;
+                        }
+                        hs = (hs + 1) & (kHashSize - 1);
+                    }
+                }
+                const bool contested = __any(dup);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (act && !dup) hObj[hs] = -1;
+                if (contested) {
+                    for (int m = 0; m < K; ++m) {  // all pairs via readlane
+                        const int om = __builtin_amdgcn_readlane(obj, m);
+                        const bool same = (om == obj) && (m != lane);
+                        if (__any(same)) {  // wave-uniform
+                            const unsigned long long km = readlane_u64(key, m);
+                            lose |= same && (km > key || (km == key && m < lane));
+                        }
                     }
                 }
                 int u = act ? sU[lane] : -1;
