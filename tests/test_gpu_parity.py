@@ -666,3 +666,21 @@ def test_tiled_kernel_shapes_round_by_round(spec, prob, shape, gpu_lib):
         assert np.array_equal(sg["p"].view(np.uint64), so["p"].view(np.uint64)), r
         assert np.array_equal(sg["p2o"], so["p2o"]) and np.array_equal(sg["o2p"], so["o2p"]), r
         assert g.gpu["edges_scanned"] == o.extra["edges_scanned"], r
+
+
+def test_integration_md_sharded_binding_stub_works(gpu_lib):
+    """The reference-side binding of the sharded solve printed in INTEGRATION.md, executed verbatim (world 1, RCCL)."""
+    import os
+    import re
+    from sslap_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(# sslap/misslap_binding.py.*?)```", text, re.S)
+    assert len(blocks) == 2
+    ns = {}
+    for code in blocks:
+        exec(compile(code.replace('C.CDLL("libmisslap.so")', f'C.CDLL({_lib.LIB_PATH!r})'), "INTEGRATION.md", "exec"), ns)
+    loc, val = synth.gen_sparse(900, 900, 0.03, seed=13)
+    sol = ns["solve_sharded"](loc, val.copy(), 0, 1, 0, lambda uid: uid, problem="max")
+    ref = orc.auction_solve(loc=loc, val=val.copy(), problem="max", cardinality_check=False)
+    assert np.array_equal(sol, ref["sol"])
