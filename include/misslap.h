@@ -44,8 +44,7 @@ typedef struct misslap_options {
                                 < 0 = library default; 0 = grid kernels only; max 512 */
     int32_t force_f64_values;/* keep 12 B/edge (int32 col + fp64 val) even when values are fp32-exact */
     int32_t profile;         /* 1: record HIP events around the full-scan bid launches, every launch of the full-scan
-                                engine and every tail-kernel launch; 3: around every bid-kernel launch as well;
-                                2: like 3, and run the stamped (diagnostic) tail kernel */
+                                engine and every tail-kernel launch; 2 / 3: around every bid-kernel launch as well */
     int32_t shard_rank;      /* multi-GPU: this process bids for U positions of its shard only */
     int32_t shard_world;     /* number of shards (1 = single GPU) */
     int32_t rounds_per_sync; /* grid rounds enqueued between host status reads; <= 0 = default */

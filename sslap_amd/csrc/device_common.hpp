@@ -55,7 +55,8 @@ struct Ctl {
     double obj_abs;        // sum of |contribution| (any order: only used as a bound, see k_obj_sum)
     int obj_minexp;        // smallest binary exponent of a lowest set bit among the contributions
     int pad1;
-    unsigned long long dbg[16]; // diagnostic cycle counters of the stamped tail build (profile == 2)
+    unsigned long long dbg[16]; // tail accounting: [0..2] rounds per mode, [3..5] 10-ns ticks, [12..15] bids / line hits /
+                                // builds / hit edges; [6..11] cycles per segment in -DMISSLAP_TAIL_STAMP* builds
 };
 
 // ---- edge storage ------------------------------------------------------------------------------

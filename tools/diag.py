@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostics on the GPU box: bid-kernel ablations and stamped tail kernel (not part of the product)."""
+"""Diagnostics on the GPU box: bid-kernel ablations (libmisslap_diag.so) and the tail kernel's accounting."""
 import ctypes as C
 import json
 import sys
@@ -43,18 +43,12 @@ for tk, shape, eng, name in [(0, k, 1, "tiled_" + n) for k, n in enumerate(shape
                                 bid_launches=g["bid_launches"], bid_ms=g["bid_ms"], bid_edges=g["bid_edges"], tail_ms=g["tail_ms"],
                                 grid_rounds=g["grid_rounds"], its=st.meta["its"])
 if "--tail" in sys.argv:
-    s2 = AuctionSolver.from_device_pointers(dl.data_ptr(), dv.data_ptr(), nnz, problem="max", max_iter=10**8, profile=2)
+    # per-mode accounting of the tail kernel (always on) -- cycles per segment of a chain / team round come from the
+    # diagnostic builds: hipcc ... -DMISSLAP_TAIL_STAMP (chain) or -DMISSLAP_TAIL_STAMP_TEAM, run through
+    # MISSLAP_LIB=<that build> python tools/tail_stats.py (prints meta.tail_stats raw)
+    s2 = AuctionSolver.from_device_pointers(dl.data_ptr(), dv.data_ptr(), nnz, problem="max", max_iter=10**8, profile=1)
     s2.solve()
     g = s2.gpu
-    allc = g["tail_stamp_cycles"]
-    cyc = allc[:4]
-    tot = sum(cyc)
-    nb0 = max(allc[10], 1.0)
-    out["tail_bid_wave0_cycles_per_bid"] = dict(zip(
-        ["row_ptr", "edges", "prices", "top2+butterfly", "reread_edge", "owner+lds"], [round(c / nb0, 1) for c in allc[4:10]]))
-    out["tail_bids_by_wave0"] = nb0
     out["tail"] = dict(rounds=g["tail_rounds"], tail_ms=g["tail_ms"], us_per_round=1e3 * g["tail_ms"] / g["tail_rounds"],
-                       cycles_per_round=tot / g["tail_rounds"],
-                       share=dict(zip(["bid", "barrier1", "resolve_apply_compact", "barrier2"], [round(c / tot, 3) for c in cyc])),
-                       bids=g["bids_made"], tail_edges=g["tail_edges"])
+                       modes=g["tail_modes"], lines=g["tail_cand"], bids=g["bids_made"], tail_edges=g["tail_edges"])
 print(json.dumps(out, indent=1))
