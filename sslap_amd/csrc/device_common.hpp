@@ -328,12 +328,10 @@ struct PriceSource {
 // Evaluate the lines of up to two persons at once: lanes 0..31 hold the slots of person A, lanes 32..63 those of
 // person B (`slot` = the lane's 8-byte slot; act0 / act1 = the half holds a person at all, wave-uniform).  One gather
 // serves both.  out[0] / out[1] are wave-uniform.
-// Winner first: if exactly one lane of a half holds the largest HIGH WORD of the values, that lane holds the best
-// candidate (no tie is possible), so one 32-bit reduction decides the winner and only the second-best value still
-// needs a 64-bit pass.  As soon as the winners are known -- and everything else has been read out of `slot` --
-// `early(out)` is called with obj / prev / pstart of both halves filled in: the owners of the winning objects are the
-// next bidders if the bids win,
-// so the caller can request their lines (into `slot` itself) before the rest of the round is computed.
+// Three 32-lane DPP reductions per half: the best value, the LAST slot holding it, the second-best value.  As soon as
+// the winners are known -- and everything else has been read out of `slot` -- `early(out)` is called with obj / prev /
+// pstart of both halves filled in: the owners of the winning objects are the next bidders if the bids win, so the
+// caller can request their lines (into `slot` itself) before the rest of the round is computed.
 // the lane's record gather of a two-person line evaluation (split off so that a caller with several lines in flight
 // can issue all gathers before it evaluates any of them)
 template <class Src>
@@ -371,22 +369,12 @@ __device__ __forceinline__ void cand_eval2_r(int2 &slot, const PriceRec r, const
     out[0].len = __builtin_amdgcn_readlane(slot.x, kCandLanes - 1);
     out[1].len = __builtin_amdgcn_readlane(slot.x, 2 * kCandLanes - 1);
     const double v = is_cand ? cost - r.price : ninf;  // vi = cost - p[j]   (:350)
-    const int hi = __double2hiint(v);
-    const int k = hi ^ ((hi >> 31) & 0x7fffffff);  // signed order of k == order of the doubles' high words
-    const int km = half_max_i32(k);
-    const int km0 = __builtin_amdgcn_readlane(km, 31), km1 = __builtin_amdgcn_readlane(km, 63);
-    const unsigned long long eq = __ballot(k == (lane < kCandLanes ? km0 : km1));
-    const unsigned eq0 = (unsigned)(eq & 0xffffffffull), eq1 = (unsigned)(eq >> 32);
+    // (Straight-line on purpose: a "winner first" shortcut -- one 32-bit reduction on the values' high words, a ballot
+    // and a wave-uniform branch -- was measured 3-4 % SLOWER here: in this latency-bound single-wavefront code the
+    // scalar compare / branch / indexed-readlane chain costs more than the 64-bit DPP pass it saves.)
     double V[2], W[2];
     int G[2];
-    if ((!act0 || __popc(eq0) == 1) && (!act1 || __popc(eq1) == 1)) {  // wave-uniform, the common case
-        G[0] = act0 ? __ffs((int)eq0) - 1 : -1;
-        G[1] = act1 ? __ffs((int)eq1) - 1 : -1;
-        V[0] = readlane_f64(v, max(G[0], 0));
-        V[1] = readlane_f64(v, kCandLanes + max(G[1], 0));
-        if (!act0) V[0] = ninf;
-        if (!act1) V[1] = ninf;
-    } else {
+    {
         const double vm = half_max_f64(v);
         V[0] = readlane_f64(vm, 31);
         V[1] = readlane_f64(vm, 63);
