@@ -23,6 +23,8 @@ struct RoundArgs {
     int *U;
     unsigned long long *bid_key;  // [N] bid of U position n (as key)
     int *bid_obj;                 // [N] object bid on by U position n
+    int4 *bid_rec;                // [kRoundSmallMax] small rounds: {object, its owner, bidder, bidder's row start} of
+                                  // U position n -- everything k_round_small needs besides the bid
     unsigned long long *best_key; // [M]
     int *best_pos;                // [M]
     int *cnt;                     // [2 * nblocks_compact] per-chunk (left holes, movers)
@@ -33,7 +35,6 @@ struct RoundArgs {
     int thr;                      // tail threshold
     int rank, world;              // bidder shard
     int shard_min_K;              // shard only rounds with K >= this (multi-GPU), see shard_range
-    int small_round;              // this round is finished by k_round_small: k_bid skips the global atomicMax
     float eps;
     int launch_idx;
     int gather_max_K;             // k_bid runs only for K < gather_max_K (k_bid_tiled takes the rest); 0 = no limit
@@ -43,6 +44,19 @@ struct RoundArgs {
 __device__ __forceinline__ bool round_live(const Ctl *c, int thr) {
     return c->K > thr && c->K > 0 && c->nits < c->max_iter;
 }
+// The small-round kernels request the control block and their first data together.  The compiler sinks a load below
+// an early exit that does not need it, so the exit is made to need it: `never` is a condition on the loaded value
+// that holds for no valid content.
+struct CtlHead {
+    int K;
+    long long nits, max_iter;
+    __device__ __forceinline__ explicit CtlHead(const Ctl *c) : K(c->K), nits(c->nits), max_iter(c->max_iter) {
+        __builtin_amdgcn_sched_barrier(0);  // the requests above are issued before anything below waits
+    }
+    __device__ __forceinline__ bool live(int thr, bool never) const {
+        return (K > thr) & (K > 0) & (nits < max_iter) & !never;
+    }
+};
 // Bidders of a round are sharded over the ranks only while K >= shard_min_K (the few big rounds where the
 // bid phase is bandwidth-bound); below that every rank bids for everybody -- the replicas stay identical
 // without any exchange, and a per-round all-reduce would cost more than the round.
@@ -60,23 +74,42 @@ constexpr int kBidBlock = 256;  // 4 wavefronts; one wavefront per bidder
 // A bid is first tried on the person's candidate line (device_common.hpp) and only on a miss by a full scan of the
 // row, which also (re)builds the line: in the rounds this kernel serves (K below the full-scan threshold) about
 // 85 % of the bids are answered from 256 bytes and <= 30 price look-ups.
-template <class E>
+// Src = PriceSource: prices only (8 B per look-up); RecSource (rounds finished by k_round_small): the
+// 16-byte price records, whose owner fields give the resolve kernel the person a winning bid evicts.  Such a round
+// is a chain of dependent memory latencies and nothing else, so the wavefront's first list entry is requested before
+// the control block is read (any position below n_rows is readable; it is used only if the round is live).
+template <class Src>
+struct SrcOf;
+template <>
+struct SrcOf<PriceSource> {
+    static constexpr bool kOwners = false;
+    static __device__ __forceinline__ PriceSource make(const RoundArgs &a) { return PriceSource{a.price}; }
+};
+template <>
+struct SrcOf<RecSource> {
+    static constexpr bool kOwners = true;
+    static __device__ __forceinline__ RecSource make(const RoundArgs &a) { return RecSource{a.rec}; }
+};
+template <class E, class Src>
 __global__ __launch_bounds__(kBidBlock) void k_bid(RoundArgs a, E ed) {
-    const Ctl *ctl = a.ctl;
-    if (!round_live(ctl, a.thr)) return;
-    if (a.gather_max_K > 0 && ctl->K >= a.gather_max_K) return;
-    int lo, hi;
-    shard_range(ctl->K, a.rank, a.world, a.shard_min_K, lo, hi);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wpb = kBidBlock / kWave;
+    const int first = blockIdx.x * wpb + wave;
+    const Ctl *ctl = a.ctl;
+    const CtlHead head(ctl);
+    const int i_first = a.U[min(first, a.n_rows - 1)];
+    if (!head.live(a.thr, i_first < -1)) return;  // (list entries are persons or -1)
+    if (a.gather_max_K > 0 && head.K >= a.gather_max_K) return;
+    int lo, hi;
+    shard_range(head.K, a.rank, a.world, a.shard_min_K, lo, hi);
     const double eps = (double)a.eps;  // float promoted to double, auction_.pyx:360
-    const PriceSource src{a.price};
+    const Src src = SrcOf<Src>::make(a);
     unsigned long long edges = 0, hit_edges = 0;
     int nb = 0, nh = 0, err = 0;
     double hint = 0.0;  // cand_build's search distance, carried from one build of this wavefront to the next
     const bool lines = E::kCand && a.cand != nullptr;
-    for (int n = lo + blockIdx.x * wpb + wave; n < hi; n += gridDim.x * wpb) {
-        const int i = a.U[n];
+    for (int n = lo + first; n < hi; n += gridDim.x * wpb) {
+        const int i = n == first ? i_first : a.U[n];
         const int s = a.row_ptr[i], e = a.row_ptr[i + 1];
         CandBid b[2];
         b[0].hit = false;
@@ -88,7 +121,7 @@ __global__ __launch_bounds__(kBidBlock) void k_bid(RoundArgs a, E ed) {
         if (!b[0].hit) {  // wave-uniform
             CandBuildArgs ba;
             const typename E::Raw none[4] = {};
-            wave_bid_full<E, PriceSource, false, false>(ed, src, s, e, none, eps, b[0], ba, err);
+            wave_bid_full<E, Src, false, false>(ed, src, s, e, none, eps, b[0], ba, err);
             if (lines && ba.want) cand_build(a.cand, i, ba, eps, hint);
         } else {
             nh += 1;
@@ -96,8 +129,12 @@ __global__ __launch_bounds__(kBidBlock) void k_bid(RoundArgs a, E ed) {
         }
         if (lane == 0) {
             a.bid_key[n] = b[0].key;
-            a.bid_obj[n] = b[0].obj;
-            if (!a.small_round) atomicMax(&a.best_key[b[0].obj], b[0].key);  // k_round_small forms the maxima itself
+            if (SrcOf<Src>::kOwners) {  // k_round_small forms the maxima itself
+                a.bid_rec[n] = make_int4(b[0].obj, b[0].prev, i, s);
+            } else {
+                a.bid_obj[n] = b[0].obj;
+                atomicMax(&a.best_key[b[0].obj], b[0].key);
+            }
         }
         edges += (unsigned long long)b[0].len;
         nb += 1;
@@ -360,7 +397,7 @@ __global__ __launch_bounds__(1024) void k_compact_small(RoundArgs a) {
 
 // RESOLVE + ASSIGN + push_all_left + round end of a round with few bidders in ONE launch (a single 1024-thread
 // workgroup; the host uses it while K_ub <= kRoundSmallMax, the round is not sharded over GPUs and the bids were
-// made by k_bid with RoundArgs::small_round set, i.e. WITHOUT the global atomicMax).  The per-object arg-max of
+// made by k_bid<E, RecSource>, i.e. WITHOUT the global atomicMax).  The per-object arg-max of
 // :375-385 -- highest bid, earliest list position among equal bids -- is formed in an LDS hash table keyed by
 // object (64-bit ds_max on the bid's bit pattern, then ds_min on the position among the holders of the maximum),
 // so the resolve phase costs LDS latencies instead of two global atomic round trips; best_key / best_pos are not
@@ -369,10 +406,22 @@ constexpr int kRoundSmallMax = 2048;
 constexpr int kRoundSmallSlots = kRoundSmallMax / 1024;  // list positions per thread, kept in registers
 constexpr int kRoundSmallHash = 2 * kRoundSmallMax;      // load factor <= 0.5
 __global__ __launch_bounds__(1024) void k_round_small(RoundArgs a) {
-    Ctl *ctl = a.ctl;
-    if (!round_live(ctl, a.thr)) return;
-    const int K = ctl->K;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    // Everything a position needs comes from its bidder (k_bid<E, RecSource>) in two loads, requested before the
+    // control block is read (positions at or beyond K hold stale bids, masked below) and kept in registers.
+    Ctl *ctl = a.ctl;
+    const CtlHead head(ctl);
+    int4 br[kRoundSmallSlots];
+    unsigned long long key[kRoundSmallSlots];
+    bool never = false;  // (objects are >= 0, a key is the bit pattern of a finite bid + 1)
+#pragma unroll
+    for (int q = 0; q < kRoundSmallSlots; ++q) {
+        br[q] = a.bid_rec[q * 1024 + t];
+        key[q] = a.bid_key[min(q * 1024 + t, a.n_rows - 1)];
+        never |= (br[q].x < 0) | (key[q] == ~0ull);
+    }
+    if (!head.live(a.thr, never)) return;
+    const int K = head.K;
     __shared__ int s_cnt[16], s_wl[16], s_wm[16];
     __shared__ int s_hole[kRoundSmallMax], s_mover[kRoundSmallMax];  // push_all_left lists
     __shared__ int hObj[kRoundSmallHash], hPos[kRoundSmallHash];
@@ -382,21 +431,14 @@ __global__ __launch_bounds__(1024) void k_round_small(RoundArgs a) {
         hKey[h] = 0ull;
         hPos[h] = kPosNone;
     }
-    // Everything a position needs is fetched up front and stays in registers.
     int obj[kRoundSmallSlots], who[kRoundSmallSlots], prev[kRoundSmallSlots], rstart[kRoundSmallSlots];
     int hs[kRoundSmallSlots];
-    unsigned long long key[kRoundSmallSlots];
 #pragma unroll
     for (int q = 0; q < kRoundSmallSlots; ++q) {
-        const int n = min(q * 1024 + t, K - 1);  // unconditional loads, masked below
-        obj[q] = a.bid_obj[n];
-        key[q] = a.bid_key[n];
-        who[q] = a.U[n];
-    }
-#pragma unroll
-    for (int q = 0; q < kRoundSmallSlots; ++q) {  // in flight during the LDS phases below
-        prev[q] = a.o2p[obj[q]];     // :401
-        rstart[q] = a.row_ptr[who[q]];
+        obj[q] = br[q].x;
+        prev[q] = br[q].y;   // :401 (nothing was assigned since the bid was made)
+        who[q] = br[q].z;
+        rstart[q] = br[q].w;
     }
     __syncthreads();  // table cleared
 #pragma unroll

@@ -122,6 +122,7 @@ struct misslap_solver {
     int *p2o = nullptr, *o2p = nullptr, *U = nullptr;
     unsigned long long *bid_key = nullptr;
     int *bid_obj = nullptr;
+    int4 *bid_rec = nullptr;
     unsigned long long *best_key = nullptr;
     int *best_pos = nullptr;
     int *cnt = nullptr, *hole_list = nullptr, *mover_list = nullptr;
@@ -140,6 +141,8 @@ struct misslap_solver {
     int tiled_min_K = 0;
     int tiled_shape = 0;  // index into kShapes of launch_bid_tiled
     Ctl *h_ctl = nullptr;  // pinned mirror
+    Ctl *h_stat = nullptr;  // pinned [2]: status copies that trail the grid rounds by one batch (status_enqueue)
+    hipEvent_t stat_ev[2] = {nullptr, nullptr};
     // scalar solver state (auction_.pyx:180-187)
     float eps = 0, target_eps = 0, theta = 0, start_eps = 0;
     int nreductions = 0;
@@ -198,6 +201,7 @@ RoundArgs round_args(misslap_solver *h) {
     a.U = h->U;
     a.bid_key = h->bid_key;
     a.bid_obj = h->bid_obj;
+    a.bid_rec = h->bid_rec;
     a.best_key = h->best_key;
     a.best_pos = h->best_pos;
     a.cnt = h->cnt;
@@ -210,7 +214,6 @@ RoundArgs round_args(misslap_solver *h) {
     a.rank = h->rank;
     a.world = h->world;
     a.shard_min_K = h->world > 1 ? h->shard_min_K : 0;
-    a.small_round = h->round_small ? 1 : 0;
     a.eps = h->eps;
     a.launch_idx = 0;
     a.gather_max_K = h->tiled_ok ? h->tiled_min_K : 0;
@@ -245,6 +248,24 @@ int read_ctl(misslap_solver *h) {
     h->K_exact = true;
     if (h->h_ctl->err)
         return fail(MISSLAP_ERR_STATE, "device-side invariant violated (error bits 0x%x)", h->h_ctl->err);
+    return MISSLAP_OK;
+}
+
+// Status of the round loop WITHOUT draining the stream: a copy of the control block is enqueued behind a batch of
+// rounds and read while the next batch runs.  K never grows inside an eps-phase, so a status that is one batch old
+// is still an upper bound for the launch grids, and every round kernel is a no-op once the round is not live: a
+// batch enqueued on a stale "go on" costs its launches and nothing else.
+int status_enqueue(misslap_solver *h, int slot) {
+    HIP_TRY(hipMemcpyAsync(&h->h_stat[slot], h->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipEventRecord(h->stat_ev[slot], h->stream));
+    return MISSLAP_OK;
+}
+int status_wait(misslap_solver *h, int slot) {
+    HIP_TRY(hipEventSynchronize(h->stat_ev[slot]));
+    const Ctl &c = h->h_stat[slot];
+    h->K_ub = c.K;
+    h->K_exact = false;  // rounds have been enqueued behind this copy
+    if (c.err) return fail(MISSLAP_ERR_STATE, "device-side invariant violated (error bits 0x%x)", c.err);
     return MISSLAP_OK;
 }
 
@@ -321,12 +342,15 @@ int launch_bid(misslap_solver *h) {
         pr->launch_idx = a.launch_idx = h->launch_idx++;
         HIP_TRY(hipEventRecord(pr->start, h->stream));
     }
-    if (h->f32) {
-        EdgesF32 ed{h->edges32};
-        hipLaunchKernelGGL(k_bid<EdgesF32>, dim3(grid), dim3(kBidBlock), 0, h->stream, a, ed);
+    const EdgesF32 e32{h->edges32};
+    const EdgesF64 e64{h->col, h->val64};
+    const dim3 g(grid), b(kBidBlock);
+    if (h->round_small) {  // bids of a round that k_round_small finishes
+        if (h->f32) hipLaunchKernelGGL((k_bid<EdgesF32, RecSource>), g, b, 0, h->stream, a, e32);
+        else hipLaunchKernelGGL((k_bid<EdgesF64, RecSource>), g, b, 0, h->stream, a, e64);
     } else {
-        EdgesF64 ed{h->col, h->val64};
-        hipLaunchKernelGGL(k_bid<EdgesF64>, dim3(grid), dim3(kBidBlock), 0, h->stream, a, ed);
+        if (h->f32) hipLaunchKernelGGL((k_bid<EdgesF32, PriceSource>), g, b, 0, h->stream, a, e32);
+        else hipLaunchKernelGGL((k_bid<EdgesF64, PriceSource>), g, b, 0, h->stream, a, e64);
     }
     if (pr) HIP_TRY(hipEventRecord(pr->stop, h->stream));
     HIP_TRY(hipGetLastError());
@@ -433,10 +457,14 @@ void free_all(misslap_solver *h) {
     (void)hipSetDevice(h->device);
     void *ptrs[] = {h->edges32, h->col,     h->val64,     h->row_ptr,    h->price,   h->p2o,     h->o2p,
                     h->U,       h->bid_key, h->bid_obj,   h->best_key,   h->best_pos, h->cnt,    h->hole_list,
-                    h->mover_list, h->ctl,  h->contrib,   h->nmatch,     h->launch_edges, h->tiled, h->tcol, h->seg4, h->rec, h->cand};
+                    h->mover_list, h->ctl,  h->contrib,   h->nmatch,     h->launch_edges, h->tiled, h->tcol, h->seg4, h->rec, h->cand,
+                    h->bid_rec};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_ctl) (void)hipHostFree(h->h_ctl);
+    if (h->h_stat) (void)hipHostFree(h->h_stat);
+    for (hipEvent_t e : h->stat_ev)
+        if (e) (void)hipEventDestroy(e);
     for (auto &r : h->prof) {
         (void)hipEventDestroy(r.start);
         (void)hipEventDestroy(r.stop);
@@ -588,6 +616,8 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
     if ((rc = dev_alloc(&h->U, N))) return rc;
     if ((rc = dev_alloc(&h->bid_key, N))) return rc;
     if ((rc = dev_alloc(&h->bid_obj, N))) return rc;
+    if ((rc = dev_alloc(&h->bid_rec, (size_t)kRoundSmallMax))) return rc;
+    HIP_TRY(hipMemsetAsync(h->bid_rec, 0, sizeof(int4) * kRoundSmallMax, h->stream));
     if ((rc = dev_alloc(&h->best_key, M))) return rc;
     if ((rc = dev_alloc(&h->best_pos, M))) return rc;
     if ((rc = dev_alloc(&h->cnt, 2 * ((N + kChunk - 1) / kChunk) + 2))) return rc;
@@ -597,6 +627,8 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
     if ((rc = dev_alloc(&h->contrib, N))) return rc;
     if ((rc = dev_alloc(&h->nmatch, N))) return rc;
     HIP_TRY(hipHostMalloc((void **)&h->h_ctl, sizeof(Ctl)));
+    HIP_TRY(hipHostMalloc((void **)&h->h_stat, 2 * sizeof(Ctl)));
+    for (hipEvent_t &e : h->stat_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     if (h->profile) {
         h->launch_edges_cap = 1 << 20;
         if ((rc = dev_alloc(&h->launch_edges, (size_t)h->launch_edges_cap))) return rc;
@@ -1130,20 +1162,37 @@ MISSLAP_API int misslap_solve(misslap_solver *h, int32_t *person_to_object_out, 
             if ((rc = read_ctl(h))) return rc;
             const Ctl &c = *h->h_ctl;
             if (c.K == 0 || c.nits >= h->max_iter) break;
-            if (c.K > h->thr) {
-                // rounds big enough for the tiled kernel are few (a handful per phase): enqueue them one at
-                // a time so that neither bid kernel is launched for a round the other one takes
-                // ... and while K is still above the small-round limit it falls fast (by a third or more per round):
-                // short batches there, so that the stale upper bound K_ub does not keep the four-launch path and a
-                // 2048-block bid grid alive for rounds that have long become small
-                const int batch = (h->tiled_ok && c.K >= h->tiled_min_K) ? 1
-                                  : c.K > kRoundSmallMax ? std::min(h->rounds_per_sync, kRoundsPerSyncLargeK)
-                                                         : h->rounds_per_sync;
-                for (int r = 0; r < batch; ++r) {
-                    if ((rc = launch_bid(h))) return rc;
-                    if ((rc = launch_tiebreak(h))) return rc;
-                    if ((rc = launch_apply(h))) return rc;
+            if (c.K > h->thr && h->tiled_ok && c.K >= h->tiled_min_K) {
+                // rounds big enough for the tiled kernel are few (a handful per phase): enqueued one at a time, K
+                // known exactly, so that neither bid kernel is launched for a round the other one takes
+                if ((rc = launch_bid(h))) return rc;
+                if ((rc = launch_tiebreak(h))) return rc;
+                if ((rc = launch_apply(h))) return rc;
+            } else if (c.K > h->thr) {
+                // Grid rounds in batches, the status read trailing by one batch (status_enqueue): these rounds are
+                // a few microseconds each, and a stream drained after every batch would idle the GPU for longer
+                // than a batch runs.  While K is still above the small-round limit it falls fast (by a third or
+                // more per round): short batches there, so that the stale upper bound K_ub does not keep the
+                // four-launch path and a 2048-block bid grid alive for rounds that have long become small.
+                int slot = 0;
+                bool outstanding = false;
+                for (bool stop = false; !stop; slot ^= 1) {
+                    const int batch = h->K_ub > kRoundSmallMax ? std::min(h->rounds_per_sync, kRoundsPerSyncLargeK)
+                                                               : h->rounds_per_sync;
+                    for (int r = 0; r < batch; ++r) {
+                        if ((rc = launch_bid(h))) return rc;
+                        if ((rc = launch_tiebreak(h))) return rc;
+                        if ((rc = launch_apply(h))) return rc;
+                    }
+                    if ((rc = status_enqueue(h, slot))) return rc;
+                    if (outstanding) {
+                        if ((rc = status_wait(h, slot ^ 1))) return rc;
+                        const Ctl &st = h->h_stat[slot ^ 1];
+                        stop = st.K <= h->thr || st.nits >= h->max_iter;
+                    }
+                    outstanding = true;
                 }
+                // (the read at the top of the loop drains the batch that is still in flight)
             } else {
                 if ((rc = launch_tail(h))) return rc;
             }
