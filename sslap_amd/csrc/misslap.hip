@@ -14,7 +14,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/misslap.h"
@@ -140,6 +142,7 @@ struct misslap_solver {
     bool tiled_ok = false;
     int tiled_min_K = 0;
     int tiled_shape = 0;  // index into kShapes of launch_bid_tiled
+    std::vector<void *> blocks;  // device memory of the arrays above (DevBlock), released as a whole
     Ctl *h_ctl = nullptr;  // pinned mirror
     Ctl *h_stat = nullptr;  // pinned [2]: status copies that trail the grid rounds by one batch (status_enqueue)
     hipEvent_t stat_ev[2] = {nullptr, nullptr};
@@ -189,6 +192,64 @@ struct DevScratch {
         return rc;
     }
 };
+
+// Several device arrays carved from ONE hipMalloc (256-byte aligned): hipMalloc / hipFree cost tens of microseconds
+// each and a handle holds some thirty arrays -- allocated one by one they are a fifth of the time it takes to set a
+// 40 M-edge problem up.  `want` registers an array, `commit` allocates and hands the pointers out; the block is
+// released as a whole (by the handle: misslap_solver::blocks, or by a DevScratch).
+struct DevBlock {
+    struct Item {
+        void **target;
+        size_t bytes;
+    };
+    std::vector<Item> items;
+    template <class T>
+    void want(T **p, size_t n) {
+        items.push_back({reinterpret_cast<void **>(p), (n ? n : 1) * sizeof(T)});
+    }
+    int commit(void **base_out) {
+        size_t total = 0;
+        for (const Item &it : items) total += (it.bytes + 255) & ~(size_t)255;
+        char *base = nullptr;
+        HIP_TRY(hipMalloc((void **)&base, total ? total : 256));
+        *base_out = base;
+        size_t off = 0;
+        for (const Item &it : items) {
+            *it.target = base + off;
+            off += (it.bytes + 255) & ~(size_t)255;
+        }
+        items.clear();
+        return MISSLAP_OK;
+    }
+};
+
+// Streams are kept across handles: creating one (a hardware queue) takes several milliseconds, more than everything
+// else a handle's setup does.  A destroyed handle parks its idle stream here; the next handle on that device takes it.
+struct StreamPool {
+    std::mutex m;
+    std::vector<std::pair<int, hipStream_t>> idle;
+    static constexpr size_t kMaxIdle = 8;
+    hipStream_t take(int device) {
+        std::lock_guard<std::mutex> g(m);
+        for (size_t k = 0; k < idle.size(); ++k)
+            if (idle[k].first == device) {
+                hipStream_t s = idle[k].second;
+                idle.erase(idle.begin() + (long)k);
+                return s;
+            }
+        return nullptr;
+    }
+    bool park(int device, hipStream_t s) {
+        std::lock_guard<std::mutex> g(m);
+        if (idle.size() >= kMaxIdle) return false;
+        idle.emplace_back(device, s);
+        return true;
+    }
+};
+StreamPool &stream_pool() {
+    static StreamPool *pool = new StreamPool();  // never destroyed: the HIP runtime may be gone at static teardown
+    return *pool;
+}
 
 RoundArgs round_args(misslap_solver *h) {
     RoundArgs a;
@@ -455,21 +516,18 @@ int run_ece(misslap_solver *h, float eps, int *ok) {
 void free_all(misslap_solver *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    void *ptrs[] = {h->edges32, h->col,     h->val64,     h->row_ptr,    h->price,   h->p2o,     h->o2p,
-                    h->U,       h->bid_key, h->bid_obj,   h->best_key,   h->best_pos, h->cnt,    h->hole_list,
-                    h->mover_list, h->ctl,  h->contrib,   h->nmatch,     h->launch_edges, h->tiled, h->tcol, h->seg4, h->rec, h->cand,
-                    h->bid_rec};
-    for (void *p : ptrs)
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->row_ptr) (void)hipFree(h->row_ptr);
+    for (void *p : h->blocks)
         if (p) (void)hipFree(p);
     if (h->h_ctl) (void)hipHostFree(h->h_ctl);
-    if (h->h_stat) (void)hipHostFree(h->h_stat);
     for (hipEvent_t e : h->stat_ev)
         if (e) (void)hipEventDestroy(e);
     for (auto &r : h->prof) {
         (void)hipEventDestroy(r.start);
         (void)hipEventDestroy(r.stop);
     }
-    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->own_stream && h->stream && !stream_pool().park(h->device, h->stream)) (void)hipStreamDestroy(h->stream);
     delete h;
 }
 
@@ -512,12 +570,16 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
     const int flip = h->maximize ? 0 : 1;
     if (h->f32) {
         if ((rc = dev_alloc(&h->edges32, (size_t)nnz + 4 * kWave))) return rc;  // tail kernel reads up to 256 past a row start
+        h->blocks.push_back(h->edges32);
         HIP_TRY(hipMemsetAsync(h->edges32 + nnz, 0, sizeof(int2) * 4 * kWave, h->stream));
         hipLaunchKernelGGL(k_build_edges_f32, dim3(grid), dim3(256), 0, h->stream, d_loc, d_val, (long long)nnz,
                            flip, h->edges32);
     } else {
-        if ((rc = dev_alloc(&h->col, (size_t)nnz + 4 * kWave))) return rc;
-        if ((rc = dev_alloc(&h->val64, (size_t)nnz + 4 * kWave))) return rc;
+        DevBlock blk;
+        blk.want(&h->col, (size_t)nnz + 4 * kWave);
+        blk.want(&h->val64, (size_t)nnz + 4 * kWave);
+        h->blocks.push_back(nullptr);
+        if ((rc = blk.commit(&h->blocks.back()))) return rc;
         HIP_TRY(hipMemsetAsync(h->col + nnz, 0, sizeof(int) * 4 * kWave, h->stream));
         HIP_TRY(hipMemsetAsync(h->val64 + nnz, 0, sizeof(double) * 4 * kWave, h->stream));
         hipLaunchKernelGGL(k_build_edges_f64, dim3(grid), dim3(256), 0, h->stream, d_loc, d_val, (long long)nnz,
@@ -550,12 +612,17 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
             h->T = T;
             const int nchunks = (int)((L + kScanChunk - 1) / kScanChunk);
             int *cnt = nullptr, *len = nullptr, *lrel = nullptr, *start = nullptr, *sums = nullptr, *flag = nullptr;
-            if ((rc = tmp.alloc(&cnt, (size_t)L))) return rc;
-            if ((rc = tmp.alloc(&len, (size_t)L))) return rc;
-            if ((rc = tmp.alloc(&lrel, (size_t)L))) return rc;
-            if ((rc = tmp.alloc(&start, (size_t)L + 1))) return rc;
-            if ((rc = tmp.alloc(&sums, (size_t)nchunks + 1))) return rc;
-            if ((rc = tmp.alloc(&flag, 1))) return rc;
+            {
+                DevBlock blk;
+                blk.want(&cnt, (size_t)L);
+                blk.want(&len, (size_t)L);
+                blk.want(&lrel, (size_t)L);
+                blk.want(&start, (size_t)L + 1);
+                blk.want(&sums, (size_t)nchunks + 1);
+                blk.want(&flag, 1);
+                tmp.ptrs.push_back(nullptr);
+                if ((rc = blk.commit(&tmp.ptrs.back()))) return rc;
+            }
             HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)L, h->stream));
             HIP_TRY(hipMemsetAsync(len, 0, sizeof(int) * (size_t)L, h->stream));
             HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), h->stream));
@@ -570,10 +637,15 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
             HIP_TRY(hipStreamSynchronize(h->stream));
             if (!unsorted && total > 0 && total < 0x1ffffff0) {
                 h->n_tiled = total;
-                if ((rc = dev_alloc(&h->tiled, (size_t)total + 16))) return rc;
-                if ((rc = dev_alloc(&h->seg4, (size_t)L + 2))) return rc;
+                {
+                    DevBlock blk;
+                    blk.want(&h->tiled, (size_t)total + 16);
+                    blk.want(&h->seg4, (size_t)L + 2);
+                    blk.want(&h->tcol, (size_t)total + 16);
+                    h->blocks.push_back(nullptr);
+                    if ((rc = blk.commit(&h->blocks.back()))) return rc;
+                }
                 HIP_TRY(hipMemsetAsync(h->tiled, 0, sizeof(int2) * ((size_t)total + 16), h->stream));
-                if ((rc = dev_alloc(&h->tcol, (size_t)total + 16))) return rc;
                 HIP_TRY(hipMemsetAsync(h->tcol, 0, sizeof(int) * ((size_t)total + 16), h->stream));
                 // k_bid_tiled: 6-byte packed edges holding price slots (buffer stride of the double-buffered shapes)
                 const int buf_stride = tcols == kTileColsBig ? 0 : tcols + 128;
@@ -606,34 +678,40 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
             HIP_TRY(hipStreamSynchronize(h->stream));  // the temporaries are released at scope exit
         }
     }
-    if ((rc = dev_alloc(&h->price, Mpad))) return rc;
-    HIP_TRY(hipMemsetAsync(h->price, 0, sizeof(double) * Mpad, h->stream));
-    if ((rc = dev_alloc(&h->rec, M))) return rc;
-    if (h->f32 && !opt->reserved[4])  // candidate lines (reserved[4] != 0: off, A/B timing and parity tests)
-        if ((rc = dev_alloc(&h->cand, N * (size_t)kCandLanes))) return rc;
-    if ((rc = dev_alloc(&h->p2o, N))) return rc;
-    if ((rc = dev_alloc(&h->o2p, M))) return rc;
-    if ((rc = dev_alloc(&h->U, N))) return rc;
-    if ((rc = dev_alloc(&h->bid_key, N))) return rc;
-    if ((rc = dev_alloc(&h->bid_obj, N))) return rc;
-    if ((rc = dev_alloc(&h->bid_rec, (size_t)kRoundSmallMax))) return rc;
-    HIP_TRY(hipMemsetAsync(h->bid_rec, 0, sizeof(int4) * kRoundSmallMax, h->stream));
-    if ((rc = dev_alloc(&h->best_key, M))) return rc;
-    if ((rc = dev_alloc(&h->best_pos, M))) return rc;
-    if ((rc = dev_alloc(&h->cnt, 2 * ((N + kChunk - 1) / kChunk) + 2))) return rc;
-    if ((rc = dev_alloc(&h->hole_list, N))) return rc;
-    if ((rc = dev_alloc(&h->mover_list, N))) return rc;
-    if ((rc = dev_alloc(&h->ctl, 1))) return rc;
-    if ((rc = dev_alloc(&h->contrib, N))) return rc;
-    if ((rc = dev_alloc(&h->nmatch, N))) return rc;
-    HIP_TRY(hipHostMalloc((void **)&h->h_ctl, sizeof(Ctl)));
-    HIP_TRY(hipHostMalloc((void **)&h->h_stat, 2 * sizeof(Ctl)));
-    for (hipEvent_t &e : h->stat_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    if (h->profile) {
-        h->launch_edges_cap = 1 << 20;
-        if ((rc = dev_alloc(&h->launch_edges, (size_t)h->launch_edges_cap))) return rc;
-        HIP_TRY(hipMemsetAsync(h->launch_edges, 0, sizeof(unsigned long long) * h->launch_edges_cap, h->stream));
+    {
+        DevBlock blk;
+        blk.want(&h->price, Mpad);
+        blk.want(&h->rec, M);
+        if (h->f32 && !opt->reserved[4])  // candidate lines (reserved[4] != 0: off, A/B timing and parity tests)
+            blk.want(&h->cand, N * (size_t)kCandLanes);
+        blk.want(&h->p2o, N);
+        blk.want(&h->o2p, M);
+        blk.want(&h->U, N);
+        blk.want(&h->bid_key, N);
+        blk.want(&h->bid_obj, N);
+        blk.want(&h->bid_rec, (size_t)kRoundSmallMax);
+        blk.want(&h->best_key, M);
+        blk.want(&h->best_pos, M);
+        blk.want(&h->cnt, 2 * ((N + kChunk - 1) / kChunk) + 2);
+        blk.want(&h->hole_list, N);
+        blk.want(&h->mover_list, N);
+        blk.want(&h->ctl, 1);
+        blk.want(&h->contrib, N);
+        blk.want(&h->nmatch, N);
+        if (h->profile) {
+            h->launch_edges_cap = 1 << 20;
+            blk.want(&h->launch_edges, (size_t)h->launch_edges_cap);
+        }
+        h->blocks.push_back(nullptr);
+        if ((rc = blk.commit(&h->blocks.back()))) return rc;
     }
+    HIP_TRY(hipMemsetAsync(h->price, 0, sizeof(double) * Mpad, h->stream));
+    HIP_TRY(hipMemsetAsync(h->bid_rec, 0, sizeof(int4) * kRoundSmallMax, h->stream));
+    if (h->profile)
+        HIP_TRY(hipMemsetAsync(h->launch_edges, 0, sizeof(unsigned long long) * h->launch_edges_cap, h->stream));
+    HIP_TRY(hipHostMalloc((void **)&h->h_ctl, 3 * sizeof(Ctl)));  // the mirror and the two trailing status copies
+    h->h_stat = h->h_ctl + 1;
+    for (hipEvent_t &e : h->stat_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     h->shard_min_K = h->tiled_ok ? h->tiled_min_K : (int)std::max<size_t>((N * 3) / 10, 8192);
     if (opt->reserved[3] > 0) h->shard_min_K = opt->reserved[3];
     if (opt->reserved[3] < 0) h->shard_min_K = 0;  // every grid round sharded + exchanged
@@ -695,7 +773,8 @@ int new_handle(misslap_solver **out, const misslap_options *opt, misslap_solver 
     h->rank = opt->shard_world > 0 ? opt->shard_rank : 0;
     h->profile = opt->profile != 0;
     h->profile_all = opt->profile >= 2;
-    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+    h->stream = stream_pool().take(h->device);
+    if (!h->stream && hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;
         return fail(MISSLAP_ERR_HIP, "hipStreamCreate failed");
     }
