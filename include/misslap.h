@@ -56,6 +56,11 @@ typedef struct misslap_options {
                                 [3]: multi-GPU shard threshold: 0 = default (the full-scan threshold, 0.3 N), > 0 = minimum K
                                      of a sharded round, < 0 = shard every grid round;
                                 [4]: 1 = no candidate lines (every bid scans its whole row; A/B timing, parity tests);
+                                [5]: 1 = partial rounds of the full-scan engine take their bidders in list order instead of
+                                     person order (A/B timing, parity tests);
+                                [7]: candidate-line tuning: bits 0..23 > 0 = k_bid (re)builds lines only in rounds with at
+                                     most so many bidders (default: all its rounds); bits 24..29 = r + 1: a line hit with
+                                     fewer than r live candidates is rebuilt (0 = library default, 1 = never);
                                 [6]: > 0 lowers the entry limit of a handle (default 2^31 - 1: int32 row pointers), for
                                      tests of that guard */
 } misslap_options;

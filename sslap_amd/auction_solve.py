@@ -27,7 +27,7 @@ _ENV_TILED = "MISSLAP_TILED_MIN_K"  # 0 default, < 0 never use the LDS-tiled bid
 
 def _options(problem, eps_start, max_iter, device=None, tail_threshold=None, profile=None, force_f64=False,
              input_on_device=False, shard=None, rounds_per_sync=None, tiled_min_k=None, tiled_shape=None, shard_min_k=None,
-             engine=None, cand=None, nnz_limit=None):
+             engine=None, cand=None, nnz_limit=None, order_partial=None, cand_build_max_k=None, cand_refresh=None):
     if problem not in ("min", "max"):
         # the reference treats every string other than 'min' as 'max' (auction_.pyx:236, :502)
         problem = "max" if problem != "min" else "min"
@@ -52,6 +52,13 @@ def _options(problem, eps_start, max_iter, device=None, tail_threshold=None, pro
     o.reserved[3] = int(os.environ.get("MISSLAP_SHARD_MIN_K", 0)) if shard_min_k is None else int(shard_min_k)
     # candidate lines (per-person exact bid shortcut, csrc/device_common.hpp): on by default, 0 = off (A/B runs)
     o.reserved[4] = (1 - int(os.environ.get("MISSLAP_CAND", 1))) if cand is None else (0 if cand else 1)
+    # partial rounds of the full-scan engine in person order (kernels_tiled.hpp, k_order_*): on by default, 0 = list order
+    o.reserved[5] = ((1 - int(os.environ.get("MISSLAP_ORDER_PARTIAL", 1))) if order_partial is None
+                     else (0 if order_partial else 1))
+    o.reserved[7] = int(os.environ.get("MISSLAP_CAND_BUILD_MAX_K", 0)) if cand_build_max_k is None else int(cand_build_max_k)
+    # k_bid rebuilds a line that hits with fewer live candidates than this (None / env unset = library default)
+    refresh = os.environ.get("MISSLAP_CAND_REFRESH") if cand_refresh is None else cand_refresh
+    o.reserved[7] |= (0 if refresh is None else int(refresh) + 1) << 24
     o.reserved[6] = 0 if nnz_limit is None else int(nnz_limit)  # tests of the int32 row-pointer guard
     return o
 

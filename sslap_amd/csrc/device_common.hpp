@@ -344,20 +344,20 @@ __device__ __forceinline__ PriceRec cand_gather2(const int2 slot, const bool act
 template <class Early, class S = NoStamp>
 __device__ __forceinline__ void cand_eval2_r(int2 &slot, const PriceRec r, const bool act0, const bool act1,
                                              const double eps, CandBid (&out)[2], int &err, Early &&early,
-                                             const S &stamp = S());
+                                             const S &stamp = S(), int *alive = nullptr);
 template <class Src, class Early, class S = NoStamp>
 __device__ __forceinline__ void cand_eval2(int2 &slot, const bool act0, const bool act1, const Src &src,
                                            const double eps, CandBid (&out)[2], int &err, Early &&early,
-                                           const S &stamp = S()) {
+                                           const S &stamp = S(), int *alive = nullptr) {
     stamp(1);  // (diagnostic builds: drains the memory counters) the line has landed
     const PriceRec r = cand_gather2(slot, act0, act1, src);
     stamp(2);  // the records have landed
-    cand_eval2_r(slot, r, act0, act1, eps, out, err, early, stamp);
+    cand_eval2_r(slot, r, act0, act1, eps, out, err, early, stamp, alive);
 }
 template <class Early, class S>
 __device__ __forceinline__ void cand_eval2_r(int2 &slot, const PriceRec r, const bool act0, const bool act1,
                                              const double eps, CandBid (&out)[2], int &err, Early &&early,
-                                             const S &stamp) {
+                                             const S &stamp, int *alive) {
     const int lane = lane_id(), l32 = lane & (kCandLanes - 1);
     const double ninf = -__builtin_huge_val();
     const bool active = lane < kCandLanes ? act0 : act1;
@@ -369,6 +369,11 @@ __device__ __forceinline__ void cand_eval2_r(int2 &slot, const PriceRec r, const
     out[0].len = __builtin_amdgcn_readlane(slot.x, kCandLanes - 1);
     out[1].len = __builtin_amdgcn_readlane(slot.x, 2 * kCandLanes - 1);
     const double v = is_cand ? cost - r.price : ninf;  // vi = cost - p[j]   (:350)
+    if (alive) {  // (callers that ask: k_bid) candidates still at or above tau: how much life the line has left
+        const unsigned long long al = __ballot(is_cand & (v >= (lane < kCandLanes ? tau[0] : tau[1])));
+        alive[0] = __popc((unsigned)al);
+        alive[1] = __popc((unsigned)(al >> 32));
+    }
     // (Straight-line on purpose: a "winner first" shortcut -- one 32-bit reduction on the values' high words, a ballot
     // and a wave-uniform branch -- was measured 3-4 % SLOWER here: in this latency-bound single-wavefront code the
     // scalar compare / branch / indexed-readlane chain costs more than the 64-bit DPP pass it saves.)

@@ -39,6 +39,8 @@ struct RoundArgs {
     int launch_idx;
     int gather_max_K;             // k_bid runs only for K < gather_max_K (k_bid_tiled takes the rest); 0 = no limit
     int2 *cand;                   // candidate lines (device_common.hpp); nullptr = none (12 B/edge layout)
+    int cand_build_max_K;         // k_bid (re)builds a missed line only in rounds with K <= this
+    int cand_refresh_min;         // ... and treats a hit that leaves fewer live candidates than this as a miss
 };
 
 __device__ __forceinline__ bool round_live(const Ctl *c, int thr) {
@@ -116,13 +118,18 @@ __global__ __launch_bounds__(kBidBlock) void k_bid(RoundArgs a, E ed) {
         if (lines) {
             const int2 slot = a.cand[(size_t)i * kCandLanes + (lane & (kCandLanes - 1))];
             int2 sl = slot;
-            cand_eval2(sl, true, false, src, eps, b, err, NoEarly());
+            int alive[2];
+            cand_eval2(sl, true, false, src, eps, b, err, NoEarly(), NoStamp(), alive);
+            // A hit on a line with little life left is answered by a full scan all the same -- the bid is the same
+            // bid -- so that the line is rebuilt HERE, where a scan is one of many in flight, and not by a miss in
+            // the tail kernel, where a scan is the whole round.
+            if (alive[0] < a.cand_refresh_min && head.K <= a.cand_build_max_K) b[0].hit = false;
         }
         if (!b[0].hit) {  // wave-uniform
             CandBuildArgs ba;
             const typename E::Raw none[4] = {};
             wave_bid_full<E, Src, false, false>(ed, src, s, e, none, eps, b[0], ba, err);
-            if (lines && ba.want) cand_build(a.cand, i, ba, eps, hint);
+            if (lines && ba.want && head.K <= a.cand_build_max_K) cand_build(a.cand, i, ba, eps, hint);
         } else {
             nh += 1;
             hit_edges += (unsigned long long)b[0].len;
@@ -171,12 +178,15 @@ __global__ __launch_bounds__(kBidBlock) void k_bid(RoundArgs a, E ed) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_tiebreak(RoundArgs a) {
+// order_pos: the bidders of this rank's shard were taken in person order (k_bid_tiled, partial rounds): shard slot
+// -> list position; nullptr = the shard is a range of list positions
+__global__ __launch_bounds__(256) void k_tiebreak(RoundArgs a, const int *order_pos) {
     const Ctl *ctl = a.ctl;
     if (!round_live(ctl, a.thr)) return;
     int lo, hi;
     shard_range(ctl->K, a.rank, a.world, a.shard_min_K, lo, hi);
-    for (int n = lo + blockIdx.x * blockDim.x + threadIdx.x; n < hi; n += gridDim.x * blockDim.x) {
+    for (int r = lo + blockIdx.x * blockDim.x + threadIdx.x; r < hi; r += gridDim.x * blockDim.x) {
+        const int n = order_pos ? order_pos[r] : r;
         const int j = a.bid_obj[n];
         if (a.bid_key[n] == a.best_key[j]) atomicMin(&a.best_pos[j], n);
     }

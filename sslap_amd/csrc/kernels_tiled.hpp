@@ -209,6 +209,62 @@ __global__ __launch_bounds__(256) void k_tile_scatter(const int2 *edges, const i
     }
 }
 
+// ---- bidders in person order (partial rounds) -----------------------------------------------------------------
+// The unassigned list U is in the reference's order, which every round shuffles (evicted owners inherit the slots of
+// the winners, push_all_left moves persons from the end into the holes).  In a round with K < N adjacent lane groups
+// would then read segments scattered all over the tile-major copy, every 60-byte segment pulling its own 128-byte
+// lines: PMC showed up to 521 MB of reads for such a round at C3 -- more than the 337 MB of a FULL scan.  So the
+// bidders of a partial round are taken in person order: rank of person i = number of unassigned persons below i
+// (p2o[i] == -1), and the bid is stored at the person's true list position (the tie rule of :379 is about list
+// positions).  Four small launches ahead of the bid kernel: inverse of U, chunk counts, scan of the counts (the ingest's
+// k_scan_of_sums), ranks + scatter.
+__global__ __launch_bounds__(256) void k_order_inverse(const Ctl *ctl, const int *U, int *pos_of) {
+    const int K = ctl->K;
+    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < K; n += gridDim.x * blockDim.x) pos_of[U[n]] = n;
+}
+__global__ __launch_bounds__(1024) void k_order_sums(const int *p2o, int n_rows, int *sums) {
+    __shared__ int s_w[16];
+    const int base = blockIdx.x * kScanChunk;
+    int v = 0;
+    for (int q = 0; q < 4; ++q) {
+        const int k = base + q * 1024 + threadIdx.x;
+        v += (k < n_rows && p2o[k] == -1);
+    }
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < 16; ++w) t += s_w[w];
+        sums[blockIdx.x] = t;
+    }
+}
+__global__ __launch_bounds__(1024) void k_order_scatter(const int *p2o, int n_rows, const int *sums, const int *pos_of,
+                                                        int *order_person, int *order_pos) {
+    __shared__ int s_w[16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    int carry = sums[blockIdx.x];  // (exclusive: unassigned persons in the chunks before this one)
+    for (int q = 0; q < 4; ++q) {
+        const int i = blockIdx.x * kScanChunk + q * 1024 + t;
+        const bool un = i < n_rows && p2o[i] == -1;
+        const unsigned long long b = __ballot(un);
+        __syncthreads();  // s_w of the previous pass is no longer read
+        if (lane == 0) s_w[wave] = __popcll(b);
+        __syncthreads();
+        int wpre = 0, tot = 0;
+        for (int w2 = 0; w2 < 16; ++w2) {
+            if (w2 < wave) wpre += s_w[w2];
+            tot += s_w[w2];
+        }
+        if (un) {
+            const int r = carry + wpre + __popcll(b & lanemask_lt());
+            order_person[r] = i;
+            order_pos[r] = pos_of[i];
+        }
+        carry += tot;
+    }
+}
+
 // ---- the kernel -------------------------------------------------------------------------------------------
 __device__ __forceinline__ double group8_max_f64(double v) {
     {
@@ -289,6 +345,8 @@ struct TiledArgs {
     int T;               // number of column tiles
     int min_K;           // the kernel runs only for K >= min_K (k_bid takes the smaller rounds)
     int nnz;             // entries of the tile-major copy incl. padding (leftover loads are clamped below it)
+    const int *order_person;  // bidders in person order and their list positions (partial rounds, see k_order_*);
+    const int *order_pos;     // nullptr: list order (full scans: U is the identity)
 };
 
 // All global loads of the tile loop are UNCONDITIONAL (masked-off lanes read a clamped, valid address and
@@ -363,7 +421,7 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
 #pragma unroll
     for (int j = 0; j < kTileRows; ++j) {
         const int pos = p0 + j * kTileGroups + group;
-        const int u = a.U[min(pos, p1 - 1)];  // unconditional load (see the note above), masked afterwards
+        const int u = (ta.order_person ? ta.order_person : a.U)[min(pos, p1 - 1)];  // unconditional load (see the note above), masked afterwards
         person[j] = (pos < p1 && !loader) ? u : -1;
         sv[j] = ninf;
         sw[j] = ninf;
@@ -635,7 +693,8 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
             const double bid = (cost - W[j]) + eps;  // :360
             if (bid_is_bad(bid)) err |= kErrNegativeBid;
             const unsigned long long key = bid_to_key(bid);
-            const int pos = p0 + j * kTileGroups + group;
+            const int slot = p0 + j * kTileGroups + group;
+            const int pos = ta.order_pos ? ta.order_pos[slot] : slot;
             a.bid_key[pos] = key;
             a.bid_obj[pos] = best[j].x;
             atomicMax(&a.best_key[best[j].x], key);

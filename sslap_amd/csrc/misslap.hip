@@ -72,6 +72,12 @@ double now_ms() {
 constexpr int kDefaultTailThreshold = 96;
 constexpr int kDefaultTailThresholdBig = 128;  // n_cols > kTailBigCols
 constexpr long long kTailBigCols = 500000;
+// k_bid answers a line hit that leaves fewer live candidates than this by a full scan + rebuild (kernels_round.hpp).
+// Lines are built in the grid rounds but earn their keep in the tail kernel, tens of thousands of rounds later: a
+// line that still hits in a grid round but is nearly spent would miss THERE, where a row scan is the whole round and
+// not one of hundreds in flight.  C3 solve 590 ms without, 511 (10), 498 (16), 493 (22), 491 (24), 493 (26), 496 (31);
+// the tail's misses fall from 6.5 % to 1.0 % of its bids.  C2 187 -> 160 ms, C5 4.61 -> 3.86 s (24).
+constexpr int kDefaultCandRefresh = 24;
 constexpr int kDefaultRoundsPerSync = 16;
 constexpr int kRoundsPerSyncLargeK = 2;  // batch length while K > kRoundSmallMax
 constexpr int kMaxGridBlocks = 2048;  // 256 CUs x 8 resident 256-thread blocks
@@ -153,6 +159,10 @@ struct misslap_solver {
     int64_t max_iter = 0;
     int thr = -1;
     bool round_small = false;  // the current round's bids skip the global atomicMax and k_round_small finishes it
+    int cand_build_max_K = 0x7fffffff;
+    int cand_refresh_min = kDefaultCandRefresh;
+    bool round_ordered = false;  // the current round's bidders were taken in person order (k_order_*, partial tiled rounds)
+    bool order_partial = true;   // ... which options.reserved[5] = 1 turns off (A/B, parity tests)
     bool profile_all = false;  // profile >= 2: events around every k_bid launch, not only the full scans
     int rounds_per_sync = kDefaultRoundsPerSync;
     int rank = 0, world = 1;
@@ -279,6 +289,8 @@ RoundArgs round_args(misslap_solver *h) {
     a.launch_idx = 0;
     a.gather_max_K = h->tiled_ok ? h->tiled_min_K : 0;
     a.cand = h->cand;
+    a.cand_build_max_K = h->cand_build_max_K;
+    a.cand_refresh_min = h->cand_refresh_min;
     return a;
 }
 
@@ -343,7 +355,23 @@ int launch_bid_tiled(misslap_solver *h) {
     const long long resident = 256;  // one workgroup per CU: its two price tiles take the whole LDS
     const long long spread = std::min<long long>(resident, (share + groups - 1) / groups);
     if (grid < spread) grid = spread;
-    TiledArgs ta{reinterpret_cast<const unsigned *>(h->tiled), h->tcol, h->seg4, h->T, h->tiled_min_K, h->n_tiled};
+    TiledArgs ta{reinterpret_cast<const unsigned *>(h->tiled), h->tcol, h->seg4, h->T, h->tiled_min_K, h->n_tiled,
+                 nullptr, nullptr};
+    // A partial round whose K the host knows: bidders in person order (kernels_tiled.hpp, k_order_*).  Scratch that
+    // is idle during a bid phase: the compaction lists (the tie-break reads order_pos before they are rewritten),
+    // the chunk counters, the objective's match counters.
+    h->round_ordered = h->order_partial && !h->phase_fresh && h->K_exact && h->K_ub < h->n_rows;
+    if (h->round_ordered) {
+        int *pos_of = h->nmatch, *order_person = h->hole_list, *order_pos = h->mover_list, *sums = h->cnt;
+        const int nchunks = (h->n_rows + kScanChunk - 1) / kScanChunk;
+        hipLaunchKernelGGL(k_order_inverse, dim3(blocks_for(h->K_ub, 256)), dim3(256), 0, h->stream, h->ctl, h->U, pos_of);
+        hipLaunchKernelGGL(k_order_sums, dim3(nchunks), dim3(1024), 0, h->stream, h->p2o, h->n_rows, sums);
+        hipLaunchKernelGGL(k_scan_of_sums, dim3(1), dim3(1024), 0, h->stream, sums, nchunks);
+        hipLaunchKernelGGL(k_order_scatter, dim3(nchunks), dim3(1024), 0, h->stream, h->p2o, h->n_rows, sums, pos_of,
+                           order_person, order_pos);
+        ta.order_person = order_person;
+        ta.order_pos = order_pos;
+    }
     ProfRec *pr = nullptr;
     if (h->profile) {
         if (h->launch_idx >= h->launch_edges_cap)
@@ -423,7 +451,8 @@ int launch_tiebreak(misslap_solver *h) {
     if (h->round_small) return MISSLAP_OK;  // k_round_small (launch_apply) resolves the ties itself
     RoundArgs a = round_args(h);
     const long long share = h->K_ub;
-    hipLaunchKernelGGL(k_tiebreak, dim3(blocks_for(share, 256)), dim3(256), 0, h->stream, a);
+    hipLaunchKernelGGL(k_tiebreak, dim3(blocks_for(share, 256)), dim3(256), 0, h->stream, a,
+                       h->round_ordered ? h->mover_list : nullptr);
     HIP_TRY(hipGetLastError());
     return MISSLAP_OK;
 }
@@ -438,6 +467,7 @@ int launch_apply(misslap_solver *h) {
         return MISSLAP_OK;
     }
     h->K_exact = false;
+    h->round_ordered = false;
     hipLaunchKernelGGL(k_apply, dim3(blocks_for(h->n_cols, 256)), dim3(256), 0, h->stream, a);
     if (h->K_ub <= kCompactSmallMax) {
         hipLaunchKernelGGL(k_compact_small, dim3(1), dim3(1024), 0, h->stream, a);
@@ -768,6 +798,9 @@ int new_handle(misslap_solver **out, const misslap_options *opt, misslap_solver 
     h->device = opt->device;
     h->maximize = opt->maximize ? 1 : 0;
     h->thr = opt->tail_threshold >= 0 ? opt->tail_threshold : -1;  // -1: resolved in build_from_device_coo
+    h->order_partial = opt->reserved[5] == 0;
+    if ((opt->reserved[7] & 0xffffff) > 0) h->cand_build_max_K = opt->reserved[7] & 0xffffff;
+    if ((opt->reserved[7] >> 24) & 63) h->cand_refresh_min = ((opt->reserved[7] >> 24) & 63) - 1;
     h->rounds_per_sync = opt->rounds_per_sync > 0 ? opt->rounds_per_sync : kDefaultRoundsPerSync;
     h->world = opt->shard_world > 0 ? opt->shard_world : 1;
     h->rank = opt->shard_world > 0 ? opt->shard_rank : 0;

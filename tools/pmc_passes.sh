@@ -15,6 +15,7 @@ G[tcc2]="TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_
 G[sq1]="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
 G[sq2]="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM"
 G[tcc3]="TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum"
+G[fetch]="FETCH_SIZE"
 for g in "$@"; do
   timeout -k 10 200 rocprofv3 --kernel-trace --pmc ${G[$g]} -d "$O/$g" -o "$g" --output-format csv -- python3 "$R/tools/pmc_scan.py" C3 2 > "$O/$g.log" 2>&1 || { echo "pass $g failed"; tail -5 "$O/$g.log"; exit 1; }
 done

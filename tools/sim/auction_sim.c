@@ -43,6 +43,10 @@ int main(int argc, char **argv) {
     }
     const int C = atoi(argv[2]), policy = atoi(argv[3]), build_thr = atoi(argv[4]), use_thr = atoi(argv[5]);
     const int cmin = getenv("SIM_CMIN") ? atoi(getenv("SIM_CMIN")) : (C + 1) / 2;
+    /* SIM_REFRESH=A: a hit that leaves fewer than A cached candidates at or above tau rebuilds the cache right away
+     * ("background" rebuild by an idle wavefront: counted separately, the bid itself stays a hit) */
+    const int refresh = getenv("SIM_REFRESH") ? atoi(getenv("SIM_REFRESH")) : 0;
+    int64_t bg_builds = 0;
     FILE *f = fopen(argv[1], "rb");
     if (!f) return 2;
     int64_t nnz;
@@ -107,11 +111,12 @@ int main(int argc, char **argv) {
                 else if (v > wi) wi = v;
             }
             if (C > 0 && (use || build)) {
-                int hit = 0;
+                int hit = 0, alive = 0;
                 if (c_valid[i]) {
                     double vc = -INFINITY, wc = -INFINITY;
                     for (int k = 0; k < c_n[i]; ++k) {
                         const double v = c_cost[(size_t)i * C + k] - p[c_col[(size_t)i * C + k]];
+                        alive += v >= c_tau[i];
                         if (v >= vc) wc = vc, vc = v;
                         else if (v > wc) wc = v;
                     }
@@ -125,8 +130,10 @@ int main(int argc, char **argv) {
                     hits[mode] += hit;
                     round_hits += hit;
                 }
-                if (!hit && build) {
-                    builds++;
+                const int bg = hit && build && alive < refresh;
+                bg_builds += bg;
+                if ((!hit || bg) && build) {
+                    builds += !bg;
                     const int len = e - s;
                     for (int g = s; g < e; ++g) tmpv[g - s] = val[g] - p[col[g]];
                     double t;
@@ -242,8 +249,9 @@ int main(int argc, char **argv) {
     uint64_t h = 1469598103934665603ull;
     for (int i = 0; i < N; ++i) h = (h ^ (uint64_t)(uint32_t)p2o[i]) * 1099511628211ull;
     printf("{\"its\": %lld, \"nreductions\": %d, \"sol_fnv\": \"%016llx\", \"C\": %d, \"policy\": %d, \"build_thr\": %d, "
-           "\"use_thr\": %d, \"inconsistent\": %lld, \"builds\": %lld,\n \"modes\": [",
-           (long long)its, nred, (unsigned long long)h, C, policy, build_thr, use_thr, (long long)bad, (long long)builds);
+           "\"use_thr\": %d, \"inconsistent\": %lld, \"builds\": %lld, \"bg_builds\": %lld,\n \"modes\": [",
+           (long long)its, nred, (unsigned long long)h, C, policy, build_thr, use_thr, (long long)bad, (long long)builds,
+           (long long)bg_builds);
     const char *names[7] = {"K=1", "K=2", "K=3..16", "K=17..64", "K=65..512", "K=513..2048", "K>2048"};
     for (int m = 0; m < 7; ++m)
         printf("%s{\"mode\": \"%s\", \"rounds_all\": %lld, \"rounds\": %lld, \"bids\": %lld, \"hit_rate\": %.4f, "
