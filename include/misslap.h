@@ -245,6 +245,14 @@ typedef struct misslap_round_ops {
     void *best_pos;    /* int32[n_objects] */
     int64_t n_objects;
     void *stream;      /* handed to the communicator's callbacks */
+    /* Optional (both or neither): a status read that does not drain the queue.  status_post enqueues a copy of the
+     * round state behind everything issued so far into slot 0 / 1; status_take waits for THAT copy only.  With them
+     * the replicated rounds are issued in batches whose status trails by one batch (K never grows inside an
+     * eps-phase and a round that is not live is a no-op, so a batch issued on a stale "go on" is harmless). */
+    int (*status_post)(void *ctx, int32_t slot);
+    int (*status_take)(void *ctx, int32_t slot, int64_t *K, int64_t *its);
+    int32_t large_round_K;          /* while K > this ... */
+    int32_t rounds_per_sync_large;  /* ... a batch has so many rounds (<= 0: rounds_per_sync) */
 } misslap_round_ops;
 int misslap_drive_sharded(const misslap_round_ops *ops, misslap_comm *comm);
 

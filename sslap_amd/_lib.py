@@ -60,6 +60,8 @@ class CommOps(C.Structure):
 _OP0 = C.CFUNCTYPE(C.c_int, C.c_void_p)
 _OP_STATUS = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64))
 _OP_PHASE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int32))
+_OP_POST = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32)
+_OP_TAKE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64))
 
 
 class RoundOps(C.Structure):
@@ -67,7 +69,9 @@ class RoundOps(C.Structure):
                 ("rounds_per_sync", C.c_int32), ("max_iter", C.c_int64), ("ctx", C.c_void_p),
                 ("status", _OP_STATUS), ("round_bid", _OP0), ("round_tiebreak", _OP0), ("round_apply", _OP0),
                 ("run_tail", _OP0), ("phase_end", _OP_PHASE), ("best_key", C.c_void_p), ("best_pos", C.c_void_p),
-                ("n_objects", C.c_int64), ("stream", C.c_void_p)]
+                ("n_objects", C.c_int64), ("stream", C.c_void_p),
+                ("status_post", _OP_POST), ("status_take", _OP_TAKE), ("large_round_K", C.c_int32),
+                ("rounds_per_sync_large", C.c_int32)]
 
 
 # every symbol include/misslap.h declares: (name, restype, argtypes)

@@ -14,8 +14,10 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstring>
 #include <mutex>
+#include <string>
 
 #include "../../include/misslap.h"
 
@@ -111,11 +113,40 @@ int drive_sharded(const misslap_round_ops *o, misslap_comm *c, Fail &&fail) {
                 if ((rc = o->round_apply(o->ctx))) return rc;
             } else if (K > o->tail_threshold) {
                 // K never grows inside a phase: from here on every rank bids for everybody (replicated,
-                // deterministic), no exchange; several rounds per status read
-                for (int r = 0; r < (o->rounds_per_sync > 0 ? o->rounds_per_sync : 1); ++r) {
-                    if ((rc = o->round_bid(o->ctx))) return rc;
-                    if ((rc = o->round_tiebreak(o->ctx))) return rc;
-                    if ((rc = o->round_apply(o->ctx))) return rc;
+                // deterministic), no exchange; several rounds per status read.  While K is still large it falls
+                // fast (by a third or more per round): short batches there, so that a stale upper bound of K does
+                // not keep the big-round launch shapes alive for rounds that have long become small.
+                auto batch_of = [&](int64_t k) {
+                    const int rps = o->rounds_per_sync > 0 ? o->rounds_per_sync : 1;
+                    return k > o->large_round_K && o->rounds_per_sync_large > 0 ? std::min(rps, o->rounds_per_sync_large)
+                                                                                 : rps;
+                };
+                auto issue = [&](int n) -> int {
+                    for (int r = 0; r < n; ++r) {
+                        if ((rc = o->round_bid(o->ctx))) return rc;
+                        if ((rc = o->round_tiebreak(o->ctx))) return rc;
+                        if ((rc = o->round_apply(o->ctx))) return rc;
+                    }
+                    return MISSLAP_OK;
+                };
+                if (!o->status_post || !o->status_take) {
+                    if ((rc = issue(batch_of(K)))) return rc;
+                } else {
+                    // The status read trails the rounds by one batch: these rounds are a few microseconds each, and
+                    // a queue drained after every batch idles the device for longer than a batch runs.  A round that
+                    // is not live is a no-op, so the batch issued on a stale "go on" costs its launches only.
+                    int slot = 0;
+                    bool outstanding = false;
+                    for (bool stop = false; !stop; slot ^= 1) {
+                        if ((rc = issue(batch_of(K)))) return rc;
+                        if ((rc = o->status_post(o->ctx, slot))) return rc;
+                        if (outstanding) {
+                            if ((rc = o->status_take(o->ctx, slot ^ 1, &K, &its))) return rc;
+                            stop = K <= o->tail_threshold || its >= o->max_iter;
+                        }
+                        outstanding = true;
+                    }
+                    // (the status read at the top of the loop drains the batch that is still in flight)
                 }
             } else {
                 if ((rc = o->run_tail(o->ctx))) return rc;

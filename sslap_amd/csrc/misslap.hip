@@ -1262,59 +1262,52 @@ MISSLAP_API int misslap_finish(misslap_solver *h, int32_t *person_to_object_out,
     return MISSLAP_OK;
 }
 
-// AuctionSolver.solve(), auction_.pyx:268-306.
+// The handle's own round operations for the solve loop (host_comm.hpp: drive_sharded).
+misslap_round_ops handle_round_ops(misslap_solver *h) {
+    misslap_round_ops o;
+    std::memset(&o, 0, sizeof(o));
+    o.struct_size = (int32_t)sizeof(o);
+    o.tail_threshold = h->thr;
+    o.shard_min_K = h->shard_min_K;
+    o.rounds_per_sync = h->rounds_per_sync;
+    o.large_round_K = kRoundSmallMax;
+    o.rounds_per_sync_large = kRoundsPerSyncLargeK;
+    o.max_iter = h->max_iter;
+    o.ctx = h;
+    o.status = [](void *x, int64_t *K, int64_t *its) {
+        misslap_solver *s = static_cast<misslap_solver *>(x);
+        const int rc = read_ctl(s);
+        *K = s->h_ctl->K;
+        *its = s->h_ctl->nits;
+        return rc;
+    };
+    o.status_post = [](void *x, int32_t slot) { return status_enqueue(static_cast<misslap_solver *>(x), slot & 1); };
+    o.status_take = [](void *x, int32_t slot, int64_t *K, int64_t *its) {
+        misslap_solver *s = static_cast<misslap_solver *>(x);
+        const int rc = status_wait(s, slot & 1);
+        *K = s->h_stat[slot & 1].K;
+        *its = s->h_stat[slot & 1].nits;
+        return rc;
+    };
+    o.round_bid = [](void *x) { return launch_bid(static_cast<misslap_solver *>(x)); };
+    o.round_tiebreak = [](void *x) { return launch_tiebreak(static_cast<misslap_solver *>(x)); };
+    o.round_apply = [](void *x) { return launch_apply(static_cast<misslap_solver *>(x)); };
+    o.run_tail = [](void *x) { return launch_tail(static_cast<misslap_solver *>(x)); };
+    o.phase_end = [](void *x, int32_t *fin) { return misslap_phase_end(static_cast<misslap_solver *>(x), fin); };
+    o.best_key = h->best_key;
+    o.best_pos = h->best_pos;
+    o.n_objects = h->n_cols;
+    o.stream = h->stream;
+    return o;
+}
+
+// AuctionSolver.solve(), auction_.pyx:268-306: the loop of host_comm.hpp with no communicator (the rounds at or above
+// the full-scan threshold are issued one at a time, K known exactly -- neither bid kernel is then launched for a round
+// the other one takes; the others in batches).
 MISSLAP_API int misslap_solve(misslap_solver *h, int32_t *person_to_object_out, misslap_meta *meta) {
     if (!h) return fail(MISSLAP_ERR_INVALID, "null handle");
-    if (h->world != 1) return fail(MISSLAP_ERR_STATE, "misslap_solve drives one GPU; sharded handles use the round API");
-    HIP_TRY(hipSetDevice(h->device));
-    const double t0 = now_ms();
-    int rc;
-    while (!h->finished) {
-        for (;;) {  // rounds of the current eps-phase
-            if ((rc = read_ctl(h))) return rc;
-            const Ctl &c = *h->h_ctl;
-            if (c.K == 0 || c.nits >= h->max_iter) break;
-            if (c.K > h->thr && h->tiled_ok && c.K >= h->tiled_min_K) {
-                // rounds big enough for the tiled kernel are few (a handful per phase): enqueued one at a time, K
-                // known exactly, so that neither bid kernel is launched for a round the other one takes
-                if ((rc = launch_bid(h))) return rc;
-                if ((rc = launch_tiebreak(h))) return rc;
-                if ((rc = launch_apply(h))) return rc;
-            } else if (c.K > h->thr) {
-                // Grid rounds in batches, the status read trailing by one batch (status_enqueue): these rounds are
-                // a few microseconds each, and a stream drained after every batch would idle the GPU for longer
-                // than a batch runs.  While K is still above the small-round limit it falls fast (by a third or
-                // more per round): short batches there, so that the stale upper bound K_ub does not keep the
-                // four-launch path and a 2048-block bid grid alive for rounds that have long become small.
-                int slot = 0;
-                bool outstanding = false;
-                for (bool stop = false; !stop; slot ^= 1) {
-                    const int batch = h->K_ub > kRoundSmallMax ? std::min(h->rounds_per_sync, kRoundsPerSyncLargeK)
-                                                               : h->rounds_per_sync;
-                    for (int r = 0; r < batch; ++r) {
-                        if ((rc = launch_bid(h))) return rc;
-                        if ((rc = launch_tiebreak(h))) return rc;
-                        if ((rc = launch_apply(h))) return rc;
-                    }
-                    if ((rc = status_enqueue(h, slot))) return rc;
-                    if (outstanding) {
-                        if ((rc = status_wait(h, slot ^ 1))) return rc;
-                        const Ctl &st = h->h_stat[slot ^ 1];
-                        stop = st.K <= h->thr || st.nits >= h->max_iter;
-                    }
-                    outstanding = true;
-                }
-                // (the read at the top of the loop drains the batch that is still in flight)
-            } else {
-                if ((rc = launch_tail(h))) return rc;
-            }
-        }
-        int fin = 0;
-        if ((rc = misslap_phase_end(h, &fin))) return rc;
-    }
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    h->solve_ms += now_ms() - t0;
-    return misslap_finish(h, person_to_object_out, meta);
+    if (h->world != 1) return fail(MISSLAP_ERR_STATE, "misslap_solve drives one GPU; sharded handles use misslap_solve_sharded");
+    return misslap_solve_sharded(h, nullptr, person_to_object_out, meta);
 }
 
 // ---- multi-GPU: communicators and the sharded solve (host_comm.hpp) ------------------------------------------------
@@ -1386,30 +1379,7 @@ MISSLAP_API int misslap_solve_sharded(misslap_solver *h, misslap_comm *comm, int
     if (!comm && h->world != 1) return fail(MISSLAP_ERR_INVALID, "a handle of %d shards needs a communicator", h->world);
     HIP_TRY(hipSetDevice(h->device));
     const double t0 = now_ms();
-    misslap_round_ops o;
-    std::memset(&o, 0, sizeof(o));
-    o.struct_size = (int32_t)sizeof(o);
-    o.tail_threshold = h->thr;
-    o.shard_min_K = h->shard_min_K;
-    o.rounds_per_sync = h->rounds_per_sync;
-    o.max_iter = h->max_iter;
-    o.ctx = h;
-    o.status = [](void *x, int64_t *K, int64_t *its) {
-        misslap_solver *s = static_cast<misslap_solver *>(x);
-        const int rc = read_ctl(s);
-        *K = s->h_ctl->K;
-        *its = s->h_ctl->nits;
-        return rc;
-    };
-    o.round_bid = [](void *x) { return launch_bid(static_cast<misslap_solver *>(x)); };
-    o.round_tiebreak = [](void *x) { return launch_tiebreak(static_cast<misslap_solver *>(x)); };
-    o.round_apply = [](void *x) { return launch_apply(static_cast<misslap_solver *>(x)); };
-    o.run_tail = [](void *x) { return launch_tail(static_cast<misslap_solver *>(x)); };
-    o.phase_end = [](void *x, int32_t *fin) { return misslap_phase_end(static_cast<misslap_solver *>(x), fin); };
-    o.best_key = h->best_key;
-    o.best_pos = h->best_pos;
-    o.n_objects = h->n_cols;
-    o.stream = h->stream;
+    const misslap_round_ops o = handle_round_ops(h);
     int rc = drive_sharded(&o, comm, fail);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));

@@ -22,8 +22,9 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def drive_with_c_loop(b, comm):
-    """Run misslap_drive_sharded over a NumpyBackend (`b`) and a sslap_amd.dist.Comm (or None)."""
+def drive_with_c_loop(b, comm, trailing=False):
+    """Run misslap_drive_sharded over a NumpyBackend (`b`) and a sslap_amd.dist.Comm (or None).  trailing: also hand
+    the loop the optional status_post / status_take pair (status reads that trail the rounds by one batch)."""
     from sslap_amd import _lib
     lib = _lib.load()
     calls = []
@@ -51,6 +52,20 @@ def drive_with_c_loop(b, comm):
     o.status, o.round_bid, o.round_tiebreak, o.round_apply, o.run_tail, o.phase_end = keep
     o.best_key, o.best_pos = b.best_key.data_ptr(), b.best_pos.data_ptr()
     o.n_objects = b.M
+    if trailing:
+        slots = {}
+
+        def post(_ctx, slot):
+            slots[slot] = b.status()  # the stand-in is synchronous: the "copy" is taken at once
+            calls.append("status_post")
+            return 0
+
+        def take(_ctx, slot, K, its):
+            K[0], its[0] = slots.pop(slot)
+            return 0
+        keep += (_lib._OP_POST(post), _lib._OP_TAKE(take))
+        o.status_post, o.status_take = keep[-2:]
+        o.large_round_K, o.rounds_per_sync_large = 24, 1
     _lib.check(lib.misslap_drive_sharded(C.byref(o), comm._c if comm is not None else None))
     return b.finish(), calls
 
@@ -142,6 +157,23 @@ def test_single_rank_c_loop_matches_oracle(built_lib):
     ref = orc.auction_solve(loc=loc, val=val.copy(), problem="max", cardinality_check=False)
     assert np.array_equal(sol, ref["sol"]) and b.its == ref["meta"]["its"]
     assert calls.count("round_bid") == calls.count("round_apply") == ref["meta"]["its"]
+
+
+@pytest.mark.parametrize("rps", [1, 3, 5])
+def test_single_rank_c_loop_trailing_status(rps, built_lib):
+    """The replicated rounds in batches whose status read trails by one batch (what the GPU handle's operations do):
+    rounds issued on a stale "go on" are no-ops, the result and the round count do not change."""
+    import cases
+    from _numpy_backend import NumpyBackend
+    from oracle import oracle as orc
+    spec = dict(kind="sparse", n=80, m=80, density=0.1, ints=5)
+    loc, val = cases.synth_inputs(spec)
+    b = NumpyBackend(loc, val, "max", 0, 1, rounds_per_sync=rps, shard_min_K=60)
+    sol, calls = drive_with_c_loop(b, None, trailing=True)
+    ref = orc.auction_solve(loc=loc, val=val.copy(), problem="max", cardinality_check=False)
+    assert np.array_equal(sol, ref["sol"]) and b.its == ref["meta"]["its"]
+    assert calls.count("status_post") > 0
+    assert calls.count("round_bid") >= ref["meta"]["its"]  # live rounds + the no-ops behind the end of a phase
 
 
 def test_comm_argument_validation(built_lib):
