@@ -577,6 +577,9 @@ __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
     // per-mode accounting (always on: two s_memrealtime reads per mode entry, 100 MHz ticks), Ctl::dbg:
     //   [0..2] rounds in chain + solo / team / block mode, [3..5] ticks
     unsigned long long md[6] = {0, 0, 0, 0, 0, 0};
+#ifdef MISSLAP_TAIL_STAMP_BLOCK
+    unsigned long long bacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     auto mode_begin = [&](int m) {
         md[3 + m] -= __builtin_amdgcn_s_memrealtime();
         md[m] -= (unsigned long long)nits;
@@ -614,6 +617,15 @@ __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
         // half, one gather serves both); a hit goes straight to LDS, a miss is queued.  Pass B: the queued persons,
         // one wavefront each, by a full scan of their rows (+ line rebuild).
         mode_begin(2);
+#ifdef MISSLAP_TAIL_STAMP_BLOCK
+        // diagnostic build: cycles of wavefront 0 per segment of a block round -> Ctl::dbg[6..11]: [6] lines landed,
+        // [7] records landed, [8] evaluated + barrier, [9] scan pass + barrier, [10] resolve / assign / compaction,
+        // [11] closing barrier
+        unsigned long long sprev_b = __builtin_amdgcn_s_memtime();
+        const CycleStamp bstamp{bacc, &sprev_b, wave == 0};
+#else
+        const NoStamp bstamp;
+#endif
         {
             const RecSource src{a.rec};
             // kBlockDepth sweeps of 2 * nwaves slots are in flight together: all their lines are requested first,
@@ -631,11 +643,13 @@ __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
                     if (E::kCand && a.cand != nullptr)
                         sl[c] = a.cand[(size_t)max(pme, 0) * kCandLanes + (lane & (kCandLanes - 1))];
                 }
+                bstamp(1);
 #pragma unroll
                 for (int c = 0; c < kBlockDepth; ++c) {
                     const int n0 = base + c * 2 * nwaves + 2 * wave;
                     if (E::kCand) rr[c] = cand_gather2(sl[c], n0 < K, n0 + 1 < K, src);
                 }
+                bstamp(2);
 #pragma unroll
                 for (int c = 0; c < kBlockDepth; ++c) {
                     const int n0 = base + c * 2 * nwaves + 2 * wave;
@@ -668,6 +682,7 @@ __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
                 }
             }
             __syncthreads();
+            bstamp(3);
             const int nmiss = sMissCnt;
             for (int m = wave; m < nmiss; m += nwaves) {
                 const int n = __builtin_amdgcn_readfirstlane(sList[m]);
@@ -691,6 +706,7 @@ __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
             }
         }
         __syncthreads();
+        bstamp(4);
 
         if (K <= kWave) {
             // ---- fast path: the whole rest of the round in wavefront 0, no LDS atomics ------------
@@ -842,7 +858,9 @@ __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
                 sMissCnt = 0;
             }
         }
+        bstamp(5);
         __syncthreads();
+        bstamp(6);
         K = sK;
         nits += 1;
         mode_end(2);
@@ -850,6 +868,10 @@ __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
     }
     if (t == 0)
         for (int k = 0; k < 6; ++k) ctl->dbg[k] += md[k];
+#ifdef MISSLAP_TAIL_STAMP_BLOCK
+    if (t == 0)
+        for (int k = 1; k <= 6; ++k) ctl->dbg[5 + k] += bacc[k];
+#endif
 
     if (t < K0) a.U[t] = sU[t];
     if (lane == 0) {
