@@ -634,4 +634,52 @@ __device__ __forceinline__ void wave_bid_full(const E &ed, const Src &src, int s
     ba.V = readlane_f64(x.v, sl);
 }
 
+// The same bid for the rounds where THROUGHPUT counts (many bidders, K above the regime of the candidate lines): only
+// the chunks the row has are requested (wave_bid_full asks for four up front, 2 KB, because in the tail kernel a row
+// must arrive in ONE latency -- at a hundred edges per row that is 2.5x the bytes), nothing is kept for a line build,
+// and the wavefront needs half the registers: more rows in flight per CU to hide the price gather behind.
+template <class E, class Src>
+__device__ __forceinline__ void wave_bid_lean(const E &ed, const Src &src, const int s, const int e, const double eps,
+                                              CandBid &out, int &err) {
+    const int lane = lane_id();
+    const double ninf = -__builtin_huge_val();
+    Top2 x;
+    x.v = ninf;
+    x.w = ninf;
+    x.g = -1;
+    int c1 = 0;
+    double a1 = 0.0;
+    for (int base = s; base < e; base += 2 * kWave) {
+        int c[2];
+        double a[2], pr[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) ed.load(min(base + u * kWave + lane, e - 1), c[u], a[u]);  // unconditional, clamped
+#pragma unroll
+        for (int u = 0; u < 2; ++u) pr[u] = src.get(c[u]).price;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int g = base + u * kWave + lane;
+            const bool ok = g < e;
+            const double v = ok ? a[u] - pr[u] : ninf;          // vi = cost - p[j]   (:350)
+            const bool ge = ok & (v >= x.v);                    // :351
+            x.w = __builtin_fmax(x.w, __builtin_fmin(v, x.v));  // :353 / :357-358
+            x.v = __builtin_fmax(x.v, v);
+            x.g = ge ? g : x.g;
+            c1 = ge ? c[u] : c1;
+            a1 = ge ? a[u] : a1;
+        }
+    }
+    const int g_mine = x.g;
+    const Top2 t2 = top2_wave_reduce(x);
+    const int sl = __ffsll((long long)__ballot(g_mine == t2.g)) - 1;
+    out.hit = false;
+    out.obj = __builtin_amdgcn_readlane(c1, sl);
+    out.prev = -1;
+    out.pstart = 0;
+    out.len = e - s;
+    const double bid = (readlane_f64(a1, sl) - t2.w) + eps;  // bbest = costbest - wi + eps   (:360)
+    if (bid_is_bad(bid)) err |= kErrNegativeBid;
+    out.key = bid_to_key(bid);
+}
+
 }  // namespace misslap

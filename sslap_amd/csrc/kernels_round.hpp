@@ -39,7 +39,7 @@ struct RoundArgs {
     int launch_idx;
     int gather_max_K;             // k_bid runs only for K < gather_max_K (k_bid_tiled takes the rest); 0 = no limit
     int2 *cand;                   // candidate lines (device_common.hpp); nullptr = none (12 B/edge layout)
-    int cand_build_max_K;         // k_bid (re)builds a missed line only in rounds with K <= this
+    int cand_build_max_K;         // k_bid uses and (re)builds lines only in rounds with K <= this
     int cand_refresh_min;         // ... and treats a hit that leaves fewer live candidates than this as a miss
 };
 
@@ -92,8 +92,13 @@ struct SrcOf<RecSource> {
     static constexpr bool kOwners = true;
     static __device__ __forceinline__ RecSource make(const RoundArgs &a) { return RecSource{a.rec}; }
 };
-template <class E, class Src>
+// kLines: 2 = lines used, refreshed and rebuilt (rounds with K <= cand_build_max_K); 1 = lines used where they still
+// answer, misses by the lean scan, nothing built (the rounds above: a line built there is spent long before the tail
+// kernel could use it, and the rounds in between rebuild it anyway); 0 = no lines (12 B/edge layout, cand = off).
+// The host picks the variant from its upper bound of K; a stale bound only means a round or two more without builds.
+template <class E, class Src, int kLines>
 __global__ __launch_bounds__(kBidBlock) void k_bid(RoundArgs a, E ed) {
+    static_assert(kLines == 2 || !SrcOf<Src>::kOwners, "the lean scan does not carry the owners k_round_small needs");
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wpb = kBidBlock / kWave;
     const int first = blockIdx.x * wpb + wave;
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(kBidBlock) void k_bid(RoundArgs a, E ed) {
     unsigned long long edges = 0, hit_edges = 0;
     int nb = 0, nh = 0, err = 0;
     double hint = 0.0;  // cand_build's search distance, carried from one build of this wavefront to the next
-    const bool lines = E::kCand && a.cand != nullptr;
+    const bool lines = kLines > 0 && E::kCand && a.cand != nullptr;
     for (int n = lo + first; n < hi; n += gridDim.x * wpb) {
         const int i = n == first ? i_first : a.U[n];
         const int s = a.row_ptr[i], e = a.row_ptr[i + 1];
@@ -123,13 +128,17 @@ __global__ __launch_bounds__(kBidBlock) void k_bid(RoundArgs a, E ed) {
             // A hit on a line with little life left is answered by a full scan all the same -- the bid is the same
             // bid -- so that the line is rebuilt HERE, where a scan is one of many in flight, and not by a miss in
             // the tail kernel, where a scan is the whole round.
-            if (alive[0] < a.cand_refresh_min && head.K <= a.cand_build_max_K) b[0].hit = false;
+            if (kLines == 2 && alive[0] < a.cand_refresh_min) b[0].hit = false;
         }
         if (!b[0].hit) {  // wave-uniform
-            CandBuildArgs ba;
-            const typename E::Raw none[4] = {};
-            wave_bid_full<E, Src, false, false>(ed, src, s, e, none, eps, b[0], ba, err);
-            if (lines && ba.want && head.K <= a.cand_build_max_K) cand_build(a.cand, i, ba, eps, hint);
+            if (kLines == 2) {
+                CandBuildArgs ba;
+                const typename E::Raw none[4] = {};
+                wave_bid_full<E, Src, false, false>(ed, src, s, e, none, eps, b[0], ba, err);
+                if (lines && ba.want) cand_build(a.cand, i, ba, eps, hint);
+            } else {
+                wave_bid_lean(ed, src, s, e, eps, b[0], err);
+            }
         } else {
             nh += 1;
             hit_edges += (unsigned long long)b[0].len;

@@ -435,11 +435,16 @@ int launch_bid(misslap_solver *h) {
     const EdgesF64 e64{h->col, h->val64};
     const dim3 g(grid), b(kBidBlock);
     if (h->round_small) {  // bids of a round that k_round_small finishes
-        if (h->f32) hipLaunchKernelGGL((k_bid<EdgesF32, RecSource>), g, b, 0, h->stream, a, e32);
-        else hipLaunchKernelGGL((k_bid<EdgesF64, RecSource>), g, b, 0, h->stream, a, e64);
+        if (h->f32) hipLaunchKernelGGL((k_bid<EdgesF32, RecSource, 2>), g, b, 0, h->stream, a, e32);
+        else hipLaunchKernelGGL((k_bid<EdgesF64, RecSource, 2>), g, b, 0, h->stream, a, e64);
+    } else if (!h->f32) {
+        hipLaunchKernelGGL((k_bid<EdgesF64, PriceSource, 0>), g, b, 0, h->stream, a, e64);
+    } else if (!h->cand) {
+        hipLaunchKernelGGL((k_bid<EdgesF32, PriceSource, 0>), g, b, 0, h->stream, a, e32);
+    } else if (h->K_ub > h->cand_build_max_K) {  // the full-scan regime: throughput, no line builds
+        hipLaunchKernelGGL((k_bid<EdgesF32, PriceSource, 1>), g, b, 0, h->stream, a, e32);
     } else {
-        if (h->f32) hipLaunchKernelGGL((k_bid<EdgesF32, PriceSource>), g, b, 0, h->stream, a, e32);
-        else hipLaunchKernelGGL((k_bid<EdgesF64, PriceSource>), g, b, 0, h->stream, a, e64);
+        hipLaunchKernelGGL((k_bid<EdgesF32, PriceSource, 2>), g, b, 0, h->stream, a, e32);
     }
     if (pr) HIP_TRY(hipEventRecord(pr->stop, h->stream));
     HIP_TRY(hipGetLastError());
@@ -745,6 +750,10 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
     h->shard_min_K = h->tiled_ok ? h->tiled_min_K : (int)std::max<size_t>((N * 3) / 10, 8192);
     if (opt->reserved[3] > 0) h->shard_min_K = opt->reserved[3];
     if (opt->reserved[3] < 0) h->shard_min_K = 0;  // every grid round sharded + exchanged
+    // candidate lines are used and built below the full-scan regime (0.3 N): C5 with lines built in every round
+    // 3.85 s and a 939 us full scan (it writes a 256-byte line per person), with this limit 3.87 s and 588 us
+    if (h->cand_build_max_K == 0x7fffffff)
+        h->cand_build_max_K = (int)std::max<size_t>((N * 3) / 10, 8192) - 1;
     h->max_iter = opt->max_iter < 1 ? 1 : opt->max_iter;  // the loop body runs before the first test (:271-275)
     hipLaunchKernelGGL(k_init_state, dim3(blocks_for((long long)(N > M ? N : M), 256)), dim3(256), 0, h->stream,
                        h->ctl, h->price, h->rec, h->p2o, h->o2p, h->U, h->best_key, h->best_pos, h->cand, h->n_rows, h->n_cols,
