@@ -88,6 +88,7 @@ int main(int argc, char **argv) {
     /* stats by mode: 0 chain (K=1), 1 pair, 2 team (3..16), 3 block (17..64), 4 (65..512), 5 (513..2048), 6 bigger */
     int64_t rounds[7] = {0}, bids[7] = {0}, hits[7] = {0}, allhit[7] = {0}, bad = 0, builds = 0;
     int64_t phase_rounds[7] = {0};
+    int64_t khist[33] = {0};  /* rounds with exactly K bidders, K <= 32 */
     int64_t its = 0;
     int K = N, nred = 0;
     FILE *trace = getenv("SIM_TRACE") ? fopen(getenv("SIM_TRACE"), "wb") : NULL;
@@ -186,6 +187,7 @@ int main(int argc, char **argv) {
             allhit[mode] += round_hits == K;
         }
         phase_rounds[mode]++;
+        if (K <= 32) khist[K]++;
         /* resolve */
         int nt = 0;
         for (int n = 0; n < K; ++n) {
@@ -258,6 +260,8 @@ int main(int argc, char **argv) {
                "\"all_hit_rounds\": %.4f}",
                m ? ",\n  " : "", names[m], (long long)phase_rounds[m], (long long)rounds[m], (long long)bids[m],
                bids[m] ? (double)hits[m] / bids[m] : 0.0, rounds[m] ? (double)allhit[m] / rounds[m] : 0.0);
+    printf("],\n \"rounds_by_K\": [");
+    for (int k = 1; k <= 32; ++k) printf("%s%lld", k > 1 ? ", " : "", (long long)khist[k]);
     printf("]}\n");
     /* sol to a file for the sha256 check */
     if (argc > 6) {

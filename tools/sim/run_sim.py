@@ -37,7 +37,10 @@ if g:
     ok = res["its"] == g["meta"]["its"] and hashlib.sha256(sol.tobytes()).hexdigest() == g["sol_sha256"]
     res["matches_fixture"] = bool(ok)
 modes = res.pop("modes")
+by_k = res.pop("rounds_by_K", None)
 print(json.dumps(res))
 for m in modes:
     print("  %-12s rounds_all=%8d counted=%8d bids=%9d hit=%.3f all-hit rounds=%.3f" % (
         m["mode"], m["rounds_all"], m["rounds"], m["bids"], m["hit_rate"], m["all_hit_rounds"]))
+if by_k:
+    print("  rounds with K = 1..32 bidders:", by_k)
