@@ -533,8 +533,13 @@ __device__ __forceinline__ void tail_team_mode(const TailArgs &a, const E &ed, i
     __syncthreads();
 }
 
-template <class E>
-__global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
+// kThreads = kTailMax (512): every mode.  kThreads = 1024 ("block only"): the rounds with more than kTeamMax bidders
+// with SIXTEEN wavefronts -- half the sweeps per wavefront in pass A, which is where a block round spends its time --
+// and nothing else: the solo / team code needs more than the 128 registers a 1024-thread workgroup leaves a
+// wavefront.  The host launches it ahead of the 512-thread kernel, which then finds K <= kTeamMax.
+template <class E, int kThreads>
+__global__ __launch_bounds__(kThreads) void k_tail(TailArgs a, E ed) {
+    constexpr bool kBlockOnly = kThreads > kTailMax;
     __shared__ int sU[kTailMax];
     __shared__ unsigned long long sKey[kTailMax];
     __shared__ int sObj[kTailMax];
@@ -546,22 +551,25 @@ __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
     __shared__ int hObj[kHashSize];
     __shared__ unsigned long long hKey[kHashSize];
     __shared__ int hPos[kHashSize];
-    __shared__ int sCnt[3][kTailMax / kWave];
+    __shared__ int sCnt[3][kThreads / kWave];
     __shared__ int sK, sMissCnt;
     __shared__ long long sNits;
 
     Ctl *ctl = a.ctl;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    constexpr int nwaves = kTailMax / kWave;
+    constexpr int nwaves = kThreads / kWave;
     int K = ctl->K;
     long long nits = ctl->nits;
     const long long max_iter = ctl->max_iter;
     if (K == 0 || K > a.thr || nits >= max_iter) return;  // uniform
+    if (kBlockOnly && K <= kTeamMax) return;
     const int K0 = K;
     const long long nits0 = nits;
-    sU[t] = (t < K) ? a.U[t] : -1;
-    sStart[t] = (t < K) ? a.row_ptr[sU[t]] : 0;
-    for (int h = t; h < kHashSize; h += kTailMax) {
+    if (t < kTailMax) {
+        sU[t] = (t < K) ? a.U[t] : -1;
+        sStart[t] = (t < K) ? a.row_ptr[sU[t]] : 0;
+    }
+    for (int h = t; h < kHashSize; h += kThreads) {
         hObj[h] = -1;
         hKey[h] = 0ull;
         hPos[h] = kPosNone;
@@ -589,7 +597,8 @@ __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
         md[m] += (unsigned long long)nits;
     };
     for (;;) {
-        if (K <= 2) {
+        if (kBlockOnly && K <= kTeamMax) break;  // the 512-thread kernel takes over
+        if (!kBlockOnly && K <= 2) {
             // ---- solo mode: wavefront 0 runs the rest of the phase alone, see tail_solo_mode
             if (wave == 0) {
                 mode_begin(0);
@@ -605,7 +614,7 @@ __global__ __launch_bounds__(kTailMax) void k_tail(TailArgs a, E ed) {
             nits = sNits;
             break;  // K == 0 or nits == max_iter
         }
-        if (K <= kTeamMax) {
+        if (!kBlockOnly && K <= kTeamMax) {
             // ---- team mode: every wavefront, until K <= 2 (or max_iter), see tail_team_mode
             mode_begin(1);
             tail_team_mode(a, ed, sU, sStart, K, nits, max_iter, eps, st);

@@ -65,13 +65,11 @@ double now_ms() {
     return std::chrono::duration<double, std::milli>(clk::now().time_since_epoch()).count();
 }
 
-// Rounds with K <= threshold run in the tail kernel.  Break-even against a grid round (two launches: k_bid +
-// k_round_small, ~12.5 us), measured with tools/sweep_thr.py after every change of either side.  Round 2 (candidate
-// lines, two-pass block mode): C3 24: 706 ms, 40: 669, 64: 656, 96: 642, 128: 643, 192: 652, 256: 656;
-// C5 40: 4.93 s, 64: 4.92, 128: 4.84, 256: 4.96 -- a grid round costs more when the price table no longer fits L2.
-constexpr int kDefaultTailThreshold = 96;
-constexpr int kDefaultTailThresholdBig = 128;  // n_cols > kTailBigCols
-constexpr long long kTailBigCols = 500000;
+// Rounds with K <= threshold run in the tail kernels.  Break-even against a grid round (two launches: k_bid +
+// k_round_small, ~12 us), measured with tools/sweep_thr.py / tools/tail_stats.py after every change of either side.
+// Round 2 with the 16-wavefront block kernel: C3 96: 485 ms, 192: 479, 256: 482, 384: 480, 512: 481; C5 128: 3.797 s,
+// 256: 3.790, 448: 3.823; C2 96: 160.9 ms, 192: 159.4, 320: 158.9 -- flat above ~150.
+constexpr int kDefaultTailThreshold = 192;
 // k_bid answers a line hit that leaves fewer live candidates than this by a full scan + rebuild (kernels_round.hpp).
 // Lines are built in the grid rounds but earn their keep in the tail kernel, tens of thousands of rounds later: a
 // line that still hits in a grid round but is nearly spent would miss THERE, where a row scan is the whole round and
@@ -508,10 +506,12 @@ int launch_tail(misslap_solver *h) {
     }
     if (h->f32) {
         EdgesF32 ed{h->edges32};
-        hipLaunchKernelGGL(k_tail<EdgesF32>, dim3(1), dim3(kTailMax), 0, h->stream, a, ed);
+        // the rounds with more than kTeamMax bidders first, with sixteen wavefronts (kernels_tail.hpp)
+        if (h->K_ub > kTeamMax) hipLaunchKernelGGL((k_tail<EdgesF32, 2 * kTailMax>), dim3(1), dim3(2 * kTailMax), 0, h->stream, a, ed);
+        hipLaunchKernelGGL((k_tail<EdgesF32, kTailMax>), dim3(1), dim3(kTailMax), 0, h->stream, a, ed);
     } else {
         EdgesF64 ed{h->col, h->val64};
-        hipLaunchKernelGGL(k_tail<EdgesF64>, dim3(1), dim3(kTailMax), 0, h->stream, a, ed);
+        hipLaunchKernelGGL((k_tail<EdgesF64, kTailMax>), dim3(1), dim3(kTailMax), 0, h->stream, a, ed);
     }
     if (pr) HIP_TRY(hipEventRecord(pr->stop, h->stream));
     // the tail keeps only the price records current: rebuild price / o2p / p2o from them
@@ -599,8 +599,8 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
     if (st.err & kErrNonFinite) return fail(MISSLAP_ERR_INVALID, "val holds a NaN or an infinity");
     if (st.max_col >= 0x7ffffffe) return fail(MISSLAP_ERR_INVALID, "column index too large (max + 1 must fit an int32)");
     h->n_cols = st.max_col + 1;  // auction_.pyx:210
-    if (h->thr < 0)  // library default, resolved now that the number of objects is known
-        h->thr = (long long)h->n_cols > kTailBigCols ? kDefaultTailThresholdBig : kDefaultTailThreshold;
+    if (h->thr < 0)  // library default
+        h->thr = kDefaultTailThreshold;
     h->f32 = !st.not_f32 && !opt->force_f64_values;
     const int flip = h->maximize ? 0 : 1;
     if (h->f32) {
