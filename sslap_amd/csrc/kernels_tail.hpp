@@ -533,13 +533,156 @@ __device__ __forceinline__ void tail_team_mode(const TailArgs &a, const E &ed, i
     __syncthreads();
 }
 
+// ---- team mode with ONE list slot per wavefront (the 16-wavefront "team only" instance of the kernel) ------------------
+// The same round as tail_team_mode -- one LDS-only barrier, every serving wavefront finishes the round for the whole
+// list on lanes = slots and stores all winners' records itself -- but wavefront w serves slot w alone: a round is a
+// serial ALU chain per wavefront, and the one-person evaluation (cand_eval1) is the shortest there is.  Lines only
+// (8 B/edge layout).  Runs until K <= 2 (or max_iter); the 512-thread kernel takes the rest.
+template <class E>
+__device__ __forceinline__ void tail_team1_mode(const TailArgs &a, const E &ed, int *sU, int *sStart, int &K,
+                                                long long &nits, const long long max_iter, const double eps,
+                                                TailStats &st) {
+    const int lane = lane_id(), l32 = lane & (kCandLanes - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    __shared__ unsigned long long uKey[2][kTeamMax];
+    __shared__ int uObj[2][kTeamMax], uPrev[2][kTeamMax], uPst[2][kTeamMax], uU[2][kTeamMax], uS[2][kTeamMax];
+    __shared__ int vTab[kTeamMax][kTeamTab];
+    const RecSource src{a.rec};
+    const bool cls = (lane >= 1) & (lane <= kCandMax);
+    const int n0 = wave;  // my slot
+    int pi = n0 < K ? __builtin_amdgcn_readfirstlane(sU[min(n0, kTailMax - 1)]) : -1;
+    int ps = n0 < K ? __builtin_amdgcn_readfirstlane(sStart[min(n0, kTailMax - 1)]) : 0;
+    vTab[wave][lane & (kTeamTab - 1)] = -1;
+    int2 slot = cand_no_line();
+    auto request = [&](int person) { slot = a.cand[(size_t)max(person, 0) * kCandLanes + l32]; };
+    if (n0 < K) request(pi);
+    __syncthreads();  // (sU / sStart have been read by everybody)
+    int par = 0;
+    for (;;) {
+        int sp = -2;  // the person whose line was requested early (-2: nothing requested)
+        CandBuildArgs bd;
+        int bd_person = -1;
+        if (n0 < K) {  // wave-uniform: BID for my slot (slots < K are always occupied: the list is compact)
+            CandBid b;
+            b.hit = false;
+            cand_eval1(slot, cls, src, eps, b, st.err, [&](const CandBid &w) {
+                sp = w.prev;
+                request(sp);  // the owner my bidder evicts if it wins
+            });
+            if (!b.hit) {
+                const typename E::Raw none[4] = {};
+                const int e = a.row_ptr[pi + 1 + lane_zero()];
+                wave_bid_full<E, RecSource, true, false>(ed, src, ps, e, none, eps, b, bd, st.err);
+                bd_person = bd.want ? pi : -1;
+            } else {
+                st.hits += 1;
+                st.hit_edges += (unsigned long long)b.len;
+            }
+            st.edges += (unsigned long long)b.len;
+            st.bids += 1;
+            if (lane == 0) {
+                uKey[par][n0] = b.key;
+                uObj[par][n0] = b.obj;
+                uPrev[par][n0] = b.prev;
+                uPst[par][n0] = b.pstart;
+                uU[par][n0] = pi;
+                uS[par][n0] = ps;
+            }
+        }
+        tail_barrier_lds();  // the bids are in LDS and every gather of the round is done; requests stay in flight
+        {
+            const bool act = lane < K;
+            const int ls = min(lane, kTeamMax - 1);
+            const unsigned long long lkey = act ? uKey[par][ls] : 0ull;
+            const int lobj = act ? uObj[par][ls] : (-2 - lane);
+            const int lprev = act ? uPrev[par][ls] : 0, lpst = act ? uPst[par][ls] : 0;
+            int u = act ? uU[par][ls] : -1;  // the list: lane l holds slot l
+            int sx = act ? uS[par][ls] : 0;
+            // clean round?  (a) no object bid on twice: one compare-and-swap per slot into my private table
+            int hs = 0;
+            bool dup = false;
+            if (act) {
+                hs = (int)(((unsigned)lobj * 2654435761u) >> 26) & (kTeamTab - 1);
+                for (;;) {
+                    const int old = atomicCAS(&vTab[wave][hs], -1, lobj);
+                    if (old == -1) break;
+                    if (old == lobj) {
+                        dup = true;
+                        break;
+                    }
+                    hs = (hs + 1) & (kTeamTab - 1);
+                }
+            }
+            const bool contested = __any(dup);
+            if (act && !dup) vTab[wave][hs] = -1;  // (LDS operations of a wavefront complete in order)
+            const bool ends = __any(act && lprev == -1);  // (b) no chain ends
+            if (!contested && !ends) {
+                // every bidder wins (:375-385 has nothing to resolve); ASSIGN (:396-418); the list keeps its shape
+                if (act && n0 < K) apply_winner(a, u, sx, lobj, lprev, lkey);
+                pi = n0 < K ? __builtin_amdgcn_readlane(lprev, min(n0, kWave - 1)) : -1;
+                ps = n0 < K ? __builtin_amdgcn_readlane(lpst, min(n0, kWave - 1)) : 0;
+            } else {
+                // RESOLVE / ASSIGN / push_all_left in full, on lanes = slots
+                bool lose = false;
+                for (int m = 0; m < K; ++m) {  // :375-385, all pairs via readlane
+                    const int om = __builtin_amdgcn_readlane(lobj, m);
+                    const bool same = (om == lobj) && (m != lane);
+                    if (__any(same)) {  // wave-uniform
+                        const unsigned long long km = readlane_u64(lkey, m);
+                        lose |= same && (km > lkey || (km == lkey && m < lane));
+                    }
+                }
+                const bool won = act && !lose;
+                if (won && n0 < K) apply_winner(a, u, sx, lobj, lprev, lkey);  // :396-418 (serving wavefronts only)
+                u = won ? lprev : u;  // the evicted owner inherits the slot (:409) / hole (:412) / a loser stays
+                sx = won ? lpst : sx;
+                const unsigned long long kmask = (1ull << K) - 1ull;
+                const unsigned long long holes = __ballot(act && u == -1) & kmask;
+                const int Kn = K - __popcll(holes);
+                const unsigned long long lmask = (1ull << Kn) - 1ull;
+                unsigned long long hl = holes & lmask;            // empty slots left of K'
+                unsigned long long mv = ~holes & ~lmask & kmask;  // persons right of K'
+                while (hl) {  // wave-uniform: k-th hole <- k-th mover (:137-162)
+                    const int hk = __ffsll((long long)hl) - 1, mk = __ffsll((long long)mv) - 1;
+                    const int mu = __builtin_amdgcn_readlane(u, mk), ms = __builtin_amdgcn_readlane(sx, mk);
+                    if (lane == hk) {
+                        u = mu;
+                        sx = ms;
+                    }
+                    hl &= hl - 1;
+                    mv &= mv - 1;
+                }
+                K = Kn;
+                pi = n0 < K ? __builtin_amdgcn_readlane(u, min(n0, kWave - 1)) : -1;
+                ps = n0 < K ? __builtin_amdgcn_readlane(sx, min(n0, kWave - 1)) : 0;
+            }
+        }
+        par ^= 1;
+        nits += 1;
+        const bool done = K <= 2 || nits >= max_iter;
+        // my slot's new occupant is usually exactly the person whose line was requested early; otherwise (a scanned
+        // row, a lost bid, a moved person) request now
+        if (!done && n0 < K && sp != pi) request(pi);
+        if (bd_person >= 0) tail_build(a, bd_person, bd, eps, st);
+        if (done) break;
+    }
+    // hand the list back: every wavefront writes its own slot
+    if (lane == 0 && n0 < kTeamMax) {
+        sU[n0] = pi;
+        sStart[n0] = ps;
+    }
+    __syncthreads();
+}
+
 // kThreads = kTailMax (512): every mode.  kThreads = 1024 ("block only"): the rounds with more than kTeamMax bidders
 // with SIXTEEN wavefronts -- half the sweeps per wavefront in pass A, which is where a block round spends its time --
 // and nothing else: the solo / team code needs more than the 128 registers a 1024-thread workgroup leaves a
 // wavefront.  The host launches it ahead of the 512-thread kernel, which then finds K <= kTeamMax.
-template <class E, int kThreads>
+// kTeamOnly (1024 threads as well): the rounds with 3..kTeamMax bidders, one slot per wavefront (tail_team1_mode).
+template <class E, int kThreads, bool kTeamOnly = false>
 __global__ __launch_bounds__(kThreads) void k_tail(TailArgs a, E ed) {
-    constexpr bool kBlockOnly = kThreads > kTailMax;
+    static_assert(!kTeamOnly || (kThreads == 2 * kTailMax && kThreads / kWave == kTeamMax), "one slot per wavefront");
+    constexpr bool kBlockOnly = kThreads > kTailMax && !kTeamOnly;
     __shared__ int sU[kTailMax];
     __shared__ unsigned long long sKey[kTailMax];
     __shared__ int sObj[kTailMax];
@@ -563,6 +706,7 @@ __global__ __launch_bounds__(kThreads) void k_tail(TailArgs a, E ed) {
     const long long max_iter = ctl->max_iter;
     if (K == 0 || K > a.thr || nits >= max_iter) return;  // uniform
     if (kBlockOnly && K <= kTeamMax) return;
+    if (kTeamOnly && (K <= 2 || K > kTeamMax)) return;
     const int K0 = K;
     const long long nits0 = nits;
     if (t < kTailMax) {
@@ -597,7 +741,15 @@ __global__ __launch_bounds__(kThreads) void k_tail(TailArgs a, E ed) {
         md[m] += (unsigned long long)nits;
     };
     for (;;) {
-        if (kBlockOnly && K <= kTeamMax) break;  // the 512-thread kernel takes over
+        if (kBlockOnly && K <= kTeamMax) break;  // the next kernel takes over
+        if (kTeamOnly) {
+            if (K > 2 && nits < max_iter) {
+                mode_begin(1);
+                tail_team1_mode(a, ed, sU, sStart, K, nits, max_iter, eps, st);
+                mode_end(1);
+            }
+            break;
+        }
         if (!kBlockOnly && K <= 2) {
             // ---- solo mode: wavefront 0 runs the rest of the phase alone, see tail_solo_mode
             if (wave == 0) {

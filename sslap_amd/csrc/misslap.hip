@@ -508,6 +508,9 @@ int launch_tail(misslap_solver *h) {
         EdgesF32 ed{h->edges32};
         // the rounds with more than kTeamMax bidders first, with sixteen wavefronts (kernels_tail.hpp)
         if (h->K_ub > kTeamMax) hipLaunchKernelGGL((k_tail<EdgesF32, 2 * kTailMax>), dim3(1), dim3(2 * kTailMax), 0, h->stream, a, ed);
+        // ... then the rounds with 3..kTeamMax bidders, one list slot per wavefront (lines only)
+        if (h->K_ub > 2 && h->cand)
+            hipLaunchKernelGGL((k_tail<EdgesF32, 2 * kTailMax, true>), dim3(1), dim3(2 * kTailMax), 0, h->stream, a, ed);
         hipLaunchKernelGGL((k_tail<EdgesF32, kTailMax>), dim3(1), dim3(kTailMax), 0, h->stream, a, ed);
     } else {
         EdgesF64 ed{h->col, h->val64};
