@@ -40,8 +40,9 @@ typedef struct misslap_options {
     float eps_start;         /* > 0 overrides eps0 = C/2 (auction_.pyx:251-252) */
     int64_t max_iter;        /* rounds, auction_.pyx:204,:308 */
     int32_t input_on_device; /* loc / val are device pointers already resident in HBM */
-    int32_t tail_threshold;  /* rounds with K <= this run in the persistent one-workgroup kernel;
-                                < 0 = library default; 0 = grid kernels only; max 512 */
+    int32_t tail_threshold;  /* rounds with K <= this run in the persistent one-workgroup kernels (launched once per
+                                eps-phase: > 16 bidders, 3..16, <= 2); < 0 = library default (192); 0 = grid kernels
+                                only; max 512 */
     int32_t force_f64_values;/* keep 12 B/edge (int32 col + fp64 val) even when values are fp32-exact */
     int32_t profile;         /* 1: record HIP events around the full-scan bid launches, every launch of the full-scan
                                 engine and every tail-kernel launch; 2 / 3: around every bid-kernel launch as well */
@@ -176,7 +177,7 @@ int misslap_solve(misslap_solver *h, int32_t *person_to_object_out, misslap_meta
 int misslap_round_bid(misslap_solver *h);
 int misslap_round_tiebreak(misslap_solver *h);
 int misslap_round_apply(misslap_solver *h);
-/* All remaining rounds with 0 < K <= tail_threshold, inside one persistent kernel launch. */
+/* All remaining rounds with 0 < K <= tail_threshold, inside the persistent kernels (no host round trip until K == 0). */
 int misslap_run_tail(misslap_solver *h);
 /* Synchronise and read the round state. */
 int misslap_get_status(misslap_solver *h, misslap_status *st);
