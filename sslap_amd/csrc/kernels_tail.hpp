@@ -2,24 +2,28 @@
 //
 // At the BASELINE sizes > 98 % of all rounds have <= 64 bidders and
 // every round depends on the prices of the previous one, so the tail is a latency chain, not a
-// bandwidth problem.  One 512-thread workgroup (8 wavefronts, one CU) loops over rounds on the
+// bandwidth problem.  One workgroup (one CU) loops over rounds on the
 // device: the unassigned list lives in LDS, bids are formed per person (auction_.pyx:339-365),
 // conflicts are resolved in LDS (:375-385), winners are applied (:388-427) and the list is
 // compacted (push_all_left, :137-162) without leaving the kernel.  K never grows inside an
 // eps-phase (every winner evicts at most one owner), so once K <= threshold the whole rest of the
-// phase runs here.  The kernel exits when K == 0 or nits == max_iter.
+// phase runs here.  The kernels exit when K == 0 or nits == max_iter.
 //
 // A bid is first tried on the person's CANDIDATE LINE (device_common.hpp: 256 bytes, <= 30 price records, an
-// exactness test) and only on a miss by a full scan of the row, which also rebuilds the line.  With the lines
-// about 90 % of the tail's bids need one 256-byte read and one 30-wide record gather instead of the whole row and
-// ~200 gathers; the dependent chain of a round is  line -> records -> 32-lane reduction -> next line.
+// exactness test) and only on a miss by a full scan of the row, which also rebuilds the line.  With the lines -- and
+// k_bid refreshing the nearly spent ones in the grid rounds -- 99 % of the tail's bids need one 256-byte read and one
+// 30-wide record gather instead of the whole row and ~200 gathers; the dependent chain of a round is
+// line -> records -> 32-lane reduction -> next line.
 //
-// Three modes by K (K only falls, so a phase moves block -> team -> solo):
-//   solo  (K <= 2, two thirds of all rounds): wavefront 0 alone, no barrier, no LDS; the two persons' lines sit
-//         in the two 32-lane halves and are evaluated by one gather;
-//   team  (3 <= K <= 16): one wavefront per list slot, the line of the slot's next occupant requested as soon as the
-//         winning candidate is known; two LDS-only barriers per round, wavefront 0 resolves;
-//   block (K > 16): several slots per wavefront, __syncthreads, LDS hash table above 64 bidders.
+// A round is a serial chain of dependent instructions per wavefront, so what makes it shorter is wavefronts: three
+// instances of k_tail by role, launched back to back once per phase (K only falls: block -> team -> solo):
+//   block (K > 16;  1024 threads): two list slots per wavefront and sweep (one per 32-lane half, one gather serves
+//         both), misses queued and scanned in a second pass, wavefront 0 resolves (LDS hash table above 64 bidders);
+//   team  (3 <= K <= 16; 1024 threads): wavefront w serves slot w alone; ONE LDS-only barrier per round, every
+//         serving wavefront finishes the round for the whole list on lanes = slots;
+//   solo / chain (K <= 2; 512 threads): wavefront 0 alone, no barrier, no LDS.
+// The 512-thread instance still holds every mode (two slots per wavefront in team mode): the 12 B/edge layout, which
+// has no lines, runs in it alone.
 //
 // Visibility: records / lines are written and re-read by this one workgroup only (same CU, same
 // vector L1, barriers between phases); the CSR is read-only.  No other workgroup runs.

@@ -357,6 +357,37 @@ def test_fuzz_random_instances_vs_oracle(seed, gpu_lib):
     assert g.gpu["edges_scanned"] == o.extra["edges_scanned"] and g.gpu["obj_f64"] == o.extra["obj_f64"]
 
 
+@pytest.mark.parametrize("knobs", [
+    dict(cand_refresh=0),                                   # lines never refreshed
+    dict(cand_refresh=30),                                  # every line hit of a grid round is rescanned and rebuilt
+    dict(cand_refresh=12, cand_build_max_k=300),            # lines used / built in small rounds only (lean scan above)
+    dict(cand_build_max_k=5),                               # lines practically only in the tail kernels
+    dict(order_partial=False, tiled_min_k=1, engine=1),     # full-scan engine everywhere, partial rounds in list order
+    dict(order_partial=True, tiled_min_k=1, engine=1, tail_threshold=0),
+    dict(cand=False, tail_threshold=300),                   # no lines: the 512-thread tail kernel takes every mode
+    dict(rounds_per_sync=1), dict(rounds_per_sync=37),      # batch length of the trailing status reads
+])
+def test_tuning_knobs_do_not_change_the_result(knobs, gpu_lib):
+    """Lines (refresh threshold, build limit, on / off), the order of the bidders in partial full-scan rounds, the
+    k_bid variant in use and the batch length of the status reads decide what is READ and WHEN -- never the bids:
+    sol, round count, prices, list order and the scanned-edge count stay those of the oracle."""
+    for seed, (n, m, dens, ints, prob) in enumerate([(3000, 3000, 12.0, 0, "max"), (2500, 4000, 30.0, 3, "min"),
+                                                    (9000, 9000, 8.0, 0, "max")]):
+        loc, val = synth.gen_sparse(n, m, dens / m, seed=900 + seed, integer_values=ints)
+        kw = dict(problem=prob, cardinality_check=False, max_iter=10**8)
+        o = orc.from_sparse(loc, val.copy(), **kw)
+        osol = o.solve()
+        g = from_sparse(loc, val.copy(), **kw, **knobs)
+        gsol = g.solve()
+        assert np.array_equal(gsol, osol), (knobs, n, m)
+        for k in cases.META_KEYS:
+            assert g.meta[k] == o.meta[k], (knobs, k)
+        sg, so = g.state(), o.state()
+        assert np.array_equal(sg["p"].view(np.uint64), so["p"].view(np.uint64)), knobs
+        assert np.array_equal(sg["U"][:sg["K"]], so["U"][:so["K"]]), knobs
+        assert g.gpu["edges_scanned"] == o.extra["edges_scanned"], knobs
+
+
 def test_plain_c_client_of_the_c_abi(tmp_path, gpu_lib):
     """tests/cabi_client.c -- plain C, no Python / torch in the process -- solves a problem through
     include/misslap.h (create / solve / destroy + the matching guard) and must print the oracle's answer."""
