@@ -24,7 +24,11 @@ for seed in range(first, first + count):
     kw = dict(problem=prob, cardinality_check=False, max_iter=int(r.choice([10**8, 10**8, 10**8, 3000, 211, 17])),
               eps_start=float(r.choice([0.0, 0.0, 1.0, 0.01])))
     gpu = dict(tail_threshold=[None, 0, 3, 17, 40, 200, 512][seed % 7], tiled_min_k=[None, None, 1, -1][seed % 4],
-               rounds_per_sync=[None, 1, 5][seed % 3])
+               rounds_per_sync=[None, 1, 5][seed % 3], cand_refresh=[None, None, 0, 30, 9][seed % 5],
+               cand_build_max_k=[None, None, None, 50, 900][(seed // 3) % 5], order_partial=[None, False][(seed // 2) % 2],
+               cand=[None, None, None, False][(seed // 5) % 4])
+    if gpu["tiled_min_k"] == 1:
+        gpu["engine"] = 1  # build the tile-major copy whatever the size
     gpu = {k: v for k, v in gpu.items() if v is not None}
     o = orc.from_sparse(loc, val.copy(), **kw)
     osol = o.solve()
