@@ -57,6 +57,7 @@ typedef struct misslap_options {
                                 [3]: multi-GPU shard threshold: 0 = default (the full-scan threshold, 0.3 N), > 0 = minimum K
                                      of a sharded round, < 0 = shard every grid round;
                                 [4]: 1 = no candidate lines (every bid scans its whole row; A/B timing, parity tests);
+                                     2 = lines, but no maintenance pass ahead of the tail kernels (k_refresh_lines);
                                 [5]: 1 = partial rounds of the full-scan engine take their bidders in list order instead of
                                      person order (A/B timing, parity tests);
                                 [7]: candidate-line tuning: bits 0..23 > 0 = k_bid (re)builds lines only in rounds with at

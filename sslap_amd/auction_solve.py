@@ -51,7 +51,9 @@ def _options(problem, eps_start, max_iter, device=None, tail_threshold=None, pro
     o.reserved[2] = int(os.environ.get("MISSLAP_ENGINE", 0)) if engine is None else int(engine)
     o.reserved[3] = int(os.environ.get("MISSLAP_SHARD_MIN_K", 0)) if shard_min_k is None else int(shard_min_k)
     # candidate lines (per-person exact bid shortcut, csrc/device_common.hpp): on by default, 0 = off (A/B runs)
-    o.reserved[4] = (1 - int(os.environ.get("MISSLAP_CAND", 1))) if cand is None else (0 if cand else 1)
+    # (cand=2 / MISSLAP_CAND=2: lines without the maintenance pass ahead of the tail kernels)
+    c = int(os.environ.get("MISSLAP_CAND", 1)) if cand is None else int(cand)
+    o.reserved[4] = 1 if c == 0 else (2 if c == 2 else 0)
     # partial rounds of the full-scan engine in person order (kernels_tiled.hpp, k_order_*): on by default, 0 = list order
     o.reserved[5] = ((1 - int(os.environ.get("MISSLAP_ORDER_PARTIAL", 1))) if order_partial is None
                      else (0 if order_partial else 1))

@@ -187,6 +187,46 @@ __global__ __launch_bounds__(kBidBlock) void k_bid(RoundArgs a, E ed) {
     }
 }
 
+// Line maintenance ahead of the tail kernels (once per eps-phase, when K has fallen to the tail threshold).  The grid
+// rounds refresh the lines of the persons who BID in them; a person who won its object in one of the big rounds (which
+// handle no lines) still carries the line of an earlier phase, and if it is evicted in the tail its stale line misses
+// there -- where a row scan is the whole round (measured at C3: 7 % of the single-bidder rounds, 36 ms per solve).  So
+// every person's line is evaluated once at the current prices (two persons per wavefront), and a line that would not
+// answer, or has fewer than `min_alive` live candidates left, is rebuilt from a full scan -- here, where a scan is
+// one of thousands in flight.  Nothing is bid: lines only decide which edges a later bid looks at.
+template <class E>
+__global__ __launch_bounds__(kBidBlock) void k_refresh_lines(RoundArgs a, E ed, int min_alive) {
+    if (!E::kCand || a.cand == nullptr) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wpb = kBidBlock / kWave;
+    const double eps = (double)a.eps;
+    const PriceSource src{a.price};
+    double hint = 0.0;
+    int err = 0;
+    for (int w = blockIdx.x * wpb + wave; 2 * w < a.n_rows; w += gridDim.x * wpb) {
+        const int i0 = 2 * w, i1 = 2 * w + 1;
+        const bool act1 = i1 < a.n_rows;
+        const int ime = (lane < kCandLanes || !act1) ? i0 : i1;
+        int2 sl = a.cand[(size_t)ime * kCandLanes + (lane & (kCandLanes - 1))];
+        CandBid b[2];
+        int alive[2];
+        cand_eval2(sl, true, act1, src, eps, b, err, NoEarly(), NoStamp(), alive);
+#pragma unroll
+        for (int X = 0; X < 2; ++X) {
+            if (X == 1 && !act1) continue;  // wave-uniform
+            if (b[X].hit && alive[X] >= min_alive) continue;
+            const int i = X ? i1 : i0;
+            const int s = a.row_ptr[i], e = a.row_ptr[i + 1];
+            CandBid full;
+            CandBuildArgs ba;
+            const typename E::Raw none[4] = {};
+            wave_bid_full<E, PriceSource, false, false>(ed, src, s, e, none, eps, full, ba, err);
+            if (ba.want) cand_build(a.cand, i, ba, eps, hint);
+        }
+    }
+    if (lane == 0 && err) atomicOr(&a.ctl->err, err);
+}
+
 // order_pos: the bidders of this rank's shard were taken in person order (k_bid_tiled, partial rounds): shard slot
 // -> list position; nullptr = the shard is a range of list positions
 __global__ __launch_bounds__(256) void k_tiebreak(RoundArgs a, const int *order_pos) {

@@ -75,6 +75,9 @@ constexpr int kDefaultTailThreshold = 192;
 // line that still hits in a grid round but is nearly spent would miss THERE, where a row scan is the whole round and
 // not one of hundreds in flight.  C3 solve 590 ms without, 511 (10), 498 (16), 493 (22), 491 (24), 493 (26), 496 (31);
 // the tail's misses fall from 6.5 % to 1.0 % of its bids.  C2 187 -> 160 ms, C5 4.61 -> 3.86 s (24).
+// The same threshold decides in k_refresh_lines, the maintenance pass over ALL persons ahead of the tail kernels, after
+// which the tail misses nothing at all (C3 443 -> 427 ms, C2 149 -> 145, C5 3.56 -> 3.54 s; with that pass the
+// threshold of the grid rounds hardly matters at C3 -- 0 / 6 / 12 / 24: 429 / 426 / 428 / 427 ms -- but both at 6: C5 3.70 s).
 constexpr int kDefaultCandRefresh = 24;
 constexpr int kDefaultRoundsPerSync = 16;
 constexpr int kRoundsPerSyncLargeK = 2;  // batch length while K > kRoundSmallMax
@@ -158,6 +161,7 @@ struct misslap_solver {
     int thr = -1;
     bool round_small = false;  // the current round's bids skip the global atomicMax and k_round_small finishes it
     int cand_build_max_K = 0x7fffffff;
+    bool line_maintenance = true;  // k_refresh_lines ahead of the tail kernels (options.reserved[4] = 2: off)
     int cand_refresh_min = kDefaultCandRefresh;
     bool round_ordered = false;  // the current round's bidders were taken in person order (k_order_*, partial tiled rounds)
     bool order_partial = true;   // ... which options.reserved[5] = 1 turns off (A/B, parity tests)
@@ -504,6 +508,11 @@ int launch_tail(misslap_solver *h) {
         if (!pr) return fail(MISSLAP_ERR_HIP, "hipEventCreate failed");
         HIP_TRY(hipEventRecord(pr->start, h->stream));
     }
+    if (h->f32 && h->cand && h->line_maintenance) {  // every line checked at today's prices (kernels_round.hpp)
+        RoundArgs ra = round_args(h);
+        hipLaunchKernelGGL(k_refresh_lines<EdgesF32>, dim3(blocks_for((h->n_rows + 1) / 2, kBidBlock / kWave)),
+                           dim3(kBidBlock), 0, h->stream, ra, EdgesF32{h->edges32}, h->cand_refresh_min);
+    }
     if (h->f32) {
         EdgesF32 ed{h->edges32};
         // the rounds with more than kTeamMax bidders first, with sixteen wavefronts (kernels_tail.hpp)
@@ -720,7 +729,8 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
         DevBlock blk;
         blk.want(&h->price, Mpad);
         blk.want(&h->rec, M);
-        if (h->f32 && !opt->reserved[4])  // candidate lines (reserved[4] != 0: off, A/B timing and parity tests)
+        h->line_maintenance = opt->reserved[4] != 2;
+    if (h->f32 && opt->reserved[4] != 1)  // candidate lines (reserved[4] = 1: off, A/B timing and parity tests)
             blk.want(&h->cand, N * (size_t)kCandLanes);
         blk.want(&h->p2o, N);
         blk.want(&h->o2p, M);

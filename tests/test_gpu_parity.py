@@ -365,6 +365,7 @@ def test_fuzz_random_instances_vs_oracle(seed, gpu_lib):
     dict(order_partial=False, tiled_min_k=1, engine=1),     # full-scan engine everywhere, partial rounds in list order
     dict(order_partial=True, tiled_min_k=1, engine=1, tail_threshold=0),
     dict(cand=False, tail_threshold=300),                   # no lines: the 512-thread tail kernel takes every mode
+    dict(cand=2),                                           # lines without the maintenance pass ahead of the tail
     dict(rounds_per_sync=1), dict(rounds_per_sync=37),      # batch length of the trailing status reads
 ])
 def test_tuning_knobs_do_not_change_the_result(knobs, gpu_lib):
