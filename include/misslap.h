@@ -41,7 +41,7 @@ typedef struct misslap_options {
     int64_t max_iter;        /* rounds, auction_.pyx:204,:308 */
     int32_t input_on_device; /* loc / val are device pointers already resident in HBM */
     int32_t tail_threshold;  /* rounds with K <= this run in the persistent one-workgroup kernels (launched once per
-                                eps-phase: > 16 bidders, 3..16, <= 2); < 0 = library default (192); 0 = grid kernels
+                                eps-phase: > 16 bidders, 3..16, <= 2); < 0 = library default (192; 40 without candidate lines); 0 = grid kernels
                                 only; max 512 */
     int32_t force_f64_values;/* keep 12 B/edge (int32 col + fp64 val) even when values are fp32-exact */
     int32_t profile;         /* 1: record HIP events around the full-scan bid launches, every launch of the full-scan

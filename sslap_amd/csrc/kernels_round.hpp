@@ -217,6 +217,7 @@ __global__ __launch_bounds__(kBidBlock) void k_refresh_lines(RoundArgs a, E ed, 
             if (b[X].hit && alive[X] >= min_alive) continue;
             const int i = X ? i1 : i0;
             const int s = a.row_ptr[i], e = a.row_ptr[i + 1];
+            if (e - s > kCandRowMax) continue;  // (wave-uniform) rows too long for a line are never cached
             CandBid full;
             CandBuildArgs ba;
             const typename E::Raw none[4] = {};

@@ -70,6 +70,10 @@ double now_ms() {
 // Round 2 with the 16-wavefront block kernel: C3 96: 485 ms, 192: 479, 256: 482, 384: 480, 512: 481; C5 128: 3.797 s,
 // 256: 3.790, 448: 3.823; C2 96: 160.9 ms, 192: 159.4, 320: 158.9 -- flat above ~150.
 constexpr int kDefaultTailThreshold = 192;
+// ... without candidate lines (12 B/edge layout, rows too long for a line) every bid of the tail is a row scan and the
+// tail only pays while few of them are in flight: C2 with fp64 values 192: 314 ms, 40: 279; C4 (300 edges per row) 192:
+// 13.7 ms, 40: 13.1
+constexpr int kDefaultTailThresholdNoLines = 40;
 // k_bid answers a line hit that leaves fewer live candidates than this by a full scan + rebuild (kernels_round.hpp).
 // Lines are built in the grid rounds but earn their keep in the tail kernel, tens of thousands of rounds later: a
 // line that still hits in a grid round but is nearly spent would miss THERE, where a row scan is the whole round and
@@ -611,9 +615,11 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
     if (st.err & kErrNonFinite) return fail(MISSLAP_ERR_INVALID, "val holds a NaN or an infinity");
     if (st.max_col >= 0x7ffffffe) return fail(MISSLAP_ERR_INVALID, "column index too large (max + 1 must fit an int32)");
     h->n_cols = st.max_col + 1;  // auction_.pyx:210
-    if (h->thr < 0)  // library default
-        h->thr = kDefaultTailThreshold;
     h->f32 = !st.not_f32 && !opt->force_f64_values;
+    if (h->thr < 0) {  // library default: by whether the persons will have candidate lines (rows of <= 256 edges)
+        const bool lines = h->f32 && opt->reserved[4] != 1 && nnz / h->n_rows <= kCandRowMax;
+        h->thr = lines ? kDefaultTailThreshold : kDefaultTailThresholdNoLines;
+    }
     const int flip = h->maximize ? 0 : 1;
     if (h->f32) {
         if ((rc = dev_alloc(&h->edges32, (size_t)nnz + 4 * kWave))) return rc;  // tail kernel reads up to 256 past a row start
