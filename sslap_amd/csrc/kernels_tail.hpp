@@ -561,8 +561,17 @@ __device__ __forceinline__ void tail_team1_mode(const TailArgs &a, const E &ed, 
     auto request = [&](int person) { slot = a.cand[(size_t)max(person, 0) * kCandLanes + l32]; };
     if (n0 < K) request(pi);
     __syncthreads();  // (sU / sStart have been read by everybody)
+#ifdef MISSLAP_TAIL_STAMP_TEAM
+    // diagnostic build: cycles of wavefront 0 per segment of a team round -> Ctl::dbg[6..9]: [6] bid of my slot,
+    // [7] barrier, [8] clean test / resolve / assign, [9] re-request, line rebuild
+    unsigned long long sacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sprev = __builtin_amdgcn_s_memtime();
+    const CycleStamp stamp{sacc, &sprev, wave == 0};
+#else
+    const NoStamp stamp;
+#endif
     int par = 0;
     for (;;) {
+        stamp.light(0);
         int sp = -2;  // the person whose line was requested early (-2: nothing requested)
         CandBuildArgs bd;
         int bd_person = -1;
@@ -593,7 +602,9 @@ __device__ __forceinline__ void tail_team1_mode(const TailArgs &a, const E &ed, 
                 uS[par][n0] = ps;
             }
         }
+        stamp.light(1);
         tail_barrier_lds();  // the bids are in LDS and every gather of the round is done; requests stay in flight
+        stamp.light(2);
         {
             const bool act = lane < K;
             const int ls = min(lane, kTeamMax - 1);
@@ -661,6 +672,7 @@ __device__ __forceinline__ void tail_team1_mode(const TailArgs &a, const E &ed, 
                 ps = n0 < K ? __builtin_amdgcn_readlane(sx, min(n0, kWave - 1)) : 0;
             }
         }
+        stamp.light(3);
         par ^= 1;
         nits += 1;
         const bool done = K <= 2 || nits >= max_iter;
@@ -668,8 +680,13 @@ __device__ __forceinline__ void tail_team1_mode(const TailArgs &a, const E &ed, 
         // row, a lost bid, a moved person) request now
         if (!done && n0 < K && sp != pi) request(pi);
         if (bd_person >= 0) tail_build(a, bd_person, bd, eps, st);
+        stamp.light(4);
         if (done) break;
     }
+#ifdef MISSLAP_TAIL_STAMP_TEAM
+    if (threadIdx.x == 0)
+        for (int k = 1; k <= 4; ++k) a.ctl->dbg[5 + k] += sacc[k];
+#endif
     // hand the list back: every wavefront writes its own slot
     if (lane == 0 && n0 < kTeamMax) {
         sU[n0] = pi;
