@@ -74,15 +74,19 @@ constexpr int kDefaultTailThreshold = 192;
 // tail only pays while few of them are in flight: C2 with fp64 values 192: 314 ms, 40: 279; C4 (300 edges per row) 192:
 // 13.7 ms, 40: 13.1
 constexpr int kDefaultTailThresholdNoLines = 40;
-// k_bid answers a line hit that leaves fewer live candidates than this by a full scan + rebuild (kernels_round.hpp).
-// Lines are built in the grid rounds but earn their keep in the tail kernel, tens of thousands of rounds later: a
-// line that still hits in a grid round but is nearly spent would miss THERE, where a row scan is the whole round and
-// not one of hundreds in flight.  C3 solve 590 ms without, 511 (10), 498 (16), 493 (22), 491 (24), 493 (26), 496 (31);
-// the tail's misses fall from 6.5 % to 1.0 % of its bids.  C2 187 -> 160 ms, C5 4.61 -> 3.86 s (24).
-// The same threshold decides in k_refresh_lines, the maintenance pass over ALL persons ahead of the tail kernels, after
-// which the tail misses nothing at all (C3 443 -> 427 ms, C2 149 -> 145, C5 3.56 -> 3.54 s; with that pass the
-// threshold of the grid rounds hardly matters at C3 -- 0 / 6 / 12 / 24: 429 / 426 / 428 / 427 ms -- but both at 6: C5 3.70 s).
-constexpr int kDefaultCandRefresh = 24;
+// Where a line is rebuilt matters more than whether it hits: lines are built in the grid rounds but earn their keep in
+// the tail kernels, tens of thousands of rounds later, and a line that still hits but is nearly spent would miss THERE,
+// where a row scan is the whole round and not one of hundreds in flight.  Two mechanisms, both on the number of
+// candidates still at or above tau ("live"):
+//   * k_refresh_lines, the maintenance pass over ALL persons ahead of the tail kernels (once per eps-phase): a line
+//     with fewer than kCandMaintenanceMin live candidates is rebuilt.  After it the tail misses nothing at all.
+//   * k_bid may answer a hit that leaves fewer than cand_refresh_min live candidates by a full scan + rebuild.  Before the
+//     maintenance pass existed this was the big lever (C3 590 ms without, 511 (10), 498 (16), 493 (22), 491 (24), 496
+//     (31); C2 187 -> 160 ms, C5 4.61 -> 3.86 s); with the pass it is redundant -- C3 24 / 8 / 0: 428 / 427 / 425 ms, C2
+//     144.8 / 142.2 / 143.9, C5 3.518 / 3.514 / 3.506 s -- and off by default (options.reserved[7] turns it on).
+// With the pass at 6 instead of 24, C5 loses 4 % (lines spent before the tail ends).
+constexpr int kDefaultCandRefresh = 0;
+constexpr int kCandMaintenanceMin = 24;
 constexpr int kDefaultRoundsPerSync = 16;
 constexpr int kRoundsPerSyncLargeK = 2;  // batch length while K > kRoundSmallMax
 constexpr int kMaxGridBlocks = 2048;  // 256 CUs x 8 resident 256-thread blocks
@@ -515,7 +519,7 @@ int launch_tail(misslap_solver *h) {
     if (h->f32 && h->cand && h->line_maintenance) {  // every line checked at today's prices (kernels_round.hpp)
         RoundArgs ra = round_args(h);
         hipLaunchKernelGGL(k_refresh_lines<EdgesF32>, dim3(blocks_for((h->n_rows + 1) / 2, kBidBlock / kWave)),
-                           dim3(kBidBlock), 0, h->stream, ra, EdgesF32{h->edges32}, h->cand_refresh_min);
+                           dim3(kBidBlock), 0, h->stream, ra, EdgesF32{h->edges32}, kCandMaintenanceMin);
     }
     if (h->f32) {
         EdgesF32 ed{h->edges32};
