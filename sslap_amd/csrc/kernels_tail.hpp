@@ -537,6 +537,115 @@ __device__ __forceinline__ void tail_team_mode(const TailArgs &a, const E &ed, i
     __syncthreads();
 }
 
+// ---- duo mode: K == 2 with one wavefront per bidder ------------------------------------------------------------------
+// The two-bidder rounds of solo mode, split over wavefronts 0 and 1 (the other wavefronts of the workgroup have ended
+// by then, so the barrier is between these two): each evaluates ONE line (cand_eval1, the shortest chain there is),
+// publishes its bid through LDS, and behind one LDS-only barrier both resolve / assign / push_all_left the two slots
+// identically in scalar code -- each stores BOTH winners' records, so that its own next gather follows them in program
+// order.  Runs while K == 2; hands the slots back through sU / sStart.  Lines only (8 B/edge layout).
+template <class E>
+__device__ __forceinline__ void tail_duo_mode(const TailArgs &a, const E &ed, int *sU, int *sStart, int &K,
+                                              long long &nits, const long long max_iter, const double eps,
+                                              TailStats &st) {
+    const int lane = lane_id(), l32 = lane & (kCandLanes - 1);
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // 0 or 1: my slot
+    __shared__ unsigned long long dKey[2][2];
+    __shared__ int dObj[2][2], dPrev[2][2], dPst[2][2];
+    const RecSource src{a.rec};
+    const bool cls = (lane >= 1) & (lane <= kCandMax);
+    int pi[2], ps[2];  // both slots, kept identically by both wavefronts
+#pragma unroll
+    for (int X = 0; X < 2; ++X) {
+        pi[X] = __builtin_amdgcn_readfirstlane(sU[X]);
+        ps[X] = __builtin_amdgcn_readfirstlane(sStart[X]);
+    }
+    int2 slot = cand_no_line();
+    auto request = [&](int person) { slot = a.cand[(size_t)max(person, 0) * kCandLanes + l32]; };
+    request(w ? pi[1] : pi[0]);
+    tail_barrier_lds();  // (sU / sStart have been read by both)
+    int par = 0;
+    for (;;) {
+        const int me = w ? pi[1] : pi[0], mys = w ? ps[1] : ps[0];
+        int sp = -2;  // the person whose line was requested early (-2: nothing requested)
+        CandBuildArgs bd;
+        int bd_person = -1;
+        CandBid b;
+        b.hit = false;
+        cand_eval1(slot, cls, src, eps, b, st.err, [&](const CandBid &x) {
+            sp = x.prev;
+            request(sp);  // the owner my bidder evicts if it wins
+        });
+        if (!b.hit) {
+            const typename E::Raw none[4] = {};
+            const int e = a.row_ptr[me + 1 + lane_zero()];
+            wave_bid_full<E, RecSource, true, false>(ed, src, mys, e, none, eps, b, bd, st.err);
+            bd_person = bd.want ? me : -1;
+        } else {
+            st.hits += 1;
+            st.hit_edges += (unsigned long long)b.len;
+        }
+        st.edges += (unsigned long long)b.len;
+        st.bids += 1;
+        if (lane == 0) {
+            dKey[par][w] = b.key;
+            dObj[par][w] = b.obj;
+            dPrev[par][w] = b.prev;
+            dPst[par][w] = b.pstart;
+        }
+        tail_barrier_lds();  // both bids are in LDS and both gathers of the round are done
+        const int o = w ^ 1;
+        const unsigned long long okey = readlane_u64(dKey[par][o], 0);
+        const int oobj = __builtin_amdgcn_readfirstlane(dObj[par][o]);
+        const int oprev = __builtin_amdgcn_readfirstlane(dPrev[par][o]);
+        const int opst = __builtin_amdgcn_readfirstlane(dPst[par][o]);
+        // the two bids by slot
+        const unsigned long long key0 = w ? okey : b.key, key1 = w ? b.key : okey;
+        const int obj0 = w ? oobj : b.obj, obj1 = w ? b.obj : oobj;
+        const int prev0 = w ? oprev : b.prev, prev1 = w ? b.prev : oprev;
+        const int pst0 = w ? opst : b.pstart, pst1 = w ? b.pstart : opst;
+        nits += 1;
+        // RESOLVE (:375-385): strict ">" -- the earlier list position keeps an object on equal bids
+        bool win0 = true, win1 = true;
+        if (obj0 == obj1) {
+            if (key1 > key0) win0 = false;
+            else win1 = false;
+        }
+        // ASSIGN (:396-418), by both wavefronts alike: a winner's slot goes to the evicted owner (or becomes a hole)
+        if (lane == 0) {
+            if (win0) apply_winner(a, pi[0], ps[0], obj0, prev0, key0);
+            if (win1) apply_winner(a, pi[1], ps[1], obj1, prev1, key1);
+        }
+        if (win0) {
+            pi[0] = prev0;
+            ps[0] = pst0;
+        }
+        if (win1) {
+            pi[1] = prev1;
+            ps[1] = pst1;
+        }
+        // push_all_left (:137-162) on two slots
+        if (pi[0] == -1 && pi[1] != -1) {
+            pi[0] = pi[1];
+            ps[0] = ps[1];
+            pi[1] = -1;
+        }
+        K = (pi[0] != -1) + (pi[1] != -1);
+        par ^= 1;
+        const bool done = K <= 1 || nits >= max_iter;
+        // the early request assumed "my bidder wins, nobody moves"; otherwise request again
+        if (!done && sp != (w ? pi[1] : pi[0])) request(w ? pi[1] : pi[0]);
+        if (bd_person >= 0) tail_build(a, bd_person, bd, eps, st);
+        if (done) break;
+    }
+    if (w == 0 && lane == 0) {  // (both wavefronts hold the same list)
+        sU[0] = pi[0];
+        sU[1] = pi[1];
+        sStart[0] = ps[0];
+        sStart[1] = ps[1];
+    }
+    tail_barrier_lds();
+}
+
 // ---- team mode with ONE list slot per wavefront (the 16-wavefront "team only" instance of the kernel) ------------------
 // The same round as tail_team_mode -- one LDS-only barrier, every serving wavefront finishes the round for the whole
 // list on lanes = slots and stores all winners' records itself -- but wavefront w serves slot w alone: a round is a
@@ -761,6 +870,24 @@ __global__ __launch_bounds__(kThreads) void k_tail(TailArgs a, E ed) {
         md[3 + m] += __builtin_amdgcn_s_memrealtime();
         md[m] += (unsigned long long)nits;
     };
+    auto flush_stats = [&]() {  // a wavefront's statistics, once, when it leaves the kernel
+        if (lane == 0) {
+            if (st.bids) {
+                atomicAdd(&ctl->edges, st.edges);
+                atomicAdd(&ctl->tail_edges, st.edges);
+                atomicAdd(&ctl->bids, st.bids);
+                if (st.hits) {
+                    atomicAdd(&ctl->cand_hits, st.hits);
+                    atomicAdd(&ctl->cand_edges, st.hit_edges);
+                }
+                atomicAdd(&ctl->dbg[12], st.bids);  // the tail's own totals: bids, line hits, line builds
+                atomicAdd(&ctl->dbg[13], st.hits);
+                atomicAdd(&ctl->dbg[14], st.builds);
+                atomicAdd(&ctl->dbg[15], st.hit_edges);
+            }
+            if (st.err) atomicOr(&ctl->err, st.err);
+        }
+    };
     for (;;) {
         if (kBlockOnly && K <= kTeamMax) break;  // the next kernel takes over
         if (kTeamOnly) {
@@ -770,6 +897,24 @@ __global__ __launch_bounds__(kThreads) void k_tail(TailArgs a, E ed) {
                 mode_end(1);
             }
             break;
+        }
+        if (!kBlockOnly && !kTeamOnly && K == 2 && K0 <= 2 && E::kCand && a.cand != nullptr) {
+            // ---- duo mode: wavefronts 0 and 1 run the two-bidder rounds, one bidder each; the other wavefronts have
+            // nothing left to do in this phase (K never grows) and END here, so the barriers of duo mode are between
+            // two wavefronts.  Then wavefront 0 runs the single-bidder chain alone.
+            if (wave >= 2) {
+                flush_stats();
+                return;
+            }
+            mode_begin(0);
+            tail_duo_mode(a, ed, sU, sStart, K, nits, max_iter, eps, st);
+            if (wave == 1) {
+                flush_stats();
+                return;
+            }
+            if (K > 0 && nits < max_iter) tail_solo_mode(a, ed, sU, sStart, K, nits, max_iter, eps, st);
+            mode_end(0);
+            break;  // K == 0 or nits == max_iter
         }
         if (!kBlockOnly && K <= 2) {
             // ---- solo mode: wavefront 0 runs the rest of the phase alone, see tail_solo_mode
@@ -1058,22 +1203,7 @@ __global__ __launch_bounds__(kThreads) void k_tail(TailArgs a, E ed) {
 #endif
 
     if (t < K0) a.U[t] = sU[t];
-    if (lane == 0) {
-        if (st.bids) {
-            atomicAdd(&ctl->edges, st.edges);
-            atomicAdd(&ctl->tail_edges, st.edges);
-            atomicAdd(&ctl->bids, st.bids);
-            if (st.hits) {
-                atomicAdd(&ctl->cand_hits, st.hits);
-                atomicAdd(&ctl->cand_edges, st.hit_edges);
-            }
-            atomicAdd(&ctl->dbg[12], st.bids);  // the tail's own totals: bids, line hits, line builds
-            atomicAdd(&ctl->dbg[13], st.hits);
-            atomicAdd(&ctl->dbg[14], st.builds);
-            atomicAdd(&ctl->dbg[15], st.hit_edges);
-        }
-        if (st.err) atomicOr(&ctl->err, st.err);
-    }
+    flush_stats();
     if (t == 0) {
         ctl->K = K;
         ctl->nits = nits;
