@@ -21,7 +21,10 @@
 //         both), misses queued and scanned in a second pass, wavefront 0 resolves (LDS hash table above 64 bidders);
 //   team  (3 <= K <= 16; 1024 threads): wavefront w serves slot w alone; ONE LDS-only barrier per round, every
 //         serving wavefront finishes the round for the whole list on lanes = slots;
-//   solo / chain (K <= 2; 512 threads): wavefront 0 alone, no barrier, no LDS.
+//   duo / chain (K <= 2; 512 threads): K = 2: wavefronts 0 and 1, one bidder each, one LDS-only barrier per round --
+//         the other six wavefronts END when K reaches 2, so that barrier is between two wavefronts; K = 1: wavefront 0
+//         alone, no barrier, no LDS.  (Solo mode -- both bidders in the two halves of wavefront 0 -- is what the
+//         layout without lines uses for K = 2.)
 // The 512-thread instance still holds every mode (two slots per wavefront in team mode): the 12 B/edge layout, which
 // has no lines, runs in it alone.
 //
