@@ -453,6 +453,23 @@ def test_two_handles_on_one_device_used_alternately(gpu_lib):
         assert h.gpu["tiled_active"] == 1
 
 
+def test_many_live_handles_and_the_stream_pool(gpu_lib):
+    """Twelve handles alive at once (each on its own stream), solved interleaved, destroyed together -- more idle
+    streams than the library's pool keeps (8) -- and then twelve more, which take streams from the pool: every
+    result equals the oracle's."""
+    import gc
+    loc, val = synth.gen_sparse(1200, 1500, 0.01, seed=21)
+    ref = orc.auction_solve(loc=loc, val=val.copy(), problem="max", cardinality_check=False, max_iter=10**8)
+    for _ in range(2):
+        hs = [from_sparse(loc, val.copy(), problem="max", cardinality_check=False, max_iter=10**8,
+                          tail_threshold=[None, 0, 7, 300][k % 4]) for k in range(12)]
+        sols = [h.solve() for h in reversed(hs)]
+        for sol, h in zip(sols, reversed(hs)):
+            assert np.array_equal(sol, ref["sol"]) and h.meta["its"] == ref["meta"]["its"]
+        del hs, sols
+        gc.collect()
+
+
 def test_create_destroy_many_times_does_not_leak(gpu_lib):
     import gc
     import torch
