@@ -62,6 +62,7 @@ struct Ctl {
 // ---- edge storage ------------------------------------------------------------------------------
 struct EdgesF32 {  // 8 B / edge
     static constexpr bool kCand = true;  // persons keep candidate lines (see below)
+    typedef int2 Slot;                   // a line slot as held in a register: {col, fp32 cost}
     typedef int2 Raw;                    // one edge as loaded (a row requested ahead of its use stays in this form)
     const int2 *e;
     __device__ __forceinline__ Raw load_raw_nt(int g) const {
@@ -86,8 +87,15 @@ struct EdgesF32 {  // 8 B / edge
         val = (double)__int_as_float(x.y);
     }
 };
+// A line slot of the 12 B/edge layout as held in registers: the 8-byte slot {col, -} plus the candidate's fp64 cost,
+// which lives in a second, parallel 256-byte line (the values of this layout do not fit the slot's fp32 field).
+struct Slot64 {
+    int x, y;
+    double c;
+};
 struct EdgesF64 {  // 12 B / edge
-    static constexpr bool kCand = false;  // a line slot holds an fp32 value: no lines in this layout
+    static constexpr bool kCand = true;  // persons keep candidate lines: 256 B of slots + 256 B of fp64 costs
+    typedef Slot64 Slot;
     struct Raw {
         int c;
         double v;
@@ -300,6 +308,39 @@ __device__ __forceinline__ int half_max_i32(int v) {
     return v;
 }
 
+// the cost of a line slot's candidate (lane-wise / of lane `sl`, wave-uniform), and the lines in memory
+__device__ __forceinline__ double slot_cost(const int2 &s) { return (double)__int_as_float(s.y); }
+__device__ __forceinline__ double slot_cost(const Slot64 &s) { return s.c; }
+__device__ __forceinline__ double slot_cost_at(const int2 &s, int sl) {
+    return (double)__int_as_float(__builtin_amdgcn_readlane(s.y, sl));
+}
+__device__ __forceinline__ double slot_cost_at(const Slot64 &s, int sl) { return readlane_f64(s.c, sl); }
+template <class Slot>
+struct LineIO;
+template <>
+struct LineIO<int2> {
+    static __device__ __forceinline__ int2 load(const int2 *cand, const double *, size_t idx) { return cand[idx]; }
+    static __device__ __forceinline__ int2 make(int x, int y) { return make_int2(x, y); }
+};
+template <>
+struct LineIO<Slot64> {
+    static __device__ __forceinline__ Slot64 load(const int2 *cand, const double *cost, size_t idx) {
+        const int2 s = cand[idx];
+        Slot64 r;
+        r.x = s.x;
+        r.y = s.y;
+        r.c = cost[idx];
+        return r;
+    }
+    static __device__ __forceinline__ Slot64 make(int x, int y) {
+        Slot64 r;
+        r.x = x;
+        r.y = y;
+        r.c = 0.0;
+        return r;
+    }
+};
+
 // What one half-wavefront (32 lanes) knows after evaluating one person's line.  All members are wave-uniform.
 struct CandBid {
     bool hit;
@@ -334,19 +375,19 @@ struct PriceSource {
 // caller can request their lines (into `slot` itself) before the rest of the round is computed.
 // the lane's record gather of a two-person line evaluation (split off so that a caller with several lines in flight
 // can issue all gathers before it evaluates any of them)
-template <class Src>
-__device__ __forceinline__ PriceRec cand_gather2(const int2 slot, const bool act0, const bool act1, const Src &src) {
+template <class Slot, class Src>
+__device__ __forceinline__ PriceRec cand_gather2(const Slot slot, const bool act0, const bool act1, const Src &src) {
     const int lane = lane_id(), l32 = lane & (kCandLanes - 1);
     const bool active = lane < kCandLanes ? act0 : act1;
     const bool is_cand = active & (l32 >= 1) & (l32 <= kCandMax) & (slot.x >= 0);
     return src.get(is_cand ? slot.x : 0);
 }
-template <class Early, class S = NoStamp>
-__device__ __forceinline__ void cand_eval2_r(int2 &slot, const PriceRec r, const bool act0, const bool act1,
+template <class Slot, class Early, class S = NoStamp>
+__device__ __forceinline__ void cand_eval2_r(Slot &slot, const PriceRec r, const bool act0, const bool act1,
                                              const double eps, CandBid (&out)[2], int &err, Early &&early,
                                              const S &stamp = S(), int *alive = nullptr);
-template <class Src, class Early, class S = NoStamp>
-__device__ __forceinline__ void cand_eval2(int2 &slot, const bool act0, const bool act1, const Src &src,
+template <class Slot, class Src, class Early, class S = NoStamp>
+__device__ __forceinline__ void cand_eval2(Slot &slot, const bool act0, const bool act1, const Src &src,
                                            const double eps, CandBid (&out)[2], int &err, Early &&early,
                                            const S &stamp = S(), int *alive = nullptr) {
     stamp(1);  // (diagnostic builds: drains the memory counters) the line has landed
@@ -354,15 +395,15 @@ __device__ __forceinline__ void cand_eval2(int2 &slot, const bool act0, const bo
     stamp(2);  // the records have landed
     cand_eval2_r(slot, r, act0, act1, eps, out, err, early, stamp, alive);
 }
-template <class Early, class S>
-__device__ __forceinline__ void cand_eval2_r(int2 &slot, const PriceRec r, const bool act0, const bool act1,
+template <class Slot, class Early, class S>
+__device__ __forceinline__ void cand_eval2_r(Slot &slot, const PriceRec r, const bool act0, const bool act1,
                                              const double eps, CandBid (&out)[2], int &err, Early &&early,
                                              const S &stamp, int *alive) {
     const int lane = lane_id(), l32 = lane & (kCandLanes - 1);
     const double ninf = -__builtin_huge_val();
     const bool active = lane < kCandLanes ? act0 : act1;
     const bool is_cand = active & (l32 >= 1) & (l32 <= kCandMax) & (slot.x >= 0);
-    const double cost = (double)__int_as_float(slot.y);
+    const double cost = slot_cost(slot);
     double tau[2];
     tau[0] = readlane_f64(__hiloint2double(slot.y, slot.x), 0);
     tau[1] = readlane_f64(__hiloint2double(slot.y, slot.x), kCandLanes);
@@ -395,7 +436,7 @@ __device__ __forceinline__ void cand_eval2_r(int2 &slot, const PriceRec r, const
         out[X].obj = __builtin_amdgcn_readlane(slot.x, sl);
         out[X].prev = __builtin_amdgcn_readlane(r.owner, sl);
         out[X].pstart = __builtin_amdgcn_readlane(r.ostart, sl);
-        c1[X] = (double)__int_as_float(__builtin_amdgcn_readlane(slot.y, sl));
+        c1[X] = slot_cost_at(slot, sl);
     }
     early(out);  // `slot` is dead from here on
     stamp.light(3);  // winners known, next lines requested
@@ -414,8 +455,8 @@ __device__ __forceinline__ void cand_eval2_r(int2 &slot, const PriceRec r, const
 // The same for ONE person (lanes 0..31 hold its line, `cls` = the lane is one of them and its slot is a candidate
 // slot, i.e. 1 <= lane <= kCandMax): the chain of single-bidder rounds is half of all rounds at C3 and two thirds
 // at C5, and a round is bound by the length of this dependent instruction sequence, not by memory.
-template <class Src, class Early, class S = NoStamp>
-__device__ __forceinline__ void cand_eval1(int2 &slot, const bool cls, const Src &src, const double eps, CandBid &out,
+template <class Slot, class Src, class Early, class S = NoStamp>
+__device__ __forceinline__ void cand_eval1(Slot &slot, const bool cls, const Src &src, const double eps, CandBid &out,
                                            int &err, Early &&early, const S &stamp = S()) {
     const int lane = lane_id();
     const double ninf = -__builtin_huge_val();
@@ -423,7 +464,7 @@ __device__ __forceinline__ void cand_eval1(int2 &slot, const bool cls, const Src
     const bool is_cand = cls & (slot.x >= 0);
     const PriceRec r = src.get(is_cand ? slot.x : 0);
     stamp(2);  // the records have landed
-    const double cost = (double)__int_as_float(slot.y);
+    const double cost = slot_cost(slot);
     const double tau = readlane_f64(__hiloint2double(slot.y, slot.x), 0);
     out.len = __builtin_amdgcn_readlane(slot.x, kCandLanes - 1);
     const double v = is_cand ? cost - r.price : ninf;  // vi = cost - p[j]   (:350)
@@ -444,7 +485,7 @@ __device__ __forceinline__ void cand_eval1(int2 &slot, const bool cls, const Src
     out.obj = __builtin_amdgcn_readlane(slot.x, sl);
     out.prev = __builtin_amdgcn_readlane(r.owner, sl);
     out.pstart = __builtin_amdgcn_readlane(r.ostart, sl);
-    const double c1 = (double)__int_as_float(__builtin_amdgcn_readlane(slot.y, sl));
+    const double c1 = slot_cost_at(slot, sl);
     early(out);  // `slot` is dead from here on
     stamp.light(3);
     const double W = readlane_f64(half_max_f64(lane == G ? ninf : v), 31);  // second best, counting multiplicity
@@ -475,7 +516,8 @@ struct CandBuildArgs {
 // doubles / halves until the count has passed the window [kCandMin, kCandMax], followed by a short bisection.
 // Every probe is four compares + popcounts on the wave's ballots.  Any t <= W with a count in [2, kCandMax]
 // gives a valid line: the search only decides how full the line gets.
-__device__ __forceinline__ void cand_build(int2 *cand, int person, const CandBuildArgs &ba, double eps,
+// `cost` = the parallel line of fp64 costs (12 B/edge layout; nullptr: the cost goes into the slot as an fp32).
+__device__ __forceinline__ void cand_build(int2 *cand, double *cost, int person, const CandBuildArgs &ba, double eps,
                                            double &hint) {
     const int lane = lane_id();
     const double ninf = -__builtin_huge_val();
@@ -523,8 +565,11 @@ __device__ __forceinline__ void cand_build(int2 *cand, int person, const CandBui
 #pragma unroll
     for (int u = 0; u < 4; ++u) {  // candidates in stored order: rank = elements before it that qualify
         const unsigned long long m = __ballot(ba.v[u] >= t) & okm[u];
-        if ((m >> lane) & 1ull)
-            line[1 + base + __popcll(m & lanemask_lt())] = make_int2(ba.c[u], __float_as_int((float)ba.a[u]));
+        if ((m >> lane) & 1ull) {
+            const int at = 1 + base + __popcll(m & lanemask_lt());
+            line[at] = make_int2(ba.c[u], cost ? 0 : __float_as_int((float)ba.a[u]));
+            if (cost) cost[(size_t)person * kCandLanes + at] = ba.a[u];
+        }
         base += __popcll(m);
     }
     if (lane < kCandLanes && (lane == 0 || lane == kCandLanes - 1 || lane > n)) {

@@ -38,7 +38,8 @@ struct RoundArgs {
     float eps;
     int launch_idx;
     int gather_max_K;             // k_bid runs only for K < gather_max_K (k_bid_tiled takes the rest); 0 = no limit
-    int2 *cand;                   // candidate lines (device_common.hpp); nullptr = none (12 B/edge layout)
+    int2 *cand;                   // candidate lines (device_common.hpp); nullptr = none
+    double *cand64;               // ... their fp64 costs (12 B/edge layout only, nullptr otherwise)
     int cand_build_max_K;         // k_bid uses and (re)builds lines only in rounds with K <= this
     int cand_refresh_min;         // ... and treats a hit that leaves fewer live candidates than this as a miss
 };
@@ -121,8 +122,8 @@ __global__ __launch_bounds__(kBidBlock) void k_bid(RoundArgs a, E ed) {
         CandBid b[2];
         b[0].hit = false;
         if (lines) {
-            const int2 slot = a.cand[(size_t)i * kCandLanes + (lane & (kCandLanes - 1))];
-            int2 sl = slot;
+            typename E::Slot sl = LineIO<typename E::Slot>::load(a.cand, a.cand64,
+                                                                 (size_t)i * kCandLanes + (lane & (kCandLanes - 1)));
             int alive[2];
             cand_eval2(sl, true, false, src, eps, b, err, NoEarly(), NoStamp(), alive);
             // A hit on a line with little life left is answered by a full scan all the same -- the bid is the same
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(kBidBlock) void k_bid(RoundArgs a, E ed) {
                 CandBuildArgs ba;
                 const typename E::Raw none[4] = {};
                 wave_bid_full<E, Src, false, false>(ed, src, s, e, none, eps, b[0], ba, err);
-                if (lines && ba.want) cand_build(a.cand, i, ba, eps, hint);
+                if (lines && ba.want) cand_build(a.cand, a.cand64, i, ba, eps, hint);
             } else {
                 wave_bid_lean(ed, src, s, e, eps, b[0], err);
             }
@@ -207,7 +208,8 @@ __global__ __launch_bounds__(kBidBlock) void k_refresh_lines(RoundArgs a, E ed, 
         const int i0 = 2 * w, i1 = 2 * w + 1;
         const bool act1 = i1 < a.n_rows;
         const int ime = (lane < kCandLanes || !act1) ? i0 : i1;
-        int2 sl = a.cand[(size_t)ime * kCandLanes + (lane & (kCandLanes - 1))];
+        typename E::Slot sl = LineIO<typename E::Slot>::load(a.cand, a.cand64,
+                                                             (size_t)ime * kCandLanes + (lane & (kCandLanes - 1)));
         CandBid b[2];
         int alive[2];
         cand_eval2(sl, true, act1, src, eps, b, err, NoEarly(), NoStamp(), alive);
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(kBidBlock) void k_refresh_lines(RoundArgs a, E ed, 
             CandBuildArgs ba;
             const typename E::Raw none[4] = {};
             wave_bid_full<E, PriceSource, false, false>(ed, src, s, e, none, eps, full, ba, err);
-            if (ba.want) cand_build(a.cand, i, ba, eps, hint);
+            if (ba.want) cand_build(a.cand, a.cand64, i, ba, eps, hint);
         }
     }
     if (lane == 0 && err) atomicOr(&a.ctl->err, err);

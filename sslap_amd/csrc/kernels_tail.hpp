@@ -43,7 +43,8 @@ struct TailArgs {
     int *p2o;
     int *o2p;
     int *U;
-    int2 *cand;     // candidate lines (nullptr in the 12 B/edge layout)
+    int2 *cand;     // candidate lines (nullptr: none)
+    double *cand64; // ... their fp64 costs (12 B/edge layout only, nullptr otherwise)
     int thr;
     float eps;
 };
@@ -104,12 +105,18 @@ __device__ __forceinline__ int lane_zero() {
 // wavefront's loads return in issue order, so a line can be used while the rows are still on their way, and a hit
 // never waits for a row at all.
 // the lane's slot of a line that never hits: tau = +inf in slot 0, every other slot empty
-__device__ __forceinline__ int2 cand_no_line() {
-    return (lane_id() & (kCandLanes - 1)) == 0 ? make_int2(0, 0x7ff00000) : make_int2(-1, 0);
+template <class Slot>
+__device__ __forceinline__ Slot cand_no_line() {
+    return (lane_id() & (kCandLanes - 1)) == 0 ? LineIO<Slot>::make(0, 0x7ff00000) : LineIO<Slot>::make(-1, 0);
+}
+// the lane's slot of person `p`'s line (l32 = lane & 31)
+template <class E>
+__device__ __forceinline__ typename E::Slot line_of(const TailArgs &a, int p, int l32) {
+    return LineIO<typename E::Slot>::load(a.cand, a.cand64, (size_t)max(p, 0) * kCandLanes + l32);
 }
 template <class E>
 struct TwoFetch {
-    int2 slot;                  // the lane's slot of its half's line
+    typename E::Slot slot;      // the lane's slot of its half's line
     typename E::Raw row[2][4];  // 12 B/edge layout (no lines): first four 64-edge chunks of each row, requested ahead
     int ev[2];                  // ... and the row ends (vector registers, the same value in every lane)
 };
@@ -130,8 +137,7 @@ __device__ __forceinline__ void request_two(const TailArgs &a, const E &ed, int 
                                             TwoFetch<E> &tf) {
     if (E::kCand) {
         const int pme = lane_id() < kCandLanes ? p0 : p1;
-        tf.slot = a.cand != nullptr ? a.cand[(size_t)max(pme, 0) * kCandLanes + (lane_id() & (kCandLanes - 1))]
-                                    : cand_no_line();
+        tf.slot = a.cand != nullptr ? line_of<E>(a, pme, lane_id() & (kCandLanes - 1)) : cand_no_line<typename E::Slot>();
     } else {
         fetch_row<E>(a, ed, p0, s0, tf.row[0], tf.ev[0]);
         fetch_row<E>(a, ed, p1, s1, tf.row[1], tf.ev[1]);
@@ -140,7 +146,7 @@ __device__ __forceinline__ void request_two(const TailArgs &a, const E &ed, int 
 
 __device__ __forceinline__ void tail_build(const TailArgs &a, int person, const CandBuildArgs &ba, double eps,
                                            TailStats &st) {
-    cand_build(a.cand, person, ba, eps, st.hint);
+    cand_build(a.cand, a.cand64, person, ba, eps, st.hint);
     st.builds += 1;
 }
 
@@ -195,12 +201,12 @@ __device__ __forceinline__ void tail_chain_mode(const TailArgs &a, const E &ed, 
     const RecSource src{a.rec};
     const bool cls = (lane >= 1) & (lane <= kCandMax);
     const bool lines = E::kCand && a.cand != nullptr;
-    int2 slot = cand_no_line();
-    typename E::Raw row[4];  // 12 B/edge layout (no lines): the row, requested ahead
+    typename E::Slot slot = cand_no_line<typename E::Slot>();
+    typename E::Raw row[4];  // (no lines): the row, requested ahead
     int ev = 0;
     auto request = [&](int person, int start) {
         if (E::kCand) {
-            if (lines) slot = a.cand[(size_t)max(person, 0) * kCandLanes + l32];
+            if (lines) slot = line_of<E>(a, person, l32);
         } else {
             fetch_row<E>(a, ed, person, start, row, ev);
         }
@@ -291,7 +297,7 @@ __device__ __forceinline__ void tail_solo_mode(const TailArgs &a, const E &ed, i
         return;
     }
     TwoFetch<E> tf;
-    tf.slot = cand_no_line();
+    tf.slot = cand_no_line<typename E::Slot>();
     request_two(a, ed, pi[0], ps[0], pi[1], ps[1], tf);
 #ifdef MISSLAP_TAIL_STAMP_SOLO
     // diagnostic build: cycles of wavefront 0 per segment of a solo round -> Ctl::dbg[6..11] (+ dbg[15] = rounds):
@@ -397,7 +403,7 @@ __device__ __forceinline__ void tail_team_mode(const TailArgs &a, const E &ed, i
     }
     wTab[wave][lane & (kTeamTab - 1)] = -1;
     TwoFetch<E> tf;
-    tf.slot = cand_no_line();
+    tf.slot = cand_no_line<typename E::Slot>();
     if (n0 < K) request_two(a, ed, pi[0], ps[0], pi[1], ps[1], tf);
     __syncthreads();  // (sU / sStart have been read by everybody)
 #ifdef MISSLAP_TAIL_STAMP_TEAM
@@ -562,8 +568,8 @@ __device__ __forceinline__ void tail_duo_mode(const TailArgs &a, const E &ed, in
         pi[X] = __builtin_amdgcn_readfirstlane(sU[X]);
         ps[X] = __builtin_amdgcn_readfirstlane(sStart[X]);
     }
-    int2 slot = cand_no_line();
-    auto request = [&](int person) { slot = a.cand[(size_t)max(person, 0) * kCandLanes + l32]; };
+    typename E::Slot slot = cand_no_line<typename E::Slot>();
+    auto request = [&](int person) { slot = line_of<E>(a, person, l32); };
     request(w ? pi[1] : pi[0]);
     tail_barrier_lds();  // (sU / sStart have been read by both)
     int par = 0;
@@ -669,8 +675,8 @@ __device__ __forceinline__ void tail_team1_mode(const TailArgs &a, const E &ed, 
     int pi = n0 < K ? __builtin_amdgcn_readfirstlane(sU[min(n0, kTailMax - 1)]) : -1;
     int ps = n0 < K ? __builtin_amdgcn_readfirstlane(sStart[min(n0, kTailMax - 1)]) : 0;
     vTab[wave][lane & (kTeamTab - 1)] = -1;
-    int2 slot = cand_no_line();
-    auto request = [&](int person) { slot = a.cand[(size_t)max(person, 0) * kCandLanes + l32]; };
+    typename E::Slot slot = cand_no_line<typename E::Slot>();
+    auto request = [&](int person) { slot = line_of<E>(a, person, l32); };
     if (n0 < K) request(pi);
     __syncthreads();  // (sU / sStart have been read by everybody)
 #ifdef MISSLAP_TAIL_STAMP_TEAM
@@ -965,15 +971,14 @@ __global__ __launch_bounds__(kThreads) void k_tail(TailArgs a, E ed) {
             // 3.51 us with one sweep in flight, 3.69 with two, 3.96 with three, 4.06 with four)
             constexpr int kBlockDepth = kBlockOnly ? 1 : 3;
             for (int base = 0; base < K; base += kBlockDepth * 2 * nwaves) {
-                int2 sl[kBlockDepth];
+                typename E::Slot sl[kBlockDepth];
                 PriceRec rr[kBlockDepth];
 #pragma unroll
                 for (int c = 0; c < kBlockDepth; ++c) {
                     const int nme = base + c * 2 * nwaves + 2 * wave + (lane >> 5);
                     const int pme = nme < K ? sU[min(nme, kTailMax - 1)] : -1;
-                    sl[c] = cand_no_line();
-                    if (E::kCand && a.cand != nullptr)
-                        sl[c] = a.cand[(size_t)max(pme, 0) * kCandLanes + (lane & (kCandLanes - 1))];
+                    sl[c] = cand_no_line<typename E::Slot>();
+                    if (E::kCand && a.cand != nullptr) sl[c] = line_of<E>(a, pme, lane & (kCandLanes - 1));
                 }
                 bstamp(1);
 #pragma unroll

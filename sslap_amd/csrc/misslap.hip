@@ -135,7 +135,8 @@ struct misslap_solver {
     int *row_ptr = nullptr;
     double *price = nullptr;
     PriceRec *rec = nullptr;
-    int2 *cand = nullptr;  // candidate lines, 256 B per person (8 B/edge layout only)
+    int2 *cand = nullptr;  // candidate lines, 256 B per person
+    double *cand64 = nullptr;  // ... and 256 B of fp64 costs per person in the 12 B/edge layout
     int *p2o = nullptr, *o2p = nullptr, *U = nullptr;
     unsigned long long *bid_key = nullptr;
     int *bid_obj = nullptr;
@@ -299,6 +300,7 @@ RoundArgs round_args(misslap_solver *h) {
     a.launch_idx = 0;
     a.gather_max_K = h->tiled_ok ? h->tiled_min_K : 0;
     a.cand = h->cand;
+    a.cand64 = h->cand64;
     a.cand_build_max_K = h->cand_build_max_K;
     a.cand_refresh_min = h->cand_refresh_min;
     return a;
@@ -444,18 +446,18 @@ int launch_bid(misslap_solver *h) {
     const EdgesF32 e32{h->edges32};
     const EdgesF64 e64{h->col, h->val64};
     const dim3 g(grid), b(kBidBlock);
-    if (h->round_small) {  // bids of a round that k_round_small finishes
-        if (h->f32) hipLaunchKernelGGL((k_bid<EdgesF32, RecSource, 2>), g, b, 0, h->stream, a, e32);
-        else hipLaunchKernelGGL((k_bid<EdgesF64, RecSource, 2>), g, b, 0, h->stream, a, e64);
-    } else if (!h->f32) {
-        hipLaunchKernelGGL((k_bid<EdgesF64, PriceSource, 0>), g, b, 0, h->stream, a, e64);
-    } else if (!h->cand) {
-        hipLaunchKernelGGL((k_bid<EdgesF32, PriceSource, 0>), g, b, 0, h->stream, a, e32);
-    } else if (h->K_ub > h->cand_build_max_K) {  // the full-scan regime: throughput, no line builds
-        hipLaunchKernelGGL((k_bid<EdgesF32, PriceSource, 1>), g, b, 0, h->stream, a, e32);
-    } else {
-        hipLaunchKernelGGL((k_bid<EdgesF32, PriceSource, 2>), g, b, 0, h->stream, a, e32);
-    }
+    // variant: 2 = lines used and rebuilt; 1 = lines used, lean scan, nothing built (the full-scan regime); 0 = no lines
+    const int variant = !h->cand ? 0 : h->K_ub > h->cand_build_max_K ? 1 : 2;
+#define MISSLAP_LAUNCH_BID(E, ED)                                                                                   \
+    do {                                                                                                            \
+        if (h->round_small) hipLaunchKernelGGL((k_bid<E, RecSource, 2>), g, b, 0, h->stream, a, ED);                \
+        else if (variant == 0) hipLaunchKernelGGL((k_bid<E, PriceSource, 0>), g, b, 0, h->stream, a, ED);           \
+        else if (variant == 1) hipLaunchKernelGGL((k_bid<E, PriceSource, 1>), g, b, 0, h->stream, a, ED);           \
+        else hipLaunchKernelGGL((k_bid<E, PriceSource, 2>), g, b, 0, h->stream, a, ED);                             \
+    } while (0)
+    if (h->f32) MISSLAP_LAUNCH_BID(EdgesF32, e32);  // (rounds that k_round_small finishes: bids with the owners)
+    else MISSLAP_LAUNCH_BID(EdgesF64, e64);
+#undef MISSLAP_LAUNCH_BID
     if (pr) HIP_TRY(hipEventRecord(pr->stop, h->stream));
     HIP_TRY(hipGetLastError());
     h->phase_fresh = false;
@@ -508,6 +510,7 @@ int launch_tail(misslap_solver *h) {
     a.o2p = h->o2p;
     a.U = h->U;
     a.cand = h->cand;
+    a.cand64 = h->cand64;
     a.thr = h->thr;
     a.eps = h->eps;
     ProfRec *pr = nullptr;
@@ -516,23 +519,25 @@ int launch_tail(misslap_solver *h) {
         if (!pr) return fail(MISSLAP_ERR_HIP, "hipEventCreate failed");
         HIP_TRY(hipEventRecord(pr->start, h->stream));
     }
-    if (h->f32 && h->cand && h->line_maintenance) {  // every line checked at today's prices (kernels_round.hpp)
-        RoundArgs ra = round_args(h);
-        hipLaunchKernelGGL(k_refresh_lines<EdgesF32>, dim3(blocks_for((h->n_rows + 1) / 2, kBidBlock / kWave)),
-                           dim3(kBidBlock), 0, h->stream, ra, EdgesF32{h->edges32}, kCandMaintenanceMin);
-    }
-    if (h->f32) {
-        EdgesF32 ed{h->edges32};
-        // the rounds with more than kTeamMax bidders first, with sixteen wavefronts (kernels_tail.hpp)
-        if (h->K_ub > kTeamMax) hipLaunchKernelGGL((k_tail<EdgesF32, 2 * kTailMax>), dim3(1), dim3(2 * kTailMax), 0, h->stream, a, ed);
-        // ... then the rounds with 3..kTeamMax bidders, one list slot per wavefront (lines only)
-        if (h->K_ub > 2 && h->cand)
-            hipLaunchKernelGGL((k_tail<EdgesF32, 2 * kTailMax, true>), dim3(1), dim3(2 * kTailMax), 0, h->stream, a, ed);
-        hipLaunchKernelGGL((k_tail<EdgesF32, kTailMax>), dim3(1), dim3(kTailMax), 0, h->stream, a, ed);
-    } else {
-        EdgesF64 ed{h->col, h->val64};
-        hipLaunchKernelGGL((k_tail<EdgesF64, kTailMax>), dim3(1), dim3(kTailMax), 0, h->stream, a, ed);
-    }
+    const EdgesF32 e32{h->edges32};
+    const EdgesF64 e64{h->col, h->val64};
+    // every line checked at today's prices (kernels_round.hpp); then the rounds with more than kTeamMax bidders, with
+    // sixteen wavefronts (kernels_tail.hpp); then -- lines only -- the rounds with 3..kTeamMax bidders, one list slot
+    // per wavefront; then the rest
+#define MISSLAP_LAUNCH_TAIL(E, ED)                                                                                       \
+    do {                                                                                                                 \
+        if (h->cand && h->line_maintenance)                                                                              \
+            hipLaunchKernelGGL(k_refresh_lines<E>, dim3(blocks_for((h->n_rows + 1) / 2, kBidBlock / kWave)),             \
+                               dim3(kBidBlock), 0, h->stream, round_args(h), ED, kCandMaintenanceMin);                   \
+        if (h->K_ub > kTeamMax)                                                                                          \
+            hipLaunchKernelGGL((k_tail<E, 2 * kTailMax>), dim3(1), dim3(2 * kTailMax), 0, h->stream, a, ED);             \
+        if (h->K_ub > 2 && h->cand)                                                                                      \
+            hipLaunchKernelGGL((k_tail<E, 2 * kTailMax, true>), dim3(1), dim3(2 * kTailMax), 0, h->stream, a, ED);       \
+        hipLaunchKernelGGL((k_tail<E, kTailMax>), dim3(1), dim3(kTailMax), 0, h->stream, a, ED);                         \
+    } while (0)
+    if (h->f32) MISSLAP_LAUNCH_TAIL(EdgesF32, e32);
+    else MISSLAP_LAUNCH_TAIL(EdgesF64, e64);
+#undef MISSLAP_LAUNCH_TAIL
     if (pr) HIP_TRY(hipEventRecord(pr->stop, h->stream));
     // the tail keeps only the price records current: rebuild price / o2p / p2o from them
     hipLaunchKernelGGL(k_sync_clear_p2o, dim3(blocks_for(h->n_rows, 256)), dim3(256), 0, h->stream, h->p2o, h->n_rows);
@@ -621,7 +626,7 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
     h->n_cols = st.max_col + 1;  // auction_.pyx:210
     h->f32 = !st.not_f32 && !opt->force_f64_values;
     if (h->thr < 0) {  // library default: by whether the persons will have candidate lines (rows of <= 256 edges)
-        const bool lines = h->f32 && opt->reserved[4] != 1 && nnz / h->n_rows <= kCandRowMax;
+        const bool lines = opt->reserved[4] != 1 && nnz / h->n_rows <= kCandRowMax;
         h->thr = lines ? kDefaultTailThreshold : kDefaultTailThresholdNoLines;
     }
     const int flip = h->maximize ? 0 : 1;
@@ -740,8 +745,10 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
         blk.want(&h->price, Mpad);
         blk.want(&h->rec, M);
         h->line_maintenance = opt->reserved[4] != 2;
-    if (h->f32 && opt->reserved[4] != 1)  // candidate lines (reserved[4] = 1: off, A/B timing and parity tests)
+        if (opt->reserved[4] != 1) {  // candidate lines (reserved[4] = 1: off, A/B timing and parity tests)
             blk.want(&h->cand, N * (size_t)kCandLanes);
+            if (!h->f32) blk.want(&h->cand64, N * (size_t)kCandLanes);  // 12 B/edge layout: the costs as fp64
+        }
         blk.want(&h->p2o, N);
         blk.want(&h->o2p, M);
         blk.want(&h->U, N);

@@ -389,6 +389,33 @@ def test_tuning_knobs_do_not_change_the_result(knobs, gpu_lib):
         assert g.gpu["edges_scanned"] == o.extra["edges_scanned"], knobs
 
 
+@pytest.mark.parametrize("thr", [None, 0, 12])
+@pytest.mark.parametrize("lines", [True, False, 2])
+def test_true_fp64_values_with_and_without_lines(lines, thr, gpu_lib):
+    """Values that are NOT fp32-exact (what most callers of the reference pass): the 12 B/edge layout with candidate
+    lines + fp64 cost lines, without lines, and without the maintenance pass, against the oracle -- sol, rounds,
+    prices, list order, scanned edges."""
+    r = np.random.default_rng(77)
+    for n, m, per_row, prob in ((2500, 2500, 40, "max"), (1800, 2600, 90, "min"), (6000, 6000, 12, "max")):
+        loc, _ = synth.gen_sparse(n, m, per_row / m, seed=300 + n)
+        val = r.random(loc.shape[0]) * 10.0 + r.random(loc.shape[0]) * 1e-9   # full 53-bit mantissas
+        assert not np.array_equal(val, val.astype(np.float32).astype(np.float64))
+        kw = dict(problem=prob, cardinality_check=False, max_iter=10**8)
+        o = orc.from_sparse(loc, val.copy(), **kw)
+        osol = o.solve()
+        g = from_sparse(loc, val.copy(), **kw, cand=lines, tail_threshold=thr)
+        gsol = g.solve()
+        assert g.gpu["bytes_per_edge"] == 12
+        assert (g.gpu["cand_hits"] > 0) == bool(lines)
+        assert np.array_equal(gsol, osol), (n, m, lines, thr)
+        for k in cases.META_KEYS:
+            assert g.meta[k] == o.meta[k], k
+        sg, so = g.state(), o.state()
+        assert np.array_equal(sg["p"].view(np.uint64), so["p"].view(np.uint64))
+        assert np.array_equal(sg["U"][:sg["K"]], so["U"][:so["K"]])
+        assert g.gpu["edges_scanned"] == o.extra["edges_scanned"] and g.gpu["obj_f64"] == o.extra["obj_f64"]
+
+
 def test_plain_c_client_of_the_c_abi(tmp_path, gpu_lib):
     """tests/cabi_client.c -- plain C, no Python / torch in the process -- solves a problem through
     include/misslap.h (create / solve / destroy + the matching guard) and must print the oracle's answer."""
@@ -512,15 +539,17 @@ def test_degenerate_shapes(thr, gpu_lib):
                 assert g.meta[k] == o.meta[k], k
 
 
-def test_f64_layout_at_c2_size_matches_reference_hash(golden_large, gpu_lib):
-    """The 12 B/edge kernel instances (int32 col + fp64 val: no candidate lines, rows requested ahead) at a BASELINE
-    size: C2's values are fp32-exact, so forcing the layout must reproduce the reference's C2 assignment."""
+@pytest.mark.parametrize("lines", [True, False])
+def test_f64_layout_at_c2_size_matches_reference_hash(lines, golden_large, gpu_lib):
+    """The 12 B/edge kernel instances (int32 col + fp64 val; candidate lines with a parallel line of fp64 costs, or --
+    lines off -- rows requested ahead) at a BASELINE size: C2's values are fp32-exact, so forcing the layout must
+    reproduce the reference's C2 assignment."""
     g = golden_large["cases"]["C2"]
     spec, kw = cases_mod.LARGE_CASES["C2"]
     loc, val = cases_mod.synth_inputs(spec)
-    s = from_sparse(loc, val, cardinality_check=False, force_f64=True, **kw)
+    s = from_sparse(loc, val, cardinality_check=False, force_f64=True, cand=lines, **kw)
     sol = s.solve()
-    assert s.gpu["bytes_per_edge"] == 12 and s.gpu["cand_hits"] == 0
+    assert s.gpu["bytes_per_edge"] == 12 and (s.gpu["cand_hits"] > 0) == lines
     assert synth.sol_digest(sol) == g["sol_sha256"]
     assert s.meta["its"] == g["meta"]["its"] and s.gpu["obj_f64"] == g["obj_f64"]
     assert s.gpu["edges_scanned"] == g["edges_scanned"]
