@@ -274,7 +274,8 @@ __device__ __forceinline__ unsigned long long lanemask_lt() {
 //
 // Line of person i = 32 slots of 8 bytes at cand[32 * i]: slot 0 = tau (fp64; +inf = no line yet), slots 1..30 =
 // {int32 col, fp32 val} (col -1 = empty), slot 31 = {row length, 0} (the scanned-edge statistics count whole rows).
-// Only the 8 B/edge layout (fp32-exact values) keeps lines; rows longer than kCandRowMax are never cached.
+// In the 12 B/edge layout (values that are not fp32-exact) the slot's fp32 field is unused and the cost lives, as fp64,
+// at the same index of a parallel line (Slot64 / LineIO).  Rows longer than kCandRowMax are never cached.
 constexpr int kCandLanes = 32;
 constexpr int kCandMax = 30;
 constexpr int kCandMin = 24;            // the threshold search aims at [kCandMin, kCandMax] candidates

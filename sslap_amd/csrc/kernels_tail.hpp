@@ -25,8 +25,9 @@
 //         the other six wavefronts END when K reaches 2, so that barrier is between two wavefronts; K = 1: wavefront 0
 //         alone, no barrier, no LDS.  (Solo mode -- both bidders in the two halves of wavefront 0 -- is what the
 //         layout without lines uses for K = 2.)
-// The 512-thread instance still holds every mode (two slots per wavefront in team mode): the 12 B/edge layout, which
-// has no lines, runs in it alone.
+// The 512-thread instance still holds every mode (two slots per wavefront in team mode): a handle whose lines are
+// switched off runs in it alone (plus the block instance).  Both edge layouts keep lines; in the 12 B/edge layout a
+// slot's cost comes from a parallel line of fp64 costs (device_common.hpp: Slot64).
 //
 // Visibility: records / lines are written and re-read by this one workgroup only (same CU, same
 // vector L1, barriers between phases); the CSR is read-only.  No other workgroup runs.
