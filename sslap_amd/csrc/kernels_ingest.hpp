@@ -11,7 +11,7 @@ struct IngestStats {
     int max_col;
     int err;          // kErr* bits
     int not_f32;      // some value is not exactly representable in fp32
-    int pad;
+    int max_row_len;  // longest row (k_max_row_len): decides whether the long-row line builder has work
     long long dense_total;  // dense ingest: number of valid entries, counted in 64 bits
 };
 
@@ -141,6 +141,14 @@ __global__ __launch_bounds__(256) void k_init_state(Ctl *ctl, double *price, Pri
         ctl->obj = 0.0;
         for (int k = 0; k < 16; ++k) ctl->dbg[k] = 0;
     }
+}
+
+__global__ __launch_bounds__(256) void k_max_row_len(const int *row_ptr, int n_rows, IngestStats *st) {
+    int m = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_rows; i += gridDim.x * blockDim.x)
+        m = max(m, row_ptr[i + 1] - row_ptr[i]);
+    for (int off = 32; off >= 1; off >>= 1) m = max(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(&st->max_row_len, m);
 }
 
 // ---- dense ingest (_from_matrix, auction_.pyx:546-557): keep v >= 0 in row-major order -----------------

@@ -230,6 +230,159 @@ __global__ __launch_bounds__(kBidBlock) void k_refresh_lines(RoundArgs a, E ed, 
     if (lane == 0 && err) atomicOr(&a.ctl->err, err);
 }
 
+// The same maintenance for LONG rows (kCandRowMax < row length <= kCandLongMax: the dense `mat=` entry of the reference,
+// rows of thousands of edges).  A full scan of such a row keeps nothing in registers that a line could be built from,
+// so their lines are built here and only here: one 256-thread workgroup per person holds the values cost - price of the
+// whole row in registers (up to 32 per thread), finds by bisection a threshold t <= W with 24..30 values at or above it
+// (a count per probe: compares in registers, one ballot per wavefront, one LDS add), collects the qualifying edges in
+// stored order and writes the line.  Everywhere else a missed line of a long row is answered by a scan without a
+// rebuild; the pass runs right before the tail kernels, which is where the lines are needed.
+constexpr int kLongThreads = 256;
+constexpr int kLongPer = 32;                           // values per thread
+constexpr int kCandLongMax = kLongThreads * kLongPer;  // 8192
+template <class E>
+__global__ __launch_bounds__(kLongThreads) void k_refresh_long(RoundArgs a, E ed, int min_alive) {
+    if (!E::kCand || a.cand == nullptr) return;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    __shared__ int s_need, s_cnt[2], s_n, s_g[kCandMax + 2], s_col[kCandMax + 2];
+    __shared__ double s_cost[kCandMax + 2], s_red[2][kLongThreads / kWave];
+    const double eps = (double)a.eps;
+    const double ninf = -__builtin_huge_val();
+    const PriceSource src{a.price};
+    for (int i = blockIdx.x; i < a.n_rows; i += gridDim.x) {
+        const int s = a.row_ptr[i], e = a.row_ptr[i + 1], len = e - s;
+        if (len <= kCandRowMax || len > kCandLongMax) continue;  // uniform over the workgroup
+        // does the line still answer, with enough life left?  (wavefront 0, like k_refresh_lines)
+        if (wave == 0) {
+            typename E::Slot sl = LineIO<typename E::Slot>::load(a.cand, a.cand64,
+                                                                 (size_t)i * kCandLanes + (lane & (kCandLanes - 1)));
+            CandBid b[2];
+            int alive[2], err = 0;
+            cand_eval2(sl, true, false, src, eps, b, err, NoEarly(), NoStamp(), alive);
+            if (lane == 0) s_need = !(b[0].hit && alive[0] >= min_alive);
+        }
+        if (t == 0) s_n = 0;
+        __syncthreads();
+        if (!s_need) {
+            __syncthreads();
+            continue;
+        }
+        // the row's values, in registers
+        double v[kLongPer];
+        double m1 = ninf, m2 = ninf;  // my best two (multiplicity counted)
+#pragma unroll
+        for (int k = 0; k < kLongPer; ++k) {
+            const int g = s + k * kLongThreads + t;
+            int c;
+            double cost;
+            ed.load(min(g, e - 1), c, cost);
+            const double x = g < e ? cost - src.get(c).price : ninf;
+            v[k] = x;
+            m2 = __builtin_fmax(m2, __builtin_fmin(x, m1));
+            m1 = __builtin_fmax(m1, x);
+        }
+        // W = the row's second-best value (multiplicity counted), lo = its smallest: wave-wide, then across wavefronts
+        double lo = __builtin_huge_val();
+#pragma unroll
+        for (int k = 0; k < kLongPer; ++k) lo = v[k] == ninf ? lo : __builtin_fmin(lo, v[k]);
+        {
+            Top2 x;
+            x.v = m1;
+            x.w = m2;
+            x.g = t;
+            const Top2 r = top2_wave_reduce(x);
+            const double wl = -wave_max_f64(-lo);
+            if (lane == 0) {
+                s_red[0][wave] = r.v;
+                s_red[1][wave] = r.w;
+                s_cost[wave] = wl;  // (scratch)
+            }
+        }
+        __syncthreads();
+        double V = ninf, W = ninf, LO = __builtin_huge_val();
+        for (int w2 = 0; w2 < kLongThreads / kWave; ++w2) {
+            const double bv = s_red[0][w2], bw = s_red[1][w2];
+            W = __builtin_fmax(W, __builtin_fmax(__builtin_fmin(bv, V), bw));
+            V = __builtin_fmax(V, bv);
+            LO = __builtin_fmin(LO, s_cost[w2]);
+        }
+        __syncthreads();
+        auto count_ge = [&](double thr, int par) {  // rows' values >= thr, uniform over the workgroup
+            int n = 0;
+#pragma unroll
+            for (int k = 0; k < kLongPer; ++k) n += v[k] >= thr;
+            for (int off = 32; off >= 1; off >>= 1) n += __shfl_xor(n, off);
+            if (t == 0) s_cnt[par] = 0;
+            __syncthreads();
+            if (lane == 0) atomicAdd(&s_cnt[par], n);
+            __syncthreads();
+            return s_cnt[par];
+        };
+        // threshold: count(v >= W) >= 2; more than kCandMax ties at the top: no line
+        double tsel = W;
+        int par = 0;
+        int nsel = count_ge(W, par);
+        par ^= 1;
+        bool ok = nsel <= kCandMax && W > ninf;
+        if (ok && nsel < kCandMin && LO < W) {
+            double hi_t = W, lo_t = LO;  // count(hi_t) = nsel < kCandMin; count(lo_t) = len > kCandMax
+            for (int it = 0; it < 48; ++it) {
+                const double mid = 0.5 * (hi_t + lo_t);
+                if (!(mid < hi_t) || !(mid > lo_t)) break;
+                const int n = count_ge(mid, par);
+                par ^= 1;
+                if (n > kCandMax) lo_t = mid;
+                else {
+                    hi_t = mid;
+                    tsel = mid;
+                    nsel = n;
+                    if (n >= kCandMin) break;
+                }
+            }
+        }
+        // collect the qualifying edges (at most kCandMax) and order them by stored index
+        if (ok) {
+#pragma unroll
+            for (int k = 0; k < kLongPer; ++k) {
+                if (v[k] >= tsel) {
+                    const int g = s + k * kLongThreads + t;
+                    int c;
+                    double cost;
+                    ed.load(g, c, cost);
+                    const int at = atomicAdd(&s_n, 1);
+                    if (at < kCandMax) {
+                        s_g[at] = g;
+                        s_col[at] = c;
+                        s_cost[at] = cost;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (wave == 0 && lane < kCandLanes) {
+            const int n = ok ? min(s_n, kCandMax) : 0;
+            int2 x = make_int2(-1, 0);  // empty slot
+            size_t at = (size_t)i * kCandLanes + lane;
+            if (lane == 0) {
+                const double tau = ok ? tsel : __builtin_huge_val();  // +inf: a line that never answers
+                x = make_int2(__double2loint(tau), __double2hiint(tau));
+            } else if (lane == kCandLanes - 1) {
+                x = make_int2(len, 0);
+            }
+            a.cand[at] = x;
+            __builtin_amdgcn_wave_barrier();
+            if (lane < n) {  // entry `lane` goes to slot 1 + (number of entries with a smaller stored index)
+                int rank = 0;
+                for (int q = 0; q < n; ++q) rank += s_g[q] < s_g[lane];
+                at = (size_t)i * kCandLanes + 1 + rank;
+                a.cand[at] = make_int2(s_col[lane], a.cand64 ? 0 : __float_as_int((float)s_cost[lane]));
+                if (a.cand64) a.cand64[at] = s_cost[lane];
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // order_pos: the bidders of this rank's shard were taken in person order (k_bid_tiled, partial rounds): shard slot
 // -> list position; nullptr = the shard is a range of list positions
 __global__ __launch_bounds__(256) void k_tiebreak(RoundArgs a, const int *order_pos) {

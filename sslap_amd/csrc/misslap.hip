@@ -74,6 +74,7 @@ constexpr int kDefaultTailThreshold = 192;
 // tail only pays while few of them are in flight: C2 with fp64 values 192: 314 ms, 40: 279; C4 (300 edges per row) 192:
 // 13.7 ms, 40: 13.1
 constexpr int kDefaultTailThresholdNoLines = 40;
+constexpr int kLongRowsFrom = 1024;  // average row length from which the long-row line builder runs
 // Where a line is rebuilt matters more than whether it hits: lines are built in the grid rounds but earn their keep in
 // the tail kernels, tens of thousands of rounds later, and a line that still hits but is nearly spent would miss THERE,
 // where a row scan is the whole round and not one of hundreds in flight.  Two mechanisms, both on the number of
@@ -170,6 +171,7 @@ struct misslap_solver {
     int thr = -1;
     bool round_small = false;  // the current round's bids skip the global atomicMax and k_round_small finishes it
     int cand_build_max_K = 0x7fffffff;
+    bool long_rows = false;  // some row is longer than kCandRowMax: k_refresh_long has work
     bool line_maintenance = true;  // k_refresh_lines ahead of the tail kernels (options.reserved[4] = 2: off)
     int cand_refresh_min = kDefaultCandRefresh;
     bool round_ordered = false;  // the current round's bidders were taken in person order (k_order_*, partial tiled rounds)
@@ -529,6 +531,9 @@ int launch_tail(misslap_solver *h) {
         if (h->cand && h->line_maintenance)                                                                              \
             hipLaunchKernelGGL(k_refresh_lines<E>, dim3(blocks_for((h->n_rows + 1) / 2, kBidBlock / kWave)),             \
                                dim3(kBidBlock), 0, h->stream, round_args(h), ED, kCandMaintenanceMin);                   \
+        if (h->cand && h->line_maintenance && h->long_rows)                                                              \
+            hipLaunchKernelGGL(k_refresh_long<E>, dim3(blocks_for(h->n_rows, 1)), dim3(kLongThreads), 0, h->stream,      \
+                               round_args(h), ED, kCandMaintenanceMin);                                                  \
         if (h->K_ub > kTeamMax)                                                                                          \
             hipLaunchKernelGGL((k_tail<E, 2 * kTailMax>), dim3(1), dim3(2 * kTailMax), 0, h->stream, a, ED);             \
         if (h->K_ub > 2 && h->cand)                                                                                      \
@@ -612,6 +617,7 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
     hipLaunchKernelGGL(k_ingest_rows, dim3(grid), dim3(256), 0, h->stream, d_loc, (long long)nnz, h->n_rows,
                        h->row_ptr, d_st);
     hipLaunchKernelGGL(k_ingest_vals, dim3(grid), dim3(256), 0, h->stream, d_val, (long long)nnz, d_st);
+    hipLaunchKernelGGL(k_max_row_len, dim3(blocks_for(h->n_rows, 256)), dim3(256), 0, h->stream, h->row_ptr, h->n_rows, d_st);
     IngestStats st;
     HIP_TRY(hipMemcpyAsync(&st, d_st, sizeof(st), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -625,8 +631,13 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
     if (st.max_col >= 0x7ffffffe) return fail(MISSLAP_ERR_INVALID, "column index too large (max + 1 must fit an int32)");
     h->n_cols = st.max_col + 1;  // auction_.pyx:210
     h->f32 = !st.not_f32 && !opt->force_f64_values;
+    // Lines for long rows (k_refresh_long) pay where a row scan is long: dense 8000^2 1.79 -> 0.60 s.  At a few
+    // hundred edges per row the pass costs more than the scans it saves (C4, 300 edges per row, 176 rounds: 13.4 ->
+    // 18.3 ms), so it runs from kLongRowsFrom edges per row on average.
+    const long long avg_row = nnz / h->n_rows;
+    h->long_rows = st.max_row_len > kCandRowMax && avg_row >= kLongRowsFrom && avg_row <= kCandLongMax;
     if (h->thr < 0) {  // library default: by whether the persons will have candidate lines (rows of <= 256 edges)
-        const bool lines = opt->reserved[4] != 1 && nnz / h->n_rows <= kCandRowMax;
+        const bool lines = opt->reserved[4] != 1 && (avg_row <= kCandRowMax || h->long_rows);
         h->thr = lines ? kDefaultTailThreshold : kDefaultTailThresholdNoLines;
     }
     const int flip = h->maximize ? 0 : 1;

@@ -416,6 +416,50 @@ def test_true_fp64_values_with_and_without_lines(lines, thr, gpu_lib):
         assert g.gpu["edges_scanned"] == o.extra["edges_scanned"] and g.gpu["obj_f64"] == o.extra["obj_f64"]
 
 
+@pytest.mark.parametrize("exact32", [True, False])
+@pytest.mark.parametrize("thr", [None, 0])
+def test_lines_of_long_rows(exact32, thr, gpu_lib):
+    """Rows of more than 256 edges get their candidate lines from the long-row builder of the maintenance pass
+    (k_refresh_long; it runs from 1024 edges per row on average): a dense matrix and a mix of long and short rows,
+    both value layouts, against the oracle -- sol, rounds, prices, list order, scanned edges."""
+    r = np.random.default_rng(123)
+
+    def check(loc, val, prob):
+        if exact32:
+            val = val.astype(np.float32).astype(np.float64)
+        kw = dict(problem=prob, cardinality_check=False, max_iter=10**8)
+        o = orc.from_sparse(loc, val.copy(), **kw)
+        osol = o.solve()
+        g = from_sparse(loc, val.copy(), **kw, tail_threshold=thr)
+        gsol = g.solve()
+        assert g.gpu["bytes_per_edge"] == (8 if exact32 else 12)
+        if thr is None:
+            assert g.gpu["cand_hits"] > 0 and g.tail_threshold == 192  # lines exist: the tail kernels are used widely
+        assert np.array_equal(gsol, osol)
+        for k in cases.META_KEYS:
+            assert g.meta[k] == o.meta[k], k
+        sg, so = g.state(), o.state()
+        assert np.array_equal(sg["p"].view(np.uint64), so["p"].view(np.uint64))
+        assert np.array_equal(sg["U"][:sg["K"]], so["U"][:so["K"]])
+        assert g.gpu["edges_scanned"] == o.extra["edges_scanned"] and g.gpu["obj_f64"] == o.extra["obj_f64"]
+
+    n = 1300  # dense
+    ii, jj = np.meshgrid(np.arange(n, dtype=np.int32), np.arange(n, dtype=np.int32), indexing="ij")
+    check(np.stack([ii.ravel(), jj.ravel()], axis=1), r.random(n * n) * 100.0, "max")
+    # three long rows (1 500 edges) for every short one (100 edges), 700 x 4 000
+    n, m = 700, 4000
+    rows, cols = [], []
+    for i in range(n):
+        k = 100 if i % 4 == 0 else 1500
+        c = np.sort(r.choice(m, size=k, replace=False)).astype(np.int32)
+        c[0] = min(c[0], i)  # (keeps a perfect matching of the persons possible)
+        c = np.unique(np.append(c, np.int32(i)))
+        rows.append(np.full(c.shape[0], i, np.int32))
+        cols.append(c)
+    loc = np.stack([np.concatenate(rows), np.concatenate(cols)], axis=1)
+    check(loc, r.random(loc.shape[0]) * 10.0, "min")
+
+
 def test_plain_c_client_of_the_c_abi(tmp_path, gpu_lib):
     """tests/cabi_client.c -- plain C, no Python / torch in the process -- solves a problem through
     include/misslap.h (create / solve / destroy + the matching guard) and must print the oracle's answer."""

@@ -20,6 +20,10 @@ for seed in range(first, first + count):
     density = float(r.choice([2.0, 4.0, 8.0, 30.0, 120.0])) / m
     ints = int(r.choice([0, 0, 0, 2, 5, 11]))
     prob = "max" if r.random() < 0.6 else "min"
+    if seed % 10 == 9:  # rows of >= 1024 edges: lines from the long-row builder of the maintenance pass
+        n = int(r.choice([1030, 1200]))
+        m = n if r.random() < 0.5 else n + int(r.integers(1, 400))
+        density = float(r.choice([0.9, 1.0]))
     loc, val = synth.gen_sparse(n, m, density, seed=900 + seed, integer_values=ints)
     if seed % 3 == 2:  # values that are not fp32-exact: the 12 B/edge layout (lines with fp64 cost lines)
         val = val + r.random(val.shape[0]) * 1e-7
