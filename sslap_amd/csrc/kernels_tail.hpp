@@ -47,6 +47,8 @@ struct TailArgs {
     int2 *cand;     // candidate lines (nullptr: none)
     double *cand64; // ... their fp64 costs (12 B/edge layout only, nullptr otherwise)
     int thr;
+    int round_budget;  // > 0: a kernel instance returns to the host after so many rounds (the host then refreshes the
+                       // lines of long rows, which the kernels cannot rebuild in place, and launches again); 0 = no limit
     float eps;
 };
 
@@ -843,10 +845,14 @@ __global__ __launch_bounds__(kThreads) void k_tail(TailArgs a, E ed) {
     constexpr int nwaves = kThreads / kWave;
     int K = ctl->K;
     long long nits = ctl->nits;
-    const long long max_iter = ctl->max_iter;
+    const long long max_iter =
+        a.round_budget > 0 ? min(ctl->max_iter, nits + (long long)(kBlockOnly ? max(a.round_budget / 4, 1) : a.round_budget))
+                           : ctl->max_iter;  // (block rounds have the most bidders, i.e. spend the most lines)
     if (K == 0 || K > a.thr || nits >= max_iter) return;  // uniform
     if (kBlockOnly && K <= kTeamMax) return;
     if (kTeamOnly && (K <= 2 || K > kTeamMax)) return;
+    // (budgeted launches: an instance that ran out of rounds leaves K to the NEXT launch's instance of the right role)
+    if (!kBlockOnly && !kTeamOnly && a.round_budget > 0 && K > 2 && E::kCand && a.cand != nullptr) return;
     const int K0 = K;
     const long long nits0 = nits;
     if (t < kTailMax) {

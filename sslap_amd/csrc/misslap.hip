@@ -74,7 +74,12 @@ constexpr int kDefaultTailThreshold = 192;
 // tail only pays while few of them are in flight: C2 with fp64 values 192: 314 ms, 40: 279; C4 (300 edges per row) 192:
 // 13.7 ms, 40: 13.1
 constexpr int kDefaultTailThresholdNoLines = 40;
-constexpr int kLongRowsFrom = 1024;  // average row length from which the long-row line builder runs
+constexpr int kLongRowsFrom = 1024;
+// Tail rounds between two maintenance passes of a long-row handle (the tail kernels cannot rebuild the line of a long
+// row in place: a missed line stays missed until the next pass, and every miss is a scan of the whole row).  Dense
+// 8000^2: no limit 341 ms, 4096: 324, 1024: 220, 256: 121, 128: 120, 64: 144, 32: 200; with a quarter of the budget for
+// the block instance (most bidders per round, i.e. most lines spent) 512: 123, 256: 101, 128: 108.
+constexpr int kLongRowTailBudget = 256;  // average row length from which the long-row line builder runs
 // Where a line is rebuilt matters more than whether it hits: lines are built in the grid rounds but earn their keep in
 // the tail kernels, tens of thousands of rounds later, and a line that still hits but is nearly spent would miss THERE,
 // where a row scan is the whole round and not one of hundreds in flight.  Two mechanisms, both on the number of
@@ -171,6 +176,7 @@ struct misslap_solver {
     int thr = -1;
     bool round_small = false;  // the current round's bids skip the global atomicMax and k_round_small finishes it
     int cand_build_max_K = 0x7fffffff;
+    int tail_round_budget = kLongRowTailBudget;
     bool long_rows = false;  // some row is longer than kCandRowMax: k_refresh_long has work
     bool line_maintenance = true;  // k_refresh_lines ahead of the tail kernels (options.reserved[4] = 2: off)
     int cand_refresh_min = kDefaultCandRefresh;
@@ -513,6 +519,7 @@ int launch_tail(misslap_solver *h) {
     a.U = h->U;
     a.cand = h->cand;
     a.cand64 = h->cand64;
+    a.round_budget = h->long_rows && h->cand && h->line_maintenance ? h->tail_round_budget : 0;
     a.thr = h->thr;
     a.eps = h->eps;
     ProfRec *pr = nullptr;
