@@ -75,6 +75,7 @@ constexpr int kDefaultTailThreshold = 192;
 // 13.7 ms, 40: 13.1
 constexpr int kDefaultTailThresholdNoLines = 40;
 constexpr int kLongRowsFrom = 1024;
+constexpr long long kLongRowsAfterTailRounds = 1500;
 // Tail rounds between two maintenance passes of a long-row handle (the tail kernels cannot rebuild the line of a long
 // row in place: a missed line stays missed until the next pass, and every miss is a scan of the whole row).  Dense
 // 8000^2: no limit 341 ms, 4096: 324, 1024: 220, 256: 121, 128: 120, 64: 144, 32: 200; with a quarter of the budget for
@@ -177,6 +178,7 @@ struct misslap_solver {
     bool round_small = false;  // the current round's bids skip the global atomicMax and k_round_small finishes it
     int cand_build_max_K = 0x7fffffff;
     int tail_round_budget = kLongRowTailBudget;
+    bool long_rows_later = false;  // rows of a few hundred edges: k_refresh_long only if the tail turns out long
     bool long_rows = false;  // some row is longer than kCandRowMax: k_refresh_long has work
     bool line_maintenance = true;  // k_refresh_lines ahead of the tail kernels (options.reserved[4] = 2: off)
     int cand_refresh_min = kDefaultCandRefresh;
@@ -509,6 +511,10 @@ int launch_apply(misslap_solver *h) {
 
 int launch_tail(misslap_solver *h) {
     if (h->thr <= 0) return MISSLAP_OK;
+    if (h->long_rows_later && h->h_ctl->tail_rounds >= kLongRowsAfterTailRounds) {  // (status read just before)
+        h->long_rows = true;
+        h->long_rows_later = false;
+    }
     TailArgs a;
     a.ctl = h->ctl;
     a.row_ptr = h->row_ptr;
@@ -643,6 +649,9 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
     // 18.3 ms), so it runs from kLongRowsFrom edges per row on average.
     const long long avg_row = nnz / h->n_rows;
     h->long_rows = st.max_row_len > kCandRowMax && avg_row >= kLongRowsFrom && avg_row <= kCandLongMax;
+    // ... below that (C4's 300 edges per row, a dense 600^2) only once the solve has shown that its tail is long:
+    // launch_tail switches the builder on after kLongRowsAfterTailRounds tail rounds
+    h->long_rows_later = !h->long_rows && avg_row > kCandRowMax && avg_row <= kCandLongMax && opt->reserved[4] != 1;
     if (h->thr < 0) {  // library default: by whether the persons will have candidate lines (rows of <= 256 edges)
         const bool lines = opt->reserved[4] != 1 && (avg_row <= kCandRowMax || h->long_rows);
         h->thr = lines ? kDefaultTailThreshold : kDefaultTailThresholdNoLines;
