@@ -122,9 +122,29 @@ CONFIGS = {
     "C3": dict(n_rows=200_000, n_cols=200_000, density=0.001),
     "C4": dict(n_rows=100_000, n_cols=150_000, density=0.002),
     "C5": dict(n_rows=1_000_000, n_cols=1_000_000, density=0.0001),
+    # not a BASELINE config: the shape of the reference's `mat=` entry (every row holds every column)
+    "D1": dict(n_rows=8_000, n_cols=8_000, density=1.0, dense=True),
 }
+
+
+def gen_dense(n_rows, n_cols, seed=1):
+    """Every (i, j) present -- what the reference's `mat=` entry produces for a matrix without negative entries
+    (auction_.pyx:546-557) -- with the same fp32-exact value stream as gen_sparse."""
+    N, M = int(n_rows), int(n_cols)
+    loc = np.empty((N * M, 2), dtype=np.int32)
+    loc[:, 0] = np.repeat(np.arange(N, dtype=np.int32), M)
+    loc[:, 1] = np.tile(np.arange(M, dtype=np.int32), N)
+    val = np.empty(N * M, dtype=np.float64)
+
+    def to_val(h):
+        u = (h >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / (1 << 24))
+        return u * np.float32(100.0)
+    _stream(seed, 3, N * M, out=val, post=to_val)
+    return loc, val
 
 
 def gen_config(name, seed=1):
     c = CONFIGS[name]
+    if c.get("dense"):
+        return gen_dense(c["n_rows"], c["n_cols"], seed=seed)
     return gen_sparse(c["n_rows"], c["n_cols"], c["density"], seed=seed)
