@@ -237,10 +237,10 @@ __global__ __launch_bounds__(kBidBlock) void k_refresh_lines(RoundArgs a, E ed, 
 // (a count per probe: compares in registers, one ballot per wavefront, one LDS add), collects the qualifying edges in
 // stored order and writes the line.  Everywhere else a missed line of a long row is answered by a scan without a
 // rebuild; the pass runs right before the tail kernels, which is where the lines are needed.
-constexpr int kLongThreads = 256;
-constexpr int kLongPer = 32;                           // values per thread
-constexpr int kCandLongMax = kLongThreads * kLongPer;  // 8192
-template <class E>
+constexpr int kLongPer = 32;                   // values per thread
+constexpr int kCandLongMax = 512 * kLongPer;  // 16384: the longest row that keeps a line (512-thread instance; 1024
+                                              // threads leave 128 registers per thread, which spills the row's values)
+template <class E, int kLongThreads>          // 256 threads: rows <= 8192 edges; 512 threads: rows <= 16384
 __global__ __launch_bounds__(kLongThreads) void k_refresh_long(RoundArgs a, E ed, int min_alive) {
     if (!E::kCand || a.cand == nullptr) return;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(kLongThreads) void k_refresh_long(RoundArgs a, E ed
     const PriceSource src{a.price};
     for (int i = blockIdx.x; i < a.n_rows; i += gridDim.x) {
         const int s = a.row_ptr[i], e = a.row_ptr[i + 1], len = e - s;
-        if (len <= kCandRowMax || len > kCandLongMax) continue;  // uniform over the workgroup
+        if (len <= kCandRowMax || len > kLongThreads * kLongPer) continue;  // uniform over the workgroup
         // does the line still answer, with enough life left?  (wavefront 0, like k_refresh_lines)
         if (wave == 0) {
             typename E::Slot sl = LineIO<typename E::Slot>::load(a.cand, a.cand64,

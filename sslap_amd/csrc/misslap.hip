@@ -178,6 +178,7 @@ struct misslap_solver {
     bool round_small = false;  // the current round's bids skip the global atomicMax and k_round_small finishes it
     int cand_build_max_K = 0x7fffffff;
     int tail_round_budget = kLongRowTailBudget;
+    int max_row_len = 0;
     bool long_rows_later = false;  // rows of a few hundred edges: k_refresh_long only if the tail turns out long
     bool long_rows = false;  // some row is longer than kCandRowMax: k_refresh_long has work
     bool line_maintenance = true;  // k_refresh_lines ahead of the tail kernels (options.reserved[4] = 2: off)
@@ -544,9 +545,14 @@ int launch_tail(misslap_solver *h) {
         if (h->cand && h->line_maintenance)                                                                              \
             hipLaunchKernelGGL(k_refresh_lines<E>, dim3(blocks_for((h->n_rows + 1) / 2, kBidBlock / kWave)),             \
                                dim3(kBidBlock), 0, h->stream, round_args(h), ED, kCandMaintenanceMin);                   \
-        if (h->cand && h->line_maintenance && h->long_rows)                                                              \
-            hipLaunchKernelGGL(k_refresh_long<E>, dim3(blocks_for(h->n_rows, 1)), dim3(kLongThreads), 0, h->stream,      \
-                               round_args(h), ED, kCandMaintenanceMin);                                                  \
+        if (h->cand && h->line_maintenance && h->long_rows) {                                                            \
+            if (h->max_row_len <= 256 * kLongPer)                                                                        \
+                hipLaunchKernelGGL((k_refresh_long<E, 256>), dim3(blocks_for(h->n_rows, 1)), dim3(256), 0, h->stream,    \
+                                   round_args(h), ED, kCandMaintenanceMin);                                              \
+            else                                                                                                         \
+                hipLaunchKernelGGL((k_refresh_long<E, 512>), dim3(blocks_for(h->n_rows, 1)), dim3(512), 0, h->stream,    \
+                                   round_args(h), ED, kCandMaintenanceMin);                                              \
+        }                                                                                                                \
         if (h->K_ub > kTeamMax)                                                                                          \
             hipLaunchKernelGGL((k_tail<E, 2 * kTailMax>), dim3(1), dim3(2 * kTailMax), 0, h->stream, a, ED);             \
         if (h->K_ub > 2 && h->cand)                                                                                      \
@@ -648,6 +654,7 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
     // hundred edges per row the pass costs more than the scans it saves (C4, 300 edges per row, 176 rounds: 13.4 ->
     // 18.3 ms), so it runs from kLongRowsFrom edges per row on average.
     const long long avg_row = nnz / h->n_rows;
+    h->max_row_len = st.max_row_len;
     h->long_rows = st.max_row_len > kCandRowMax && avg_row >= kLongRowsFrom && avg_row <= kCandLongMax;
     // ... below that (C4's 300 edges per row, a dense 600^2) only once the solve has shown that its tail is long:
     // launch_tail switches the builder on after kLongRowsAfterTailRounds tail rounds
