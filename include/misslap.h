@@ -280,6 +280,9 @@ int misslap_hopcroft_karp(const int32_t *loc, int64_t nnz, int32_t n_rows, int32
  * host array; *phases (may be NULL) receives the number of augmentation phases.  Needs a GPU. */
 int misslap_matching_gpu(const int32_t *loc, int64_t nnz, int32_t n_rows, int32_t n_cols, int32_t device, int32_t *size,
                          int32_t *left_pairings, int32_t *right_pairings, int32_t *phases);
+/* The same matcher on the graph a solver handle already holds in device memory (no host copy of the entries, no second
+ * upload): what the front-end's feasibility guard (auction_.pyx:562-566, :608-612) uses once the handle exists. */
+int misslap_matching_of(misslap_solver *h, int32_t *size, int32_t *phases);
 
 const char *misslap_last_error(void);
 int misslap_abi_version(void);

@@ -95,6 +95,7 @@ SYMBOLS = {
     "misslap_set_stream": (C.c_int, [_VP, _VP]),
     "misslap_get_state": (C.c_int, [_VP, _VP, _VP, _VP, _VP]),
     "misslap_device_info": (C.c_int, [C.c_int32, C.c_char_p, C.c_int32, _I32P, C.POINTER(C.c_int64)]),
+    "misslap_matching_of": (C.c_int, [_VP, _I32P, _I32P]),
     "misslap_rccl_unique_id": (C.c_int, [_VP]),
     "misslap_comm_init_rccl": (C.c_int, [C.POINTER(_VP), _VP, C.c_int32, C.c_int32, C.c_int32]),
     "misslap_comm_init_custom": (C.c_int, [C.POINTER(_VP), C.POINTER(CommOps)]),

@@ -263,6 +263,13 @@ class AuctionSolver:
         _lib.check(_lib.load().misslap_exchange_buffers(self._h, C.byref(k), C.byref(p), C.byref(n)))
         return k.value, p.value, n.value
 
+    def matching_cardinality(self):
+        """Size of a maximum matching of the handle's graph (GPU matcher on the device-resident CSR): the feasibility
+        guard of the front-end (auction_.pyx:562-566, :608-612) without a host copy of the entries."""
+        size = C.c_int32()
+        _lib.check(_lib.load().misslap_matching_of(self._h, C.byref(size), None))
+        return int(size.value)
+
     def set_stream(self, hip_stream):
         _lib.check(_lib.load().misslap_set_stream(self._h, C.c_void_p(int(hip_stream))))
 
@@ -300,9 +307,8 @@ def from_matrix(mat, problem="min", eps_start=0, max_iter=1000000, fast=False, c
         raise ValueError(f"Matrix is infeasible - Fewer than {N} valid values provided for {N} rows.")
     _lib.check(rc)
     solver = AuctionSolver._from_handle(h, opts, problem)
-    if cardinality_check:  # :562-566
-        r, c = np.nonzero(mat >= 0)
-        cardinality = _cardinality(np.stack([r, c], axis=1), N, M)
+    if cardinality_check:  # :562-566, on the CSR the handle already holds in device memory
+        cardinality = solver.matching_cardinality()
         if cardinality < N:
             raise ValueError(f"Matrix is infeasible (Maximum matching possible only involves {cardinality} "
                              f"out of {N} rows.)")
@@ -325,14 +331,30 @@ def from_sparse(loc, val, problem="min", eps_start=0, max_iter=1000000, fast=Fal
     loc_long = loc.astype(np.int32)  # :601
     if num_entries < N:  # :604-605
         raise ValueError(f"Matrix is infeasible - Fewer than {N} valid values provided for {N} rows.")
+    if fast:
+        eps_start = 1 / N  # :614-615 (nothing before this line depends on it)
     if cardinality_check:  # :608-612 (on the true graph; the reference indexes out of bounds here)
         n_true, m_true = int(loc_long[:, 0].max()) + 1, int(loc_long[:, 1].max()) + 1
+        failed = None
+        if num_entries >= int(os.environ.get("MISSLAP_MATCHING_GPU_MIN_NNZ", 2_000_000)):
+            # large graphs: the handle first, then the GPU matcher on the CSR it holds in device memory -- the entries
+            # are uploaded once.  A constructor error is kept until the guard (which the reference runs first) has spoken.
+            try:
+                solver = AuctionSolver(loc_long, val, problem=problem, eps_start=eps_start, max_iter=max_iter, **gpu_opts)
+            except ValueError as e:
+                failed = e
+            else:
+                cardinality = solver.matching_cardinality()
+                if cardinality < n_true:
+                    raise ValueError(f"Matrix is infeasible (Maximum matching possible only involves {cardinality} "
+                                     f"out of {n_true} rows.)")
+                return solver
         cardinality = _cardinality(loc_long, n_true, m_true)
         if cardinality < n_true:
             raise ValueError(f"Matrix is infeasible (Maximum matching possible only involves {cardinality} "
                              f"out of {n_true} rows.)")
-    if fast:
-        eps_start = 1 / N  # :614-615
+        if failed is not None:
+            raise failed
     return AuctionSolver(loc_long, val, problem=problem, eps_start=eps_start, max_iter=max_iter, **gpu_opts)
 
 

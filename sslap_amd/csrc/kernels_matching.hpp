@@ -23,7 +23,8 @@ namespace misslap {
 
 struct MatchArgs {
     const int *row_ptr;  // int32[N + 1]
-    const int *col;      // int32[nnz], adjacency of the rows in stored order
+    const int *col;      // adjacency of the rows in stored order: entry g at col[g * col_stride]
+    int col_stride;      // 1: a plain int32[nnz]; 2: the {col, val} pairs of a solver handle's 8 B/edge layout
     int *match_row;      // int32[N]: column matched to row u, -1 = free
     int *match_col;      // int32[M]: row matched to column v, -1 = free
     int *level;          // int32[N]: BFS layer of row u in this phase, -1 = not reached
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(256) void k_m_init(MatchArgs a) {
 __global__ __launch_bounds__(256) void k_m_greedy(MatchArgs a) {
     for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < a.n_rows; u += gridDim.x * blockDim.x) {
         for (int g = a.row_ptr[u]; g < a.row_ptr[u + 1]; ++g) {
-            const int v = a.col[g];
+            const int v = a.col[(size_t)g * a.col_stride];
             if (a.match_col[v] == -1 && atomicCAS(&a.match_col[v], -1, u) == -1) {
                 a.match_row[u] = v;
                 break;
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(256) void k_m_bfs_layer(MatchArgs a, int L) {
         if (a.level[u] != L) continue;  // wave-uniform
         const int r = a.root[u];
         for (int g = a.row_ptr[u] + lane; g < a.row_ptr[u + 1]; g += kWave) {
-            const int v = a.col[g];
+            const int v = a.col[(size_t)g * a.col_stride];
             if (a.pred_col[v] != -1 || atomicCAS(&a.pred_col[v], -1, u) != -1) continue;  // somebody's already
             const int w = a.match_col[v];
             if (w == -1) {  // a free column: the end of a shortest augmenting path of tree r (one per tree)

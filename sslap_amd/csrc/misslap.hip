@@ -917,6 +917,42 @@ MISSLAP_API int misslap_hopcroft_karp(const int32_t *loc, int64_t nnz, int32_t n
 }
 // The same guard on the GPU (kernels_matching.hpp): BFS-layered maximum matching; the cardinality equals the host
 // version's (and the reference's), the pairings are a maximum matching but not necessarily the same one.
+// Greedy start + phases of the GPU matcher (kernels_matching.hpp) on a CSR already in device memory; the matched-row
+// count is left in a.counters[2].
+static int run_matching_phases(hipStream_t st, const MatchArgs &a, int *nph_out) {
+    const int n_rows = a.n_rows, n_cols = a.n_cols;
+    const int gV = blocks_for(std::max(n_rows, n_cols), 256), gW = blocks_for(n_rows, 4);
+    hipLaunchKernelGGL(k_m_init, dim3(gV), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_m_greedy, dim3(gV), dim3(256), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    int nph = 0;
+    for (;;) {  // phases (:199-211)
+        HIP_TRY(hipMemsetAsync(a.counters, 0, 4 * sizeof(int), st));
+        hipLaunchKernelGGL(k_m_phase_init, dim3(gV), dim3(256), 0, st, a);
+        int cnt[4] = {0, 0, 0, 0};
+        bool augmented = false;
+        for (int L = 0; L <= n_rows; ++L) {
+            HIP_TRY(hipMemsetAsync(a.counters + 1, 0, sizeof(int), st));
+            hipLaunchKernelGGL(k_m_bfs_layer, dim3(gW), dim3(256), 0, st, a, L);
+            HIP_TRY(hipMemcpyAsync(cnt, a.counters, sizeof(cnt), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if (cnt[0] > 0) {  // this layer reached free columns: flip one shortest path per tree
+                hipLaunchKernelGGL(k_m_augment, dim3(blocks_for(n_rows, 256)), dim3(256), 0, st, a);
+                augmented = true;
+                break;
+            }
+            if (cnt[1] == 0) break;  // the layering is exhausted: no augmenting path is left
+        }
+        HIP_TRY(hipGetLastError());
+        if (!augmented) break;
+        ++nph;
+    }
+    HIP_TRY(hipMemsetAsync(a.counters + 2, 0, sizeof(int), st));
+    hipLaunchKernelGGL(k_m_count, dim3(blocks_for(n_rows, 256)), dim3(256), 0, st, a);
+    *nph_out = nph;
+    return MISSLAP_OK;
+}
+
 MISSLAP_API int misslap_matching_gpu(const int32_t *loc, int64_t nnz, int32_t n_rows, int32_t n_cols, int32_t device,
                                      int32_t *size, int32_t *left_pairings, int32_t *right_pairings, int32_t *phases) {
     if (!size || nnz < 0 || n_rows < 0 || n_cols < 0 || (nnz > 0 && !loc)) return fail(MISSLAP_ERR_INVALID, "bad argument");
@@ -958,38 +994,14 @@ MISSLAP_API int misslap_matching_gpu(const int32_t *loc, int64_t nnz, int32_t n_
     if ((rc = tmp.alloc(&d_err, 1))) return rc;
     a.row_ptr = row_ptr;
     a.col = col;
+    a.col_stride = 1;
     hipStream_t st = nullptr;  // the default stream: this entry point is synchronous
     HIP_TRY(hipMemcpyAsync(d_loc, loc, sizeof(int) * 2 * (size_t)nnz, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(d_err, 0, sizeof(int), st));
-    const int gE = blocks_for(nnz, 256 * 4), gV = blocks_for(std::max(n_rows, n_cols), 256), gW = blocks_for(n_rows, 4);
+    const int gE = blocks_for(nnz, 256 * 4);
     hipLaunchKernelGGL(k_m_row_ptr, dim3(gE), dim3(256), 0, st, d_loc, (long long)nnz, n_rows, row_ptr, col, d_err);
-    hipLaunchKernelGGL(k_m_init, dim3(gV), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(k_m_greedy, dim3(gV), dim3(256), 0, st, a);
-    HIP_TRY(hipGetLastError());
     int nph = 0;
-    for (;;) {  // phases (:199-211)
-        HIP_TRY(hipMemsetAsync(a.counters, 0, 4 * sizeof(int), st));
-        hipLaunchKernelGGL(k_m_phase_init, dim3(gV), dim3(256), 0, st, a);
-        int cnt[4] = {0, 0, 0, 0};
-        bool augmented = false;
-        for (int L = 0; L <= n_rows; ++L) {
-            HIP_TRY(hipMemsetAsync(a.counters + 1, 0, sizeof(int), st));
-            hipLaunchKernelGGL(k_m_bfs_layer, dim3(gW), dim3(256), 0, st, a, L);
-            HIP_TRY(hipMemcpyAsync(cnt, a.counters, sizeof(cnt), hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            if (cnt[0] > 0) {  // this layer reached free columns: flip one shortest path per tree
-                hipLaunchKernelGGL(k_m_augment, dim3(blocks_for(n_rows, 256)), dim3(256), 0, st, a);
-                augmented = true;
-                break;
-            }
-            if (cnt[1] == 0) break;  // the layering is exhausted: no augmenting path is left
-        }
-        HIP_TRY(hipGetLastError());
-        if (!augmented) break;
-        ++nph;
-    }
-    HIP_TRY(hipMemsetAsync(a.counters + 2, 0, sizeof(int), st));
-    hipLaunchKernelGGL(k_m_count, dim3(blocks_for(n_rows, 256)), dim3(256), 0, st, a);
+    if ((rc = run_matching_phases(st, a, &nph))) return rc;
     int out[4] = {0, 0, 0, 0}, err = 0;
     HIP_TRY(hipMemcpyAsync(out, a.counters, sizeof(out), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(&err, d_err, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -997,6 +1009,42 @@ MISSLAP_API int misslap_matching_gpu(const int32_t *loc, int64_t nnz, int32_t n_
     if (right_pairings) HIP_TRY(hipMemcpyAsync(right_pairings, a.match_col, sizeof(int) * (size_t)n_cols, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (err) return fail(MISSLAP_ERR_INVALID, "loc rows must be sorted in ascending order");
+    *size = out[2];
+    if (phases) *phases = nph;
+    return MISSLAP_OK;
+}
+
+// The same matcher on the graph a solver handle already holds in device memory (its CSR): no host copy of the
+// entries, no second upload -- what the front-end's feasibility guard uses after it has created the handle.
+MISSLAP_API int misslap_matching_of(misslap_solver *h, int32_t *size, int32_t *phases) {
+    if (!h || !size) return fail(MISSLAP_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    DevScratch tmp;
+    int rc;
+    MatchArgs a{};
+    a.n_rows = h->n_rows;
+    a.n_cols = h->n_cols;
+    a.row_ptr = h->row_ptr;
+    a.col = h->f32 ? reinterpret_cast<const int *>(h->edges32) : h->col;
+    a.col_stride = h->f32 ? 2 : 1;
+    {
+        DevBlock blk;
+        blk.want(&a.match_row, (size_t)h->n_rows);
+        blk.want(&a.match_col, (size_t)h->n_cols);
+        blk.want(&a.level, (size_t)h->n_rows);
+        blk.want(&a.root, (size_t)h->n_rows);
+        blk.want(&a.pred_col, (size_t)h->n_cols);
+        blk.want(&a.end_of_root, (size_t)h->n_rows);
+        blk.want(&a.counters, 4);
+        tmp.ptrs.push_back(nullptr);
+        if ((rc = blk.commit(&tmp.ptrs.back()))) return rc;
+    }
+    hipStream_t st = h->stream;
+    int nph = 0;
+    if ((rc = run_matching_phases(st, a, &nph))) return rc;
+    int out[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(out, a.counters, sizeof(out), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     *size = out[2];
     if (phases) *phases = nph;
     return MISSLAP_OK;

@@ -150,3 +150,35 @@ def test_front_end_uses_gpu_matcher_for_large_graphs(gpu_lib, monkeypatch):
         from_sparse(loc, np.ones(loc.shape[0]), problem="max", cardinality_check=True)
     loc, val = synth.gen_sparse(300, 300, 0.05, seed=2)
     from_sparse(loc, val, problem="max", cardinality_check=True).solve()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(cases.MATCH_CASES))
+def test_matching_on_a_solver_handle_matches_reference(name, golden_matching, gpu_lib):
+    """misslap_matching_of: the matcher on the CSR a solver handle already holds in device memory (both edge layouts)
+    gives the reference's cardinality -- the guard of the front-end without a host copy of the entries."""
+    from sslap_amd.auction_solve import AuctionSolver
+    manifest, arrays = golden_matching
+    spec, _entry = cases.MATCH_CASES[name]
+    loc = cases.matching_graph(spec)
+    rows = np.unique(loc[:, 0])
+    if rows.shape[0] != int(loc[:, 0].max()) + 1:
+        pytest.skip("a row without entries: no solver handle exists for such input")
+    want = manifest["cases"][name]["size"]
+    for f64 in (False, True):
+        s = AuctionSolver(loc.astype(np.int32), np.ones(loc.shape[0]), problem="max", force_f64=f64)
+        assert s.matching_cardinality() == want, (name, f64)
+
+
+@pytest.mark.gpu
+def test_dense_front_end_guard_runs_on_the_handle(gpu_lib):
+    """from_matrix(cardinality_check=True): feasible matrices pass, a matrix whose rows share too few valid columns
+    raises the reference's text (auction_.pyx:566) -- the matching runs on the handle's device-resident CSR."""
+    from sslap_amd import from_matrix
+    r = np.random.default_rng(3)
+    mat = r.random((300, 300)) * 10
+    from_matrix(mat, problem="max", cardinality_check=True).solve()
+    bad = np.full((60, 80), -1.0)
+    bad[:, :25] = r.random((60, 25))  # 60 rows compete for 25 columns
+    with pytest.raises(ValueError, match=r"Maximum matching possible only involves 25 out of 60 rows"):
+        from_matrix(bad, problem="max", cardinality_check=True)
