@@ -127,6 +127,15 @@ struct ProfRec {
 
 }  // namespace
 
+namespace {
+struct Blk {  // a device block and its size (the size it is returned to the block cache with)
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+int block_alloc(void **p, size_t bytes, size_t *got);
+void block_free(int device, void *p, size_t bytes);
+}  // namespace
+
 struct misslap_solver {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -165,7 +174,7 @@ struct misslap_solver {
     bool tiled_ok = false;
     int tiled_min_K = 0;
     int tiled_shape = 0;  // index into kShapes of launch_bid_tiled
-    std::vector<void *> blocks;  // device memory of the arrays above (DevBlock), released as a whole
+    std::vector<Blk> blocks;  // device memory of the arrays above (DevBlock), released as a whole
     Ctl *h_ctl = nullptr;  // pinned mirror
     Ctl *h_stat = nullptr;  // pinned [2]: status copies that trail the grid rounds by one batch (status_enqueue)
     hipEvent_t stat_ev[2] = {nullptr, nullptr};
@@ -192,6 +201,7 @@ struct misslap_solver {
     bool profile = false;
     int K_ub = 0;  // host-side upper bound of K (K never grows inside a phase)
     bool K_exact = false;  // K_ub was read from the device and no round has been enqueued since
+    bool ctl_fresh = false;  // the pinned mirror h_ctl equals the device's control block (nothing enqueued since the read)
     bool phase_fresh = true;  // no round of the current eps-phase has been enqueued yet
     std::vector<ProfRec> prof;
     size_t prof_used = 0;
@@ -209,18 +219,22 @@ int dev_alloc(T **p, size_t n) {
 
 // Device temporaries of a constructor: freed when the scope is left, on every path.
 struct DevScratch {
-    std::vector<void *> ptrs;
-    DevScratch() = default;
+    std::vector<Blk> blks;
+    int device = 0;
+    DevScratch() { (void)hipGetDevice(&device); }
     DevScratch(const DevScratch &) = delete;
     DevScratch &operator=(const DevScratch &) = delete;
     ~DevScratch() {
-        for (void *p : ptrs)
-            if (p) (void)hipFree(p);
+        for (const Blk &b : blks) block_free(device, b.p, b.bytes);
     }
     template <class T>
     int alloc(T **p, size_t n) {
-        const int rc = dev_alloc(p, n);
-        if (rc == MISSLAP_OK) ptrs.push_back(*p);
+        Blk b;
+        const int rc = block_alloc(&b.p, (n ? n : 1) * sizeof(T), &b.bytes);
+        if (rc == MISSLAP_OK) {
+            *p = static_cast<T *>(b.p);
+            blks.push_back(b);
+        }
         return rc;
     }
 };
@@ -239,12 +253,12 @@ struct DevBlock {
     void want(T **p, size_t n) {
         items.push_back({reinterpret_cast<void **>(p), (n ? n : 1) * sizeof(T)});
     }
-    int commit(void **base_out) {
+    int commit(Blk *out) {
         size_t total = 0;
         for (const Item &it : items) total += (it.bytes + 255) & ~(size_t)255;
-        char *base = nullptr;
-        HIP_TRY(hipMalloc((void **)&base, total ? total : 256));
-        *base_out = base;
+        const int rc = block_alloc(&out->p, total ? total : 256, &out->bytes);
+        if (rc) return rc;
+        char *base = static_cast<char *>(out->p);
         size_t off = 0;
         for (const Item &it : items) {
             *it.target = base + off;
@@ -255,32 +269,92 @@ struct DevBlock {
     }
 };
 
-// Streams are kept across handles: creating one (a hardware queue) takes several milliseconds, more than everything
-// else a handle's setup does.  A destroyed handle parks its idle stream here; the next handle on that device takes it.
-struct StreamPool {
+// Host-side resources are kept across handles: creating a stream (a hardware queue) takes several milliseconds -- more
+// than everything else a handle's setup does --, the pinned mirror of the control block and the two status events
+// another tenth of a millisecond.  A destroyed handle parks its idle bundle here; the next handle on that device takes it.
+struct HostRes {
+    hipStream_t stream = nullptr;
+    Ctl *h_ctl = nullptr;  // pinned, 3 blocks: the mirror and the two trailing status copies
+    hipEvent_t ev[2] = {nullptr, nullptr};
+};
+struct HostResPool {
     std::mutex m;
-    std::vector<std::pair<int, hipStream_t>> idle;
+    std::vector<std::pair<int, HostRes>> idle;
     static constexpr size_t kMaxIdle = 8;
-    hipStream_t take(int device) {
+    bool take(int device, HostRes *out) {
         std::lock_guard<std::mutex> g(m);
         for (size_t k = 0; k < idle.size(); ++k)
             if (idle[k].first == device) {
-                hipStream_t s = idle[k].second;
+                *out = idle[k].second;
                 idle.erase(idle.begin() + (long)k);
-                return s;
+                return true;
             }
-        return nullptr;
+        return false;
     }
-    bool park(int device, hipStream_t s) {
+    bool park(int device, const HostRes &r) {
         std::lock_guard<std::mutex> g(m);
         if (idle.size() >= kMaxIdle) return false;
-        idle.emplace_back(device, s);
+        idle.emplace_back(device, r);
         return true;
     }
 };
-StreamPool &stream_pool() {
-    static StreamPool *pool = new StreamPool();  // never destroyed: the HIP runtime may be gone at static teardown
+HostResPool &host_pool() {
+    static HostResPool *pool = new HostResPool();  // never destroyed: the HIP runtime may be gone at static teardown
     return *pool;
+}
+
+// ... and so are small device blocks: hipMalloc + hipFree of a handle's four blocks cost a quarter of a millisecond,
+// which is what a 20 x 20 problem takes to SOLVE.  Freed blocks of at most kMaxEach bytes wait here (at most
+// kMaxEntries, kMaxHeld bytes in total) for a request they fit within a factor of two.
+struct BlockCache {
+    struct Ent {
+        int device;
+        size_t bytes;
+        void *p;
+    };
+    std::mutex m;
+    std::vector<Ent> idle;
+    size_t held = 0;
+    static constexpr size_t kMaxEntries = 16, kMaxEach = (size_t)32 << 20, kMaxHeld = (size_t)256 << 20;
+    void *take(int device, size_t bytes, size_t *got) {
+        std::lock_guard<std::mutex> g(m);
+        size_t best = idle.size();
+        for (size_t k = 0; k < idle.size(); ++k)
+            if (idle[k].device == device && idle[k].bytes >= bytes && idle[k].bytes <= 2 * bytes + 4096 &&
+                (best == idle.size() || idle[k].bytes < idle[best].bytes))
+                best = k;
+        if (best == idle.size()) return nullptr;
+        void *p = idle[best].p;
+        *got = idle[best].bytes;
+        held -= idle[best].bytes;
+        idle.erase(idle.begin() + (long)best);
+        return p;
+    }
+    bool give(int device, void *p, size_t bytes) {
+        if (bytes == 0 || bytes > kMaxEach) return false;
+        std::lock_guard<std::mutex> g(m);
+        if (idle.size() >= kMaxEntries || held + bytes > kMaxHeld) return false;
+        idle.push_back({device, bytes, p});
+        held += bytes;
+        return true;
+    }
+};
+BlockCache &block_cache() {
+    static BlockCache *c = new BlockCache();
+    return *c;
+}
+// a device block of at least `bytes` on the current device, from the cache if one fits; *got = its real size
+int block_alloc(void **p, size_t bytes, size_t *got) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    *p = block_cache().take(dev, bytes, got);
+    if (*p) return MISSLAP_OK;
+    HIP_TRY(hipMalloc(p, bytes));
+    *got = bytes;
+    return MISSLAP_OK;
+}
+void block_free(int device, void *p, size_t bytes) {
+    if (p && !block_cache().give(device, p, bytes)) (void)hipFree(p);
 }
 
 RoundArgs round_args(misslap_solver *h) {
@@ -337,9 +411,18 @@ ProfRec *prof_next(misslap_solver *h, int kind) {
     return r;
 }
 
+// (A status read is a stream drain: ~20 us.  A solve of a small problem is a few hundred rounds of ~1 us inside one
+// tail launch per eps-phase and was spending most of its time in the five reads per phase; with the mirror reused
+// while nothing has been enqueued since the last read, two remain.)
 int read_ctl(misslap_solver *h) {
+    if (h->ctl_fresh) {
+        if (h->h_ctl->err)
+            return fail(MISSLAP_ERR_STATE, "device-side invariant violated (error bits 0x%x)", h->h_ctl->err);
+        return MISSLAP_OK;
+    }
     HIP_TRY(hipMemcpyAsync(h->h_ctl, h->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    h->ctl_fresh = true;
     h->K_ub = h->h_ctl->K;
     h->K_exact = true;
     if (h->h_ctl->err)
@@ -352,6 +435,7 @@ int read_ctl(misslap_solver *h) {
 // is still an upper bound for the launch grids, and every round kernel is a no-op once the round is not live: a
 // batch enqueued on a stale "go on" costs its launches and nothing else.
 int status_enqueue(misslap_solver *h, int slot) {
+    h->ctl_fresh = false;
     HIP_TRY(hipMemcpyAsync(&h->h_stat[slot], h->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipEventRecord(h->stat_ev[slot], h->stream));
     return MISSLAP_OK;
@@ -366,6 +450,7 @@ int status_wait(misslap_solver *h, int slot) {
 }
 
 int launch_bid_tiled(misslap_solver *h) {
+    h->ctl_fresh = false;
     RoundArgs a = round_args(h);
     // K_ub is only an upper bound unless the host has just read K: the device decides sharded / replicated from
     // the exact K, so the smaller sharded grid is used only when the host knows the same K
@@ -425,6 +510,7 @@ bool use_round_small(const misslap_solver *h) {
 }
 
 int launch_bid(misslap_solver *h) {
+    h->ctl_fresh = false;
     // (not behind a full-scan engine launch: the engines always feed best_key, which k_round_small ignores)
     h->round_small = use_round_small(h) && !(h->tiled_ok && h->K_ub >= h->tiled_min_K);
     if (h->tiled_ok && h->K_ub >= h->tiled_min_K) {
@@ -476,6 +562,7 @@ int launch_bid(misslap_solver *h) {
 }
 
 int launch_tiebreak(misslap_solver *h) {
+    h->ctl_fresh = false;
     if (h->round_small) return MISSLAP_OK;  // k_round_small (launch_apply) resolves the ties itself
     RoundArgs a = round_args(h);
     const long long share = h->K_ub;
@@ -486,6 +573,7 @@ int launch_tiebreak(misslap_solver *h) {
 }
 
 int launch_apply(misslap_solver *h) {
+    h->ctl_fresh = false;
     RoundArgs a = round_args(h);
     if (h->round_small) {
         h->round_small = false;
@@ -512,6 +600,7 @@ int launch_apply(misslap_solver *h) {
 
 int launch_tail(misslap_solver *h) {
     if (h->thr <= 0) return MISSLAP_OK;
+    h->ctl_fresh = false;
     if (h->long_rows_later && h->h_ctl->tail_rounds >= kLongRowsAfterTailRounds) {  // (status read just before)
         h->long_rows = true;
         h->long_rows_later = false;
@@ -579,6 +668,7 @@ int run_ece(misslap_solver *h, float eps, int *ok) {
         *ok = 0;
         return MISSLAP_OK;
     }
+    h->ctl_fresh = false;
     HIP_TRY(hipMemsetAsync(&h->ctl->ece_fail, 0, sizeof(int), h->stream));
     const int grid = blocks_for(h->n_rows, 4);
     if (h->f32) {
@@ -601,17 +691,23 @@ void free_all(misslap_solver *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    if (h->row_ptr) (void)hipFree(h->row_ptr);
-    for (void *p : h->blocks)
-        if (p) (void)hipFree(p);
-    if (h->h_ctl) (void)hipHostFree(h->h_ctl);
-    for (hipEvent_t e : h->stat_ev)
-        if (e) (void)hipEventDestroy(e);
+    for (const Blk &b : h->blocks) block_free(h->device, b.p, b.bytes);
     for (auto &r : h->prof) {
         (void)hipEventDestroy(r.start);
         (void)hipEventDestroy(r.stop);
     }
-    if (h->own_stream && h->stream && !stream_pool().park(h->device, h->stream)) (void)hipStreamDestroy(h->stream);
+    HostRes res;
+    res.stream = h->own_stream ? h->stream : nullptr;
+    res.h_ctl = h->h_ctl;
+    res.ev[0] = h->stat_ev[0];
+    res.ev[1] = h->stat_ev[1];
+    const bool whole = res.stream && res.h_ctl && res.ev[0] && res.ev[1];
+    if (!whole || !host_pool().park(h->device, res)) {
+        if (res.h_ctl) (void)hipHostFree(res.h_ctl);
+        for (hipEvent_t e : res.ev)
+            if (e) (void)hipEventDestroy(e);
+        if (res.stream) (void)hipStreamDestroy(res.stream);
+    }
     delete h;
 }
 
@@ -631,7 +727,12 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
         HIP_TRY(hipMemcpyAsync(&d_st->max_col, &init, sizeof(int), hipMemcpyHostToDevice, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));  // `init` lives on this stack frame
     }
-    if ((rc = dev_alloc(&h->row_ptr, (size_t)h->n_rows + 1))) return rc;
+    {
+        DevBlock blk;
+        blk.want(&h->row_ptr, (size_t)h->n_rows + 1);
+        h->blocks.emplace_back();
+        if ((rc = blk.commit(&h->blocks.back()))) return rc;
+    }
     const int grid = blocks_for(nnz, 256 * 8);
     hipLaunchKernelGGL(k_ingest_rows, dim3(grid), dim3(256), 0, h->stream, d_loc, (long long)nnz, h->n_rows,
                        h->row_ptr, d_st);
@@ -665,8 +766,10 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
     }
     const int flip = h->maximize ? 0 : 1;
     if (h->f32) {
-        if ((rc = dev_alloc(&h->edges32, (size_t)nnz + 4 * kWave))) return rc;  // tail kernel reads up to 256 past a row start
-        h->blocks.push_back(h->edges32);
+        DevBlock blk;
+        blk.want(&h->edges32, (size_t)nnz + 4 * kWave);  // the tail kernel reads up to 256 entries past a row start
+        h->blocks.emplace_back();
+        if ((rc = blk.commit(&h->blocks.back()))) return rc;
         HIP_TRY(hipMemsetAsync(h->edges32 + nnz, 0, sizeof(int2) * 4 * kWave, h->stream));
         hipLaunchKernelGGL(k_build_edges_f32, dim3(grid), dim3(256), 0, h->stream, d_loc, d_val, (long long)nnz,
                            flip, h->edges32);
@@ -674,7 +777,7 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
         DevBlock blk;
         blk.want(&h->col, (size_t)nnz + 4 * kWave);
         blk.want(&h->val64, (size_t)nnz + 4 * kWave);
-        h->blocks.push_back(nullptr);
+        h->blocks.emplace_back();
         if ((rc = blk.commit(&h->blocks.back()))) return rc;
         HIP_TRY(hipMemsetAsync(h->col + nnz, 0, sizeof(int) * 4 * kWave, h->stream));
         HIP_TRY(hipMemsetAsync(h->val64 + nnz, 0, sizeof(double) * 4 * kWave, h->stream));
@@ -716,8 +819,8 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
                 blk.want(&start, (size_t)L + 1);
                 blk.want(&sums, (size_t)nchunks + 1);
                 blk.want(&flag, 1);
-                tmp.ptrs.push_back(nullptr);
-                if ((rc = blk.commit(&tmp.ptrs.back()))) return rc;
+                tmp.blks.emplace_back();
+                if ((rc = blk.commit(&tmp.blks.back()))) return rc;
             }
             HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)L, h->stream));
             HIP_TRY(hipMemsetAsync(len, 0, sizeof(int) * (size_t)L, h->stream));
@@ -738,7 +841,7 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
                     blk.want(&h->tiled, (size_t)total + 16);
                     blk.want(&h->seg4, (size_t)L + 2);
                     blk.want(&h->tcol, (size_t)total + 16);
-                    h->blocks.push_back(nullptr);
+                    h->blocks.emplace_back();
                     if ((rc = blk.commit(&h->blocks.back()))) return rc;
                 }
                 HIP_TRY(hipMemsetAsync(h->tiled, 0, sizeof(int2) * ((size_t)total + 16), h->stream));
@@ -801,16 +904,17 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
             h->launch_edges_cap = 1 << 20;
             blk.want(&h->launch_edges, (size_t)h->launch_edges_cap);
         }
-        h->blocks.push_back(nullptr);
+        h->blocks.emplace_back();
         if ((rc = blk.commit(&h->blocks.back()))) return rc;
     }
     HIP_TRY(hipMemsetAsync(h->price, 0, sizeof(double) * Mpad, h->stream));
     HIP_TRY(hipMemsetAsync(h->bid_rec, 0, sizeof(int4) * kRoundSmallMax, h->stream));
     if (h->profile)
         HIP_TRY(hipMemsetAsync(h->launch_edges, 0, sizeof(unsigned long long) * h->launch_edges_cap, h->stream));
-    HIP_TRY(hipHostMalloc((void **)&h->h_ctl, 3 * sizeof(Ctl)));  // the mirror and the two trailing status copies
+    if (!h->h_ctl) HIP_TRY(hipHostMalloc((void **)&h->h_ctl, 3 * sizeof(Ctl)));  // the mirror and the two trailing status copies
     h->h_stat = h->h_ctl + 1;
-    for (hipEvent_t &e : h->stat_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (hipEvent_t &e : h->stat_ev)
+        if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     h->shard_min_K = h->tiled_ok ? h->tiled_min_K : (int)std::max<size_t>((N * 3) / 10, 8192);
     if (opt->reserved[3] > 0) h->shard_min_K = opt->reserved[3];
     if (opt->reserved[3] < 0) h->shard_min_K = 0;  // every grid round sharded + exchanged
@@ -879,7 +983,13 @@ int new_handle(misslap_solver **out, const misslap_options *opt, misslap_solver 
     h->rank = opt->shard_world > 0 ? opt->shard_rank : 0;
     h->profile = opt->profile != 0;
     h->profile_all = opt->profile >= 2;
-    h->stream = stream_pool().take(h->device);
+    HostRes res;
+    if (host_pool().take(h->device, &res)) {
+        h->stream = res.stream;
+        h->h_ctl = res.h_ctl;
+        h->stat_ev[0] = res.ev[0];
+        h->stat_ev[1] = res.ev[1];
+    }
     if (!h->stream && hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;
         return fail(MISSLAP_ERR_HIP, "hipStreamCreate failed");
@@ -1036,8 +1146,8 @@ MISSLAP_API int misslap_matching_of(misslap_solver *h, int32_t *size, int32_t *p
         blk.want(&a.pred_col, (size_t)h->n_cols);
         blk.want(&a.end_of_root, (size_t)h->n_rows);
         blk.want(&a.counters, 4);
-        tmp.ptrs.push_back(nullptr);
-        if ((rc = blk.commit(&tmp.ptrs.back()))) return rc;
+        tmp.blks.emplace_back();
+        if ((rc = blk.commit(&tmp.blks.back()))) return rc;
     }
     hipStream_t st = h->stream;
     int nph = 0;
@@ -1275,7 +1385,10 @@ MISSLAP_API int misslap_phase_end(misslap_solver *h, int32_t *finished) {
             HIP_TRY(hipGetLastError());
             h->nreductions += 1;  // :292
             h->K_ub = h->n_rows;
-            h->K_exact = true;  // k_reset_phase sets K = n_rows
+            h->K_exact = true;  // k_reset_phase sets K = n_rows ...
+            h->h_ctl->K = h->n_rows;  // ... and nothing else the mirror holds: it stays current (ctl_fresh)
+            h->h_ctl->nholes = 0;
+            h->h_ctl->nleft = 0;
             h->phase_fresh = true;
         }
     }
@@ -1289,6 +1402,7 @@ MISSLAP_API int misslap_finish(misslap_solver *h, int32_t *person_to_object_out,
     int rc;
     int ece = 0;
     if ((rc = run_ece(h, h->target_eps, &ece))) return rc;  // :297 / :300
+    h->ctl_fresh = false;  // (the objective kernels below write the control block)
     // objective (:302, :489-523)
     HIP_TRY(hipMemsetAsync(&h->ctl->dup_rows, 0, sizeof(int), h->stream));
     hipLaunchKernelGGL(k_obj_reset, dim3(1), dim3(1), 0, h->stream, h->ctl);
