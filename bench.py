@@ -11,10 +11,13 @@ Contract (one JSON line on rank 0):
   cpu_baseline = the C oracle (oracle/, a port of the reference's algorithm) on a bounded sample of the
              same workload, one host core, rank 0, N = 1 only.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3] [--no-cpu] [--pmc-steps]
-For N > 1 launch with torch.distributed.run (one rank per GPU); persons of each round are sharded over
-the ranks, with RCCL all-reduces on the per-object best bids issued by the library itself
-(misslap_solve_sharded, include/misslap.h; sslap_amd/dist.py only creates the communicator).
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3] [--no-cpu] [--mode sharded|replicas]
+N > 1: one rank per GPU.  Under torch.distributed.run (RANK / WORLD_SIZE in the environment) this process IS a rank;
+without a launcher `python bench.py --gpus N` starts the N ranks itself -- fresh child processes, spawned before this
+process has imported torch or touched the GPU; the parent only relays rank 0's JSON line.  Mode 'sharded': persons of
+each big round sharded over the ranks, RCCL all-reduces on the per-object best bids issued by the library itself
+(misslap_solve_sharded, include/misslap.h; sslap_amd/dist.py only creates the communicator); mode 'replicas': one
+independent solve per GPU, no collective.
 """
 import argparse
 import json
@@ -68,6 +71,71 @@ def cpu_baseline(cfg, budget_rounds, whole):
     return out
 
 
+def launch_ranks(n, argv):
+    """`--gpus N` without a launcher: start the N ranks as fresh child processes of this script (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1), relay rank 0's stdout, exit with the worst return code.
+    Nothing here imports torch or calls into HIP: a process that has initialised the GPU must never be replaced or
+    forked, and the children must be the first to open the device."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    if os.environ.get("MISSLAP_BENCH_TRACE"):
+        print(f"bench.py parent: spawning {n} ranks, torch_imported_in_parent={'torch' in sys.modules}", file=sys.stderr)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    deadline = time.time() + float(os.environ.get("MISSLAP_BENCH_TIMEOUT_S", 3000))
+    out = b""
+    try:
+        while True:
+            rcs = [p.poll() for p in procs]
+            if all(rc is not None for rc in rcs):
+                break
+            if any(rc not in (None, 0) for rc in rcs) or time.time() > deadline:
+                for p in procs:  # one rank failed (or the run hangs): the others would wait in a collective for ever
+                    if p.poll() is None:
+                        p.kill()
+                break
+            try:
+                out += procs[0].communicate(timeout=1.0)[0] or b""
+            except subprocess.TimeoutExpired:
+                pass
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    rest = procs[0].stdout.read() if procs[0].stdout and not procs[0].stdout.closed else b""
+    sys.stdout.write((out + (rest or b"")).decode())
+    sys.stdout.flush()
+    rcs = [p.wait() for p in procs]
+    raise SystemExit(0 if all(rc == 0 for rc in rcs) else next(rc for rc in rcs if rc != 0) or 1)
+
+
+def measured_copy_peak(torch):
+    """Device copy rate of THIS GPU in THIS process (read + write bytes of a 1 GiB fp32 copy per second): the
+    'achievable' HBM rate next to the 8 TB/s of the data sheet (report both)."""
+    n = 1 << 28
+    a = torch.empty(n, dtype=torch.float32, device="cuda").normal_()
+    b = torch.empty_like(a)
+    for _ in range(3):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 20
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    del a, b
+    return 2 * n * 4 / (ms * 1e-3) / 1e9
+
+
 def source_digest():
     """sha256 over the kernel sources the library is built from: ties a committed PMC measurement to the code it was
     taken on (the GPU box has no .git, so a commit hash alone could not be checked there)."""
@@ -111,6 +179,9 @@ def main():
                          "exchange (strong scaling; the default); 'replicas' = N independent problems, one per GPU, "
                          "no collective (weak scaling: how independent LAPs -- the reference's typical use -- scale)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args.gpus, sys.argv[1:])  # does not return
 
     import numpy as np
     import torch
@@ -238,7 +309,9 @@ def main():
         # this same command, summarised by tools/pmc_summary.py with the gfx950 corrections).  The file names the
         # kernel sources (sha256) and the commit it was measured on: any other code gets null, not a stale number.
         traffic, traffic_meta = None, {}
-        tpath = os.path.join(ROOT, "profiles", f"r02_pmc_traffic_{args.config}.json")
+        tpath = os.path.join(ROOT, "profiles", f"r03_pmc_traffic_{args.config}.json")
+        if not os.path.exists(tpath):
+            tpath = os.path.join(ROOT, "profiles", f"r02_pmc_traffic_{args.config}.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             traffic_meta = dict(traffic_commit=tj.get("commit"), traffic_source_sha256=tj.get("source_sha256"),
@@ -267,6 +340,22 @@ def main():
                         "edges_read": e3 - (g3["cand_edges"] - gpu_tail_cand_edges(g3)),
                         "note": "one extra untimed solve, every bid launch timed (profile 3); edges = reference-"
                                 "equivalent row lengths of the bidders, edges_read = rows actually streamed"}
+        # SURVEY 8(d), second solve figure: one more (untimed) step from HOST arrays -- the reference's `setup` timer
+        # brackets the CSR build from host arrays (auction_.pyx:206-207, :265), here that includes the H2D copy of the
+        # COO input (16 B per entry, pageable numpy memory)
+        incl_h2d = None
+        if world == 1 and args.config != "C5":
+            loc_h, val_h = synth.gen_config(args.config)
+            t_h = time.perf_counter()
+            sh = AuctionSolver(loc_h, val_h, problem="max", max_iter=10**8, device=local_rank)
+            sh.solve()
+            wall_h = 1e3 * (time.perf_counter() - t_h)
+            incl_h2d = {"solve_ms_incl_h2d": round(sh.gpu["setup_ms"] + sh.gpu["solve_ms"], 3),
+                        "setup_ms_incl_h2d": round(sh.gpu["setup_ms"], 3), "wall_ms": round(wall_h, 3),
+                        "h2d_bytes": int(loc_h.nbytes + val_h.nbytes),
+                        "note": "create from host numpy arrays (H2D of the COO input + CSR build) + solve; never part of `value`"}
+            del sh, loc_h, val_h
+        copy_peak = measured_copy_peak(torch)
         out = {
             "metric": "Medges/s (bid-phase CSR nnz/s) + solve ms, N=200k d=0.1% sparse LAP",
             "value": round(edges_all / dt / 1e6, 2),
@@ -287,6 +376,7 @@ def main():
                        "bytes_per_edge": bpe, "generator": "sslap_amd.synth seed=1"},
             "solve_ms": round(sum(g["solve_ms"] for _, g in runs) / len(runs), 3),
             "setup_ms": round(sum(g["setup_ms"] for _, g in runs) / len(runs), 3),
+            "solve_incl_h2d": incl_h2d,
             "rounds": meta["its"], "eps_phases": meta["nreductions"] + 1,
             "grid_rounds": gpu["grid_rounds"], "tail_rounds": gpu["tail_rounds"],
             "edges_scanned_per_solve": gpu["edges_scanned"],
@@ -295,6 +385,7 @@ def main():
             "edges_read_per_solve": gpu["edges_scanned"] - gpu["cand_edges"],
             "candidate_line_hit_rate": round(gpu["cand_hits"] / max(gpu["bids_made"], 1), 4),
             "sol_sha256": synth.sol_digest(sol), "obj_f64": gpu["obj_f64"],
+            "complete_assignment": list(gpu["complete_assignment"]), "valid_assignment": gpu["valid_assignment"],
             "bid_phase": {
                 "full_scan_kernel": rk_name,
                 "fullscan_launches": fs_launches, "fullscan_avg_us": round(1e3 * fs_ms / max(fs_launches, 1), 2),
@@ -323,6 +414,10 @@ def main():
                 "launches": rk_launches, "avg_launch_us": round(1e3 * rk_ms / max(rk_launches, 1), 3),
                 "algorithmic_bytes_per_edge": bpe,
                 "algorithmic_bytes_per_launch": round(rk_edges * bpe / max(rk_launches, 1)),
+                # the same achieved rate against what a device copy reaches on this GPU in this process
+                "peak_measured_copy": round(copy_peak, 1), "frac_of_measured": round(achieved / copy_peak, 5),
+                "fullscan_frac_of_measured": round(fs_achieved / copy_peak, 5),
+                "timing": "HIP events handed to the launch (hipExtLaunchKernel): begin / end of the kernel itself",
                 "traffic": traffic,
                 "traffic_source": "rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction calibrated on known-size "
                                   "kernels + WRITE_SIZE), bytes per launch" if traffic else None,

@@ -22,7 +22,15 @@
 extern "C" {
 #endif
 
-#define MISSLAP_ABI_VERSION 1
+#define MISSLAP_ABI_VERSION 2
+/* ABI history.
+ *   1  (rounds 1-2) misslap_options = 88 bytes: the tuning knobs travelled in `reserved[8]`; misslap_meta had no size
+ *      field.  Still ACCEPTED: a caller that passes struct_size == 88 to misslap_create* is served with the version-1
+ *      meaning of reserved[] and receives the version-1 misslap_meta layout (376 bytes) from misslap_solve /
+ *      misslap_finish / misslap_solve_sharded on that handle (INTEGRATION.md section 5 lists both layouts).
+ *   2  the knobs are named fields, misslap_meta starts with `struct_size` (the library writes min(struct_size,
+ *      sizeof) bytes: a caller built against a shorter version-2 header keeps working when fields are appended),
+ *      validity flags of the assignment, misslap_trim_caches. */
 
 #define MISSLAP_OK 0
 #define MISSLAP_ERR_INVALID 1    /* malformed arguments / input contract violated */
@@ -49,27 +57,31 @@ typedef struct misslap_options {
     int32_t shard_rank;      /* multi-GPU: this process bids for U positions of its shard only */
     int32_t shard_world;     /* number of shards (1 = single GPU) */
     int32_t rounds_per_sync; /* grid rounds enqueued between host status reads; <= 0 = default */
-    int32_t reserved[8];     /* [0]: LDS-tiled bid kernel: 0 = default threshold, < 0 = never, > 0 = minimum K;
-                                [1]: launch shape of k_bid_tiled: 0 = chosen by the library from the average segment
-                                     length, k + 1 = shape k of misslap.hip:kTiledShapes (tuning knob);
-                                [2]: != 0 together with [0] > 0: build the tile-major copy whatever the size and
-                                     density of the problem (tests);
-                                [3]: multi-GPU shard threshold: 0 = default (the full-scan threshold, 0.3 N), > 0 = minimum K
-                                     of a sharded round, < 0 = shard every grid round;
-                                [4]: 1 = no candidate lines (every bid scans its whole row; A/B timing, parity tests);
-                                     2 = lines, but no maintenance pass ahead of the tail kernels (k_refresh_lines);
-                                [5]: 1 = partial rounds of the full-scan engine take their bidders in list order instead of
-                                     person order (A/B timing, parity tests);
-                                [7]: candidate-line tuning: bits 0..23 > 0 = k_bid (re)builds lines only in rounds with at
-                                     most so many bidders (default: all its rounds); bits 24..29 = r + 1: a line hit with
-                                     fewer than r live candidates is rebuilt (0 = library default, 1 = never);
-                                [6]: > 0 lowers the entry limit of a handle (default 2^31 - 1: int32 row pointers), for
-                                     tests of that guard */
+    /* ---- tuning knobs (all 0 = library default; none of them changes a single bit of the result) ---- */
+    int32_t tiled_min_K;     /* LDS-tiled full-scan bid kernel: 0 = default threshold (0.3 N), < 0 = never, > 0 = minimum K */
+    int32_t tiled_shape;     /* its launch shape: 0 = chosen from the average (person, tile) segment length, k + 1 =
+                                shape k of misslap.hip:kTiledShapes */
+    int32_t tiled_force;     /* != 0 together with tiled_min_K > 0: build the tile-major copy whatever the size and
+                                density of the problem (tests) */
+    int32_t shard_min_K;     /* multi-GPU shard threshold: 0 = default (the full-scan threshold), > 0 = minimum K of a
+                                sharded round, < 0 = shard every grid round */
+    int32_t cand_mode;       /* candidate lines: 0 = on, 1 = off (every bid scans its whole row; A/B timing, parity
+                                tests), 2 = on, but no maintenance pass ahead of the tail kernels (k_refresh_lines) */
+    int32_t partial_in_list_order; /* 1 = partial rounds of the full-scan engine take their bidders in list order
+                                instead of person order (A/B timing, parity tests) */
+    int32_t nnz_limit;       /* > 0 lowers the entry limit of a handle (default 2^31 - 1: int32 row pointers), for
+                                tests of that guard */
+    int32_t cand_build_max_K;/* > 0: k_bid (re)builds lines only in rounds with at most so many bidders */
+    int32_t cand_refresh_min;/* r + 1: a line hit with fewer than r live candidates is rebuilt by k_bid (0 = library
+                                default, 1 = never) */
+    int32_t reserved[7];     /* must be zero */
 } misslap_options;
 
 /* Result block of misslap_finish: the reference's `meta` dict (auction_.pyx:264,:297-304)
- * plus GPU-side measurements. */
+ * plus GPU-side measurements.  The caller sets struct_size first (see the ABI history above). */
 typedef struct misslap_meta {
+    int32_t struct_size; /* IN: set to sizeof(misslap_meta) before the call; the library writes that many bytes at most */
+    int32_t abi_version; /* OUT: MISSLAP_ABI_VERSION of the library */
     float start_eps;     /* auction_.pyx:264 (unrounded fp32) */
     float final_eps;     /* :303 */
     float target_eps;    /* :247 */
@@ -115,6 +127,16 @@ typedef struct misslap_meta {
     double tail_stats[12];       /* tail kernel accounting: [0..2] rounds in chain+solo / team / block mode, [3..5] their
                                     duration in 10-ns ticks, [6] bids, [7] bids answered by candidate lines, [8] line
                                     (re)builds, [9] edges of the rows those lines answered, [10..11] reserved */
+    /* validity of the returned assignment, reduced on the device so that `sol` is the only O(N) copy-out (the flags
+     * the reference's benchmark harness forms on the host, benchmarking.py:56-64, with size = n_rows and numpy's
+     * wrap-around for sol = -1):
+     *   complete_assignment  bit 0: np.unique(sol).size == n_rows, bit 1: (sol >= 0).all(), bit 2: (sol < n_rows).all()
+     *   valid_assignment     1 if every selected entry (i, sol[i]) exists and its value -- in the caller's sign -- is >= 0 */
+    int32_t complete_assignment;
+    int32_t valid_assignment;
+    int32_t lines_active;        /* 1 = the handle kept candidate lines (0: switched off by option, by row length, or
+                                    because eps could fall below the rounding error of a price update, see create) */
+    int32_t reserved_i;
 } misslap_meta;
 
 /* Snapshot of the round state (tests / multi-GPU driver). */
@@ -283,6 +305,13 @@ int misslap_matching_gpu(const int32_t *loc, int64_t nnz, int32_t n_rows, int32_
 /* The same matcher on the graph a solver handle already holds in device memory (no host copy of the entries, no second
  * upload): what the front-end's feasibility guard (auction_.pyx:562-566, :608-612) uses once the handle exists. */
 int misslap_matching_of(misslap_solver *h, int32_t *size, int32_t *phases);
+
+/* Host-side caches: a destroyed handle parks its idle HIP stream, pinned status mirror and events (at most 8 bundles)
+ * and freed device blocks of <= 32 MB (at most 16 blocks / 256 MB) for the next handle.  This releases all of them
+ * (streams destroyed, device and pinned memory freed); *freed_bytes (may be NULL) receives the device bytes returned.
+ * Call it when the embedding application needs the memory back; never while another thread creates / destroys handles
+ * on a stream that may still use a parked block (the entry point synchronises every device it frees on). */
+int misslap_trim_caches(int64_t *freed_bytes);
 
 const char *misslap_last_error(void);
 int misslap_abi_version(void);

@@ -15,12 +15,19 @@ class Options(C.Structure):
         ("struct_size", C.c_int32), ("device", C.c_int32), ("maximize", C.c_int32), ("eps_start", C.c_float),
         ("max_iter", C.c_int64), ("input_on_device", C.c_int32), ("tail_threshold", C.c_int32),
         ("force_f64_values", C.c_int32), ("profile", C.c_int32), ("shard_rank", C.c_int32),
-        ("shard_world", C.c_int32), ("rounds_per_sync", C.c_int32), ("reserved", C.c_int32 * 8),
+        ("shard_world", C.c_int32), ("rounds_per_sync", C.c_int32),
+        # tuning knobs (0 = library default)
+        ("tiled_min_K", C.c_int32), ("tiled_shape", C.c_int32), ("tiled_force", C.c_int32),
+        ("shard_min_K", C.c_int32), ("cand_mode", C.c_int32), ("partial_in_list_order", C.c_int32),
+        ("nnz_limit", C.c_int32), ("cand_build_max_K", C.c_int32), ("cand_refresh_min", C.c_int32),
+        ("reserved", C.c_int32 * 7),
     ]
 
 
 class Meta(C.Structure):
+    """misslap_meta (ABI 2).  Create with new_meta(): struct_size must be set before a call."""
     _fields_ = [
+        ("struct_size", C.c_int32), ("abi_version", C.c_int32),
         ("start_eps", C.c_float), ("final_eps", C.c_float), ("target_eps", C.c_float),
         ("eCE", C.c_int32), ("soln_found", C.c_int32), ("nreductions", C.c_int32),
         ("its", C.c_int64), ("n_assigned", C.c_int64),
@@ -37,7 +44,15 @@ class Meta(C.Structure):
         ("merge_launches", C.c_int64), ("merge_ms", C.c_double),
         ("shard_edges", C.c_uint64), ("cand_hits", C.c_uint64), ("cand_edges", C.c_uint64),
         ("tail_stats", C.c_double * 12),
+        ("complete_assignment", C.c_int32), ("valid_assignment", C.c_int32), ("lines_active", C.c_int32),
+        ("reserved_i", C.c_int32),
     ]
+
+
+def new_meta():
+    m = Meta()
+    m.struct_size = C.sizeof(Meta)
+    return m
 
 
 class Status(C.Structure):
@@ -104,6 +119,7 @@ SYMBOLS = {
     "misslap_drive_sharded": (C.c_int, [C.POINTER(RoundOps), _VP]),
     "misslap_hopcroft_karp": (C.c_int, [_VP, C.c_int64, C.c_int32, C.c_int32, _I32P, _VP, _VP]),
     "misslap_matching_gpu": (C.c_int, [_VP, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _I32P, _VP, _VP, _I32P]),
+    "misslap_trim_caches": (C.c_int, [C.POINTER(C.c_int64)]),
     "misslap_last_error": (C.c_char_p, []),
     "misslap_abi_version": (C.c_int, []),
 }
@@ -149,7 +165,7 @@ def load():
         for name, (res, args) in SYMBOLS.items():
             f = getattr(lib, name)
             f.restype, f.argtypes = res, args
-        if lib.misslap_abi_version() != 1:
+        if lib.misslap_abi_version() != 2:
             raise RuntimeError("libmisslap.so ABI version mismatch")
         _LIB = lib
     return _LIB

@@ -44,24 +44,25 @@ def _options(problem, eps_start, max_iter, device=None, tail_threshold=None, pro
     o.rounds_per_sync = int(os.environ.get(_ENV_RPS, 0)) if rounds_per_sync is None else int(rounds_per_sync)
     if shard is not None:
         o.shard_rank, o.shard_world = int(shard[0]), int(shard[1])
-    o.reserved[0] = int(os.environ.get(_ENV_TILED, 0)) if tiled_min_k is None else int(tiled_min_k)
+    o.tiled_min_K = int(os.environ.get(_ENV_TILED, 0)) if tiled_min_k is None else int(tiled_min_k)
     # launch shape of k_bid_tiled: None / env unset = chosen by the library; k = shape k of misslap.hip:kTiledShapes
     shape = os.environ.get("MISSLAP_TILED_SHAPE") if tiled_shape is None else tiled_shape
-    o.reserved[1] = 0 if shape is None else int(shape) + 1
-    o.reserved[2] = int(os.environ.get("MISSLAP_ENGINE", 0)) if engine is None else int(engine)
-    o.reserved[3] = int(os.environ.get("MISSLAP_SHARD_MIN_K", 0)) if shard_min_k is None else int(shard_min_k)
+    o.tiled_shape = 0 if shape is None else int(shape) + 1
+    o.tiled_force = int(os.environ.get("MISSLAP_ENGINE", 0)) if engine is None else int(engine)
+    o.shard_min_K = int(os.environ.get("MISSLAP_SHARD_MIN_K", 0)) if shard_min_k is None else int(shard_min_k)
     # candidate lines (per-person exact bid shortcut, csrc/device_common.hpp): on by default, 0 = off (A/B runs)
     # (cand=2 / MISSLAP_CAND=2: lines without the maintenance pass ahead of the tail kernels)
     c = int(os.environ.get("MISSLAP_CAND", 1)) if cand is None else int(cand)
-    o.reserved[4] = 1 if c == 0 else (2 if c == 2 else 0)
+    o.cand_mode = 1 if c == 0 else (2 if c == 2 else 0)
     # partial rounds of the full-scan engine in person order (kernels_tiled.hpp, k_order_*): on by default, 0 = list order
-    o.reserved[5] = ((1 - int(os.environ.get("MISSLAP_ORDER_PARTIAL", 1))) if order_partial is None
-                     else (0 if order_partial else 1))
-    o.reserved[7] = int(os.environ.get("MISSLAP_CAND_BUILD_MAX_K", 0)) if cand_build_max_k is None else int(cand_build_max_k)
+    o.partial_in_list_order = ((1 - int(os.environ.get("MISSLAP_ORDER_PARTIAL", 1))) if order_partial is None
+                               else (0 if order_partial else 1))
+    o.cand_build_max_K = (int(os.environ.get("MISSLAP_CAND_BUILD_MAX_K", 0)) if cand_build_max_k is None
+                          else int(cand_build_max_k))
     # k_bid rebuilds a line that hits with fewer live candidates than this (None / env unset = library default)
     refresh = os.environ.get("MISSLAP_CAND_REFRESH") if cand_refresh is None else cand_refresh
-    o.reserved[7] |= (0 if refresh is None else int(refresh) + 1) << 24
-    o.reserved[6] = 0 if nnz_limit is None else int(nnz_limit)  # tests of the int32 row-pointer guard
+    o.cand_refresh_min = 0 if refresh is None else int(refresh) + 1
+    o.nnz_limit = 0 if nnz_limit is None else int(nnz_limit)  # tests of the int32 row-pointer guard
     return o
 
 
@@ -162,7 +163,7 @@ class AuctionSolver:
         """Run the auction (auction_.pyx:268-306); returns person_to_object as int32[N]."""
         lib = _lib.load()
         sol = np.empty(self.num_rows, dtype=np.int32)
-        meta = _lib.Meta()
+        meta = _lib.new_meta()
         _lib.check(lib.misslap_solve(self._h, sol.ctypes.data, C.byref(meta)))
         self._fill_meta(meta)
         return sol
@@ -172,7 +173,7 @@ class AuctionSolver:
         per-object arg-max exchanged on the solver's stream inside the library (misslap_solve_sharded)."""
         lib = _lib.load()
         sol = np.empty(self.num_rows, dtype=np.int32)
-        meta = _lib.Meta()
+        meta = _lib.new_meta()
         _lib.check(lib.misslap_solve_sharded(self._h, comm._c if comm is not None else None, sol.ctypes.data,
                                              C.byref(meta)))
         self._fill_meta(meta)
@@ -193,7 +194,12 @@ class AuctionSolver:
                  setup_ms=float(m.setup_ms), solve_ms=float(m.solve_ms), final_eps_f32=float(m.final_eps),
                  start_eps_f32=float(m.start_eps), tail_edges=int(m.tail_edges), shard_edges=int(m.shard_edges),
                  tiled_active=int(m.tiled_active), tiled_min_K=int(m.tiled_min_K),
-                 cand_hits=int(m.cand_hits), cand_edges=int(m.cand_edges))
+                 cand_hits=int(m.cand_hits), cand_edges=int(m.cand_edges), lines_active=int(m.lines_active),
+                 # validity of the assignment as the reference's benchmark harness forms it (benchmarking.py:56-64),
+                 # reduced on the device: (np.unique(sol).size == N, (sol >= 0).all(), (sol < N).all()), and
+                 # (mat[arange(N), sol] >= 0).all()
+                 complete_assignment=tuple(bool(m.complete_assignment >> k & 1) for k in range(3)),
+                 valid_assignment=bool(m.valid_assignment))
         d = [float(x) for x in m.tail_stats]
         g["tail_modes"] = {name: dict(rounds=int(d[k]), ms=round(d[3 + k] * 1e-5, 3),
                                       us_per_round=round(d[3 + k] * 1e-2 / d[k], 3) if d[k] else None)
@@ -253,7 +259,7 @@ class AuctionSolver:
 
     def finish(self):
         sol = np.empty(self.num_rows, dtype=np.int32)
-        meta = _lib.Meta()
+        meta = _lib.new_meta()
         _lib.check(_lib.load().misslap_finish(self._h, sol.ctypes.data, C.byref(meta)))
         self._fill_meta(meta)
         return sol

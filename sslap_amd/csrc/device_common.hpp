@@ -32,6 +32,8 @@ constexpr int kErrNonFinite = 8;     // NaN / inf among the values
 constexpr int kErrColNegative = 16;  // negative row / column index
 constexpr int kErrLdsBase = 32;      // k_bid_tiled: the price buffers do not start at LDS address 0
 constexpr int kErrTooMany = 64;      // dense ingest: more valid entries than int32 row pointers can address
+constexpr int kErrPriceFell = 128;   // a price update lowered a price: eps is below the rounding error of fl(fl(c - w) + eps)
+                                     // -- candidate lines (which rely on prices only rising) may have answered wrongly
 
 // Device-resident control block: the scalar part of the reference's solver state.
 struct Ctl {
@@ -57,6 +59,7 @@ struct Ctl {
     int pad1;
     unsigned long long dbg[16]; // tail accounting: [0..2] rounds per mode, [3..5] 10-ns ticks, [12..15] bids / line hits /
                                 // builds / hit edges; [6..11] cycles per segment in -DMISSLAP_TAIL_STAMP* builds
+    unsigned long long val_cnt[4]; // k_validity: distinct owned objects, sol < 0, sol >= n_rows, invalid selected entries
 };
 
 // ---- edge storage ------------------------------------------------------------------------------

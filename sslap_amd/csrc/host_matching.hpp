@@ -33,6 +33,27 @@ struct HopcroftKarp {
         for (int i = 0; i < n_rows; ++i) row_ptr[(size_t)i + 1] += row_ptr[(size_t)i];
     }
 
+    // The same graph from a CSR (row pointers + column of every entry, `stride` ints apart): the fallback of the GPU
+    // matcher on the graph a solver handle holds in device memory.
+    HopcroftKarp(const int *row_ptr_, const int *col_, int stride, int n_rows_, int n_cols_)
+        : n_rows(n_rows_), n_cols(n_cols_), row_ptr(row_ptr_, row_ptr_ + n_rows_ + 1), col((size_t)row_ptr_[n_rows_]),
+          pair_u((size_t)n_rows_, -1), pair_v((size_t)n_cols_, -1), dist((size_t)n_rows_, 0) {
+        for (size_t k = 0; k < col.size(); ++k) col[k] = col_[k * (size_t)stride];
+    }
+
+    // Start from a matching found elsewhere (the GPU matcher's, when it gave up): match_row[u] = v / match_col[v] = u,
+    // -1 = free.  Inconsistent pairs are dropped.
+    void seed(const int *match_row, const int *match_col) {
+        for (int u = 0; u < n_rows; ++u) {
+            const int v = match_row[u];
+            if (v >= 0 && v < n_cols && match_col[v] == u && pair_v[v] == -1) {
+                pair_u[u] = v;
+                pair_v[v] = u;
+                matching += 1;
+            }
+        }
+    }
+
     void bfs(std::vector<int> &queue) {  // breadth_first_search, :119-150
         size_t front = 0, back = 0;
         for (int u = 0; u < n_rows; ++u) {

@@ -411,6 +411,7 @@ __global__ __launch_bounds__(256) void k_apply(RoundArgs a) {
             r.price = key_to_bid(a.best_key[j]);     // p[j] = best_bids[j]   (:397)
             r.owner = i;
             r.ostart = a.row_ptr[i];
+            if (r.price < a.price[j]) atomicOr(&ctl->err, kErrPriceFell);  // (never with eps above the rounding error)
             a.rec[j] = r;
             a.price[j] = r.price;
             const int prev = a.o2p[j];               // :401

@@ -449,13 +449,38 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
                                                  (__attribute__((address_space(3))) void *)(dst + piece * 128), 16, 0,
                                                  0);
     };
+#ifndef MISSLAP_TILED_THROTTLE
+#define MISSLAP_TILED_THROTTLE -1  // >= 0: a loader wavefront keeps at most this many + 1 pieces of a fill in flight
+#endif
+    // The CU's vector memory path returns in order: a fill issued as one burst (26 pieces per loader wavefront) sits
+    // in front of every edge load the compute wavefronts issue behind it.  A paced fill -- the next piece only when
+    // the oldest has landed but for MISSLAP_TILED_THROTTLE -- leaves room between its pieces; it has a whole tile's
+    // compute time to complete.
+    auto dma_fill_paced = [&](int tile, int first, int stride) {
+        constexpr int kPieces = kTileCols / 128;
+        const double *gsrc = a.price + (size_t)tile * kTileCols + 2 * lane;
+        double *dst = s_price + (kDouble ? (tile & 1) : 0) * kBufDoubles;
+        for (int piece = first; piece < kPieces; piece += stride) {
+            if (ABL != 1)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc + piece * 128),
+                                                 (__attribute__((address_space(3))) void *)(dst + piece * 128), 16, 0,
+                                                 0);
+            if (MISSLAP_TILED_THROTTLE >= 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MISSLAP_TILED_THROTTLE < 0 ? 0 : MISSLAP_TILED_THROTTLE) : "memory");
+        }
+    };
     if (loader) {
         const int me = wave_u - (kWaves - kLoaders);
+#ifdef MISSLAP_TILED_LOADER_PRIO
+        __builtin_amdgcn_s_setprio(MISSLAP_TILED_LOADER_PRIO);
+#endif
         dma_fill(rot(0), me, kLoaders);
         for (int tile = 0; tile < T; ++tile) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my pieces of tile `tile` have landed
             if (ABL != 4) __syncthreads();                    // ... and tile - 1 is no longer read
-            if (tile + 1 < T) dma_fill(rot(tile + 1), me, kLoaders);
+            if (tile + 1 < T) {
+                if (MISSLAP_TILED_THROTTLE >= 0) dma_fill_paced(rot(tile + 1), me, kLoaders);
+                else dma_fill(rot(tile + 1), me, kLoaders);
+            }
         }
     }
     // Software pipeline over steps = (tile, batch of kTileBatch persons): while step s is consumed, the edges

@@ -7,12 +7,14 @@
 //
 // Build: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fno-honor-nans -shared -fPIC misslap.hip -o libmisslap.so
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -20,6 +22,7 @@
 #include <vector>
 
 #include "../../include/misslap.h"
+#include "abi_v1.hpp"
 #include "device_common.hpp"
 #include "kernels_check.hpp"
 #ifdef MISSLAP_DIAG
@@ -98,25 +101,48 @@ constexpr int kDefaultRoundsPerSync = 16;
 constexpr int kRoundsPerSyncLargeK = 2;  // batch length while K > kRoundSmallMax
 constexpr int kMaxGridBlocks = 2048;  // 256 CUs x 8 resident 256-thread blocks
 constexpr int kNumTiledShapes = 10;
-// (shape 0 is the default: three loader wavefronts measured 1-2 % faster than one inside a solve)
+// (shape 0 is the default: three loader wavefronts measured 1-2 % faster than one inside a solve; shape 4 -- eight
+// persons per 8-lane group, one load per segment -- spilled 34 VGPRs and was retired: selecting it is an error)
 // launch shapes of k_bid_tiled: {threads, persons per lane group, persons in flight, loads per segment,
 // prices per LDS tile, loader wavefronts, lanes per person}; see kernels_tiled.hpp
 const int kTiledShapes[kNumTiledShapes][7] = {
     {1024, 4, 2, 2, kTileColsHalf, 3, 4}, {1024, 4, 2, 2, kTileColsHalf, 0, 4}, {1024, 4, 2, 3, kTileColsBig, 0, 4},
-    {1024, 4, 2, 2, kTileColsHalf, 1, 4}, {1024, 8, 4, 1, kTileColsHalf, 1, 8}, {1024, 4, 1, 2, kTileColsHalf, 1, 4},
+    {1024, 4, 2, 2, kTileColsHalf, 1, 4}, {0, 0, 0, 0, 0, 0, 0} /* retired */, {1024, 4, 1, 2, kTileColsHalf, 1, 4},
     {1024, 4, 2, 3, kTileColsHalf, 1, 4}, {1024, 4, 2, 2, kTileColsHalf, 2, 4},
     // longer (person, tile) segments: 8 / 16 lanes per person, i.e. 32 / 64 edges per step without the leftover loop
     {1024, 4, 2, 2, kTileColsHalf, 3, 8}, {1024, 4, 2, 2, kTileColsHalf, 3, 16}};
 #define MISSLAP_FOR_TILED_SHAPES(X)                                                                                  \
     X(0, 1024, 4, 2, 2, kTileColsHalf, 3, 4) X(1, 1024, 4, 2, 2, kTileColsHalf, 0, 4)                                \
     X(2, 1024, 4, 2, 3, kTileColsBig, 0, 4) X(3, 1024, 4, 2, 2, kTileColsHalf, 1, 4)                                 \
-    X(4, 1024, 8, 4, 1, kTileColsHalf, 1, 8) X(5, 1024, 4, 1, 2, kTileColsHalf, 1, 4)                                \
+    X(5, 1024, 4, 1, 2, kTileColsHalf, 1, 4)                                                                         \
     X(6, 1024, 4, 2, 3, kTileColsHalf, 1, 4) X(7, 1024, 4, 2, 2, kTileColsHalf, 2, 4)                                \
     X(8, 1024, 4, 2, 2, kTileColsHalf, 3, 8) X(9, 1024, 4, 2, 2, kTileColsHalf, 3, 16)
 inline size_t tiled_lds_bytes(int tile_cols) {  // see the LDS map in k_bid_tiled; + statistics scratch
     const size_t doubles = tile_cols == kTileColsBig ? (size_t)tile_cols + 2 : 2 * (size_t)tile_cols + 128;
     return doubles * sizeof(double) + 16 * 12;
 }
+
+// Profiled launches (options.profile): the two events are handed to the launch itself (hipExtLaunchKernel), so they
+// carry the begin / end timestamps of the KERNEL -- what a rocprofv3 kernel trace reports.  Events recorded around a
+// launch on the stream bracket the dispatch gap as well (~7 us per launch at C3: 92.4 against 85.6 us in round 2).
+// MISSLAP_PROFILE_PLAIN_EVENTS=1 selects the bracketing form (A/B of the two clocks).
+inline bool plain_events() {
+    static const bool v = [] {
+        const char *e = std::getenv("MISSLAP_PROFILE_PLAIN_EVENTS");
+        return e && e[0] == '1';
+    }();
+    return v;
+}
+#define MISSLAP_LAUNCH_TIMED(PR, KERNEL, GRID, BLOCK, LDS, STREAM, ...)                              \
+    do {                                                                                            \
+        if ((PR) && !plain_events()) {                                                              \
+            hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, (PR)->start, (PR)->stop, 0, __VA_ARGS__); \
+        } else {                                                                                    \
+            if (PR) (void)hipEventRecord((PR)->start, STREAM);                                      \
+            hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, __VA_ARGS__);                      \
+            if (PR) (void)hipEventRecord((PR)->stop, STREAM);                                       \
+        }                                                                                           \
+    } while (0)
 
 struct ProfRec {
     hipEvent_t start, stop;
@@ -137,6 +163,9 @@ void block_free(int device, void *p, size_t bytes);
 }  // namespace
 
 struct misslap_solver {
+    int abi = MISSLAP_ABI_VERSION;  // 1: created with version-1 options (88 bytes) -> version-1 misslap_meta layout
+    int n_cus = 256;                // compute units of the device (one k_bid_tiled workgroup per CU)
+    bool lines_guard_off = false;   // lines switched off at create: eps may fall below a price update's rounding error
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -221,10 +250,14 @@ int dev_alloc(T **p, size_t n) {
 struct DevScratch {
     std::vector<Blk> blks;
     int device = 0;
+    bool drained = false;  // set by the owner after it has synchronised the stream(s) that used the blocks
     DevScratch() { (void)hipGetDevice(&device); }
     DevScratch(const DevScratch &) = delete;
     DevScratch &operator=(const DevScratch &) = delete;
     ~DevScratch() {
+        // The blocks go back to a process-wide cache (not through hipFree, which would synchronise): on an error
+        // return kernels may still be running on them, and another thread's handle could be handed that memory.
+        if (!drained && !blks.empty()) (void)hipDeviceSynchronize();
         for (const Blk &b : blks) block_free(device, b.p, b.bytes);
     }
     template <class T>
@@ -460,7 +493,7 @@ int launch_bid_tiled(misslap_solver *h) {
     const int groups = (shp[0] - 64 * shp[5]) / shp[6];  // lane groups; loader wavefronts own no persons
     const int per_wg_max = groups * shp[1];
     long long grid = (share + per_wg_max - 1) / per_wg_max;
-    const long long resident = 256;  // one workgroup per CU: its two price tiles take the whole LDS
+    const long long resident = h->n_cus;  // one workgroup per CU: its two price tiles take the whole LDS
     const long long spread = std::min<long long>(resident, (share + groups - 1) / groups);
     if (grid < spread) grid = spread;
     TiledArgs ta{reinterpret_cast<const unsigned *>(h->tiled), h->tcol, h->seg4, h->T, h->tiled_min_K, h->n_tiled,
@@ -488,18 +521,16 @@ int launch_bid_tiled(misslap_solver *h) {
         if (!pr) return fail(MISSLAP_ERR_HIP, "hipEventCreate failed");
         pr->fullscan = h->phase_fresh;  // K == N; with several ranks: this rank's share of the full scan
         pr->launch_idx = a.launch_idx = h->launch_idx++;
-        HIP_TRY(hipEventRecord(pr->start, h->stream));
     }
     const size_t lds = tiled_lds_bytes(shp[4]);
     const dim3 g((unsigned)grid);
     switch (h->tiled_shape) {
 #define X(I, TH, R, B, D, TC, LD, GL) \
-    case I: hipLaunchKernelGGL((k_bid_tiled<TH, R, B, D, TC, LD, 0, GL>), g, dim3(TH), lds, h->stream, a, ta); break;
+    case I: MISSLAP_LAUNCH_TIMED(pr, (k_bid_tiled<TH, R, B, D, TC, LD, 0, GL>), g, dim3(TH), (unsigned)lds, h->stream, a, ta); break;
         MISSLAP_FOR_TILED_SHAPES(X)
 #undef X
         default: return fail(MISSLAP_ERR_STATE, "bad tiled shape");
     }
-    if (pr) HIP_TRY(hipEventRecord(pr->stop, h->stream));
     HIP_TRY(hipGetLastError());
     return MISSLAP_OK;
 }
@@ -538,7 +569,6 @@ int launch_bid(misslap_solver *h) {
         if (!pr) return fail(MISSLAP_ERR_HIP, "hipEventCreate failed");
         pr->fullscan = fullscan;
         pr->launch_idx = a.launch_idx = h->launch_idx++;
-        HIP_TRY(hipEventRecord(pr->start, h->stream));
     }
     const EdgesF32 e32{h->edges32};
     const EdgesF64 e64{h->col, h->val64};
@@ -547,15 +577,14 @@ int launch_bid(misslap_solver *h) {
     const int variant = !h->cand ? 0 : h->K_ub > h->cand_build_max_K ? 1 : 2;
 #define MISSLAP_LAUNCH_BID(E, ED)                                                                                   \
     do {                                                                                                            \
-        if (h->round_small) hipLaunchKernelGGL((k_bid<E, RecSource, 2>), g, b, 0, h->stream, a, ED);                \
-        else if (variant == 0) hipLaunchKernelGGL((k_bid<E, PriceSource, 0>), g, b, 0, h->stream, a, ED);           \
-        else if (variant == 1) hipLaunchKernelGGL((k_bid<E, PriceSource, 1>), g, b, 0, h->stream, a, ED);           \
-        else hipLaunchKernelGGL((k_bid<E, PriceSource, 2>), g, b, 0, h->stream, a, ED);                             \
+        if (h->round_small) MISSLAP_LAUNCH_TIMED(pr, (k_bid<E, RecSource, 2>), g, b, 0, h->stream, a, ED);          \
+        else if (variant == 0) MISSLAP_LAUNCH_TIMED(pr, (k_bid<E, PriceSource, 0>), g, b, 0, h->stream, a, ED);     \
+        else if (variant == 1) MISSLAP_LAUNCH_TIMED(pr, (k_bid<E, PriceSource, 1>), g, b, 0, h->stream, a, ED);     \
+        else MISSLAP_LAUNCH_TIMED(pr, (k_bid<E, PriceSource, 2>), g, b, 0, h->stream, a, ED);                       \
     } while (0)
     if (h->f32) MISSLAP_LAUNCH_BID(EdgesF32, e32);  // (rounds that k_round_small finishes: bids with the owners)
     else MISSLAP_LAUNCH_BID(EdgesF64, e64);
 #undef MISSLAP_LAUNCH_BID
-    if (pr) HIP_TRY(hipEventRecord(pr->stop, h->stream));
     HIP_TRY(hipGetLastError());
     h->phase_fresh = false;
     return MISSLAP_OK;
@@ -654,7 +683,7 @@ int launch_tail(misslap_solver *h) {
     if (pr) HIP_TRY(hipEventRecord(pr->stop, h->stream));
     // the tail keeps only the price records current: rebuild price / o2p / p2o from them
     hipLaunchKernelGGL(k_sync_clear_p2o, dim3(blocks_for(h->n_rows, 256)), dim3(256), 0, h->stream, h->p2o, h->n_rows);
-    hipLaunchKernelGGL(k_sync_from_rec, dim3(blocks_for(h->n_cols, 256)), dim3(256), 0, h->stream, h->rec, h->price,
+    hipLaunchKernelGGL(k_sync_from_rec, dim3(blocks_for(h->n_cols, 256)), dim3(256), 0, h->stream, h->ctl, h->rec, h->price,
                        h->o2p, h->p2o, h->n_cols);
     HIP_TRY(hipGetLastError());
     h->phase_fresh = false;
@@ -751,6 +780,23 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
     if (st.max_col >= 0x7ffffffe) return fail(MISSLAP_ERR_INVALID, "column index too large (max + 1 must fit an int32)");
     h->n_cols = st.max_col + 1;  // auction_.pyx:210
     h->f32 = !st.not_f32 && !opt->force_f64_values;
+    // Candidate lines are exact only while prices never fall (device_common.hpp).  A price update is
+    // fl(fl(c - w) + eps) with w <= fl(c - p): it can land BELOW p once eps is smaller than the rounding error of
+    // those operations, i.e. for huge |cost| with a small target eps (1 / N).  Then the lines are switched off for
+    // the handle (the full scans never depend on the invariant); kErrPriceFell is the run-time backstop.
+    int cand_mode = opt->cand_mode;
+    {
+        double max_abs_d;
+        const long long b = (long long)st.max_abs_bits;
+        std::memcpy(&max_abs_d, &b, sizeof(double));
+        const double target = 1.0 / (double)h->n_rows;
+        double eps_floor = 0.15 * target;  // the last phase runs with target > eps >= 0.15 target (:280-283)
+        if (opt->eps_start > 0 && (double)opt->eps_start < eps_floor) eps_floor = (double)opt->eps_start;
+        if (cand_mode != 1 && max_abs_d * 0x1p-44 > eps_floor) {  // < 2^9 ulps of the largest cost
+            cand_mode = 1;
+            h->lines_guard_off = true;
+        }
+    }
     // Lines for long rows (k_refresh_long) pay where a row scan is long: dense 8000^2 1.79 -> 0.60 s.  At a few
     // hundred edges per row the pass costs more than the scans it saves (C4, 300 edges per row, 176 rounds: 13.4 ->
     // 18.3 ms), so it runs from kLongRowsFrom edges per row on average.
@@ -759,9 +805,9 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
     h->long_rows = st.max_row_len > kCandRowMax && avg_row >= kLongRowsFrom && avg_row <= kCandLongMax;
     // ... below that (C4's 300 edges per row, a dense 600^2) only once the solve has shown that its tail is long:
     // launch_tail switches the builder on after kLongRowsAfterTailRounds tail rounds
-    h->long_rows_later = !h->long_rows && avg_row > kCandRowMax && avg_row <= kCandLongMax && opt->reserved[4] != 1;
+    h->long_rows_later = !h->long_rows && avg_row > kCandRowMax && avg_row <= kCandLongMax && cand_mode != 1;
     if (h->thr < 0) {  // library default: by whether the persons will have candidate lines (rows of <= 256 edges)
-        const bool lines = opt->reserved[4] != 1 && (avg_row <= kCandRowMax || h->long_rows);
+        const bool lines = cand_mode != 1 && (avg_row <= kCandRowMax || h->long_rows);
         h->thr = lines ? kDefaultTailThreshold : kDefaultTailThresholdNoLines;
     }
     const int flip = h->maximize ? 0 : 1;
@@ -787,11 +833,13 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
     const size_t N = (size_t)h->n_rows, M = (size_t)h->n_cols;
     // second, tile-major copy of the edges for the full-scan bid engines (8 B/edge layout, big rounds only)
     // launch shape: options.reserved[1] = k + 1 picks shape k (tuning); 0 = by the average (person, tile) segment length
-    const bool shape_auto = !(opt->reserved[1] >= 1 && opt->reserved[1] <= kNumTiledShapes);
-    h->tiled_shape = shape_auto ? 0 : opt->reserved[1] - 1;
-    const int tiled_opt = opt->reserved[0];  // 0 default, < 0 never, > 0 minimum K for the full-scan engines
+    const bool shape_auto = !(opt->tiled_shape >= 1 && opt->tiled_shape <= kNumTiledShapes);
+    h->tiled_shape = shape_auto ? 0 : opt->tiled_shape - 1;
+    if (kTiledShapes[h->tiled_shape][0] == 0)
+        return fail(MISSLAP_ERR_INVALID, "k_bid_tiled launch shape %d was retired", h->tiled_shape);
+    const int tiled_opt = opt->tiled_min_K;  // 0 default, < 0 never, > 0 minimum K for the full-scan engines
     size_t Mpad = M;
-    const bool forced_engine = opt->reserved[2] != 0 && tiled_opt > 0;  // tests / tuning: any size
+    const bool forced_engine = opt->tiled_force != 0 && tiled_opt > 0;  // tests / tuning: any size
     if (h->f32 && tiled_opt >= 0 && (N >= 4096 || forced_engine)) {
         const bool forced = forced_engine;  // tests / tuning: skip the density heuristics
         const int tcols = kTiledShapes[h->tiled_shape][4];
@@ -881,8 +929,8 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
         DevBlock blk;
         blk.want(&h->price, Mpad);
         blk.want(&h->rec, M);
-        h->line_maintenance = opt->reserved[4] != 2;
-        if (opt->reserved[4] != 1) {  // candidate lines (reserved[4] = 1: off, A/B timing and parity tests)
+        h->line_maintenance = cand_mode != 2;
+        if (cand_mode != 1) {  // candidate lines (cand_mode 1: off -- A/B timing, parity tests, the precision guard)
             blk.want(&h->cand, N * (size_t)kCandLanes);
             if (!h->f32) blk.want(&h->cand64, N * (size_t)kCandLanes);  // 12 B/edge layout: the costs as fp64
         }
@@ -916,8 +964,8 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
     for (hipEvent_t &e : h->stat_ev)
         if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     h->shard_min_K = h->tiled_ok ? h->tiled_min_K : (int)std::max<size_t>((N * 3) / 10, 8192);
-    if (opt->reserved[3] > 0) h->shard_min_K = opt->reserved[3];
-    if (opt->reserved[3] < 0) h->shard_min_K = 0;  // every grid round sharded + exchanged
+    if (opt->shard_min_K > 0) h->shard_min_K = opt->shard_min_K;
+    if (opt->shard_min_K < 0) h->shard_min_K = 0;  // every grid round sharded + exchanged
     // candidate lines are used and built below the full-scan regime (0.3 N): C5 with lines built in every round
     // 3.85 s and a 939 us full scan (it writes a 256-byte line per person), with this limit 3.87 s and 588 us
     if (h->cand_build_max_K == 0x7fffffff)
@@ -943,12 +991,13 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
     h->K_exact = true;
     h->phase_fresh = true;
     HIP_TRY(hipStreamSynchronize(h->stream));
+    tmp.drained = true;
     return MISSLAP_OK;
 }
 
-// entries a handle can hold: row pointers are int32 (options.reserved[6] > 0 lowers the limit: guard tests)
+// entries a handle can hold: row pointers are int32 (options.nnz_limit > 0 lowers the limit: guard tests)
 int64_t nnz_limit(const misslap_options *opt) {
-    return opt->reserved[6] > 0 ? (int64_t)opt->reserved[6] : (int64_t)0x7fffffff;
+    return opt->nnz_limit > 0 ? (int64_t)opt->nnz_limit : (int64_t)0x7fffffff;
 }
 
 // Device-resident inputs: the library works on a private non-blocking stream, which is not ordered behind the
@@ -958,10 +1007,51 @@ int sync_device_inputs(const misslap_options *opt) {
     return MISSLAP_OK;
 }
 
-int new_handle(misslap_solver **out, const misslap_options *opt, misslap_solver **hp) {
+// The caller's options in the current layout.  struct_size 88 = a version-1 caller (abi_v1.hpp): its reserved[] knobs
+// are mapped onto the named fields and the handle remembers to answer with the version-1 misslap_meta.  A version-2
+// struct may be shorter than this library's (built against an older version-2 header: the missing tail is zero =
+// defaults) but not longer than it knows how to read.
+int normalise_options(const misslap_options *in, misslap_options *out, int *abi) {
+    if (!in) return fail(MISSLAP_ERR_INVALID, "null options");
+    std::memset(out, 0, sizeof(*out));
+    if (in->struct_size == (int32_t)sizeof(misslap_options_v1)) {
+        misslap_options_v1 v1;
+        std::memcpy(&v1, in, sizeof(v1));
+        std::memcpy(out, &v1, offsetof(misslap_options_v1, reserved));  // identical prefix
+        out->tiled_min_K = v1.reserved[0];
+        out->tiled_shape = v1.reserved[1];
+        out->tiled_force = v1.reserved[2];
+        out->shard_min_K = v1.reserved[3];
+        out->cand_mode = v1.reserved[4];
+        out->partial_in_list_order = v1.reserved[5];
+        out->nnz_limit = v1.reserved[6];
+        out->cand_build_max_K = v1.reserved[7] & 0xffffff;
+        out->cand_refresh_min = (v1.reserved[7] >> 24) & 63;
+        *abi = 1;
+    } else {
+        // (the named knobs end where version 1's 88 bytes end: a version-2 struct is told apart by being longer)
+        constexpr int32_t kMinV2 = (int32_t)offsetof(misslap_options, reserved) + 4;
+        static_assert(offsetof(misslap_options, reserved) == sizeof(misslap_options_v1), "see above");
+        if (in->struct_size < kMinV2 || in->struct_size > (int32_t)sizeof(misslap_options))
+            return fail(MISSLAP_ERR_INVALID, "misslap_options.struct_size %d: expected %d (ABI %d; %d = ABI 1 is accepted too)",
+                        in->struct_size, (int)sizeof(misslap_options), MISSLAP_ABI_VERSION, (int)sizeof(misslap_options_v1));
+        std::memcpy(out, in, (size_t)in->struct_size);
+        for (int32_t r : out->reserved)
+            if (r != 0) return fail(MISSLAP_ERR_INVALID, "misslap_options.reserved must be zero");
+        *abi = 2;
+    }
+    out->struct_size = (int32_t)sizeof(misslap_options);
+    if (out->cand_mode < 0 || out->cand_mode > 2) return fail(MISSLAP_ERR_INVALID, "cand_mode %d: 0, 1 or 2", out->cand_mode);
+    if (out->cand_refresh_min < 0 || out->cand_refresh_min > 32)
+        return fail(MISSLAP_ERR_INVALID, "cand_refresh_min %d: 0 .. 32", out->cand_refresh_min);
+    if (out->cand_build_max_K < 0) return fail(MISSLAP_ERR_INVALID, "cand_build_max_K must not be negative");
+    if (out->tiled_shape < 0 || out->tiled_shape > kNumTiledShapes)
+        return fail(MISSLAP_ERR_INVALID, "tiled_shape %d: 0 (automatic) .. %d", out->tiled_shape, kNumTiledShapes);
+    return MISSLAP_OK;
+}
+
+int new_handle(misslap_solver **out, const misslap_options *opt, int abi, misslap_solver **hp) {
     if (!out || !opt) return fail(MISSLAP_ERR_INVALID, "null argument");
-    if (opt->struct_size != (int32_t)sizeof(misslap_options))
-        return fail(MISSLAP_ERR_INVALID, "misslap_options.struct_size mismatch (ABI %d)", MISSLAP_ABI_VERSION);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(MISSLAP_ERR_NO_DEVICE, "no HIP device available: libmisslap has no CPU fallback");
@@ -972,12 +1062,18 @@ int new_handle(misslap_solver **out, const misslap_options *opt, misslap_solver 
         return fail(MISSLAP_ERR_INVALID, "bad shard rank/world");
     HIP_TRY(hipSetDevice(opt->device));
     misslap_solver *h = new misslap_solver();
+    h->abi = abi;
     h->device = opt->device;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, opt->device) == hipSuccess && cus > 0)
+            h->n_cus = cus;
+    }
     h->maximize = opt->maximize ? 1 : 0;
     h->thr = opt->tail_threshold >= 0 ? opt->tail_threshold : -1;  // -1: resolved in build_from_device_coo
-    h->order_partial = opt->reserved[5] == 0;
-    if ((opt->reserved[7] & 0xffffff) > 0) h->cand_build_max_K = opt->reserved[7] & 0xffffff;
-    if ((opt->reserved[7] >> 24) & 63) h->cand_refresh_min = ((opt->reserved[7] >> 24) & 63) - 1;
+    h->order_partial = opt->partial_in_list_order == 0;
+    if (opt->cand_build_max_K > 0) h->cand_build_max_K = opt->cand_build_max_K;
+    if (opt->cand_refresh_min > 0) h->cand_refresh_min = opt->cand_refresh_min - 1;
     h->rounds_per_sync = opt->rounds_per_sync > 0 ? opt->rounds_per_sync : kDefaultRoundsPerSync;
     h->world = opt->shard_world > 0 ? opt->shard_world : 1;
     h->rank = opt->shard_world > 0 ? opt->shard_rank : 0;
@@ -1029,8 +1125,18 @@ MISSLAP_API int misslap_hopcroft_karp(const int32_t *loc, int64_t nnz, int32_t n
 // version's (and the reference's), the pairings are a maximum matching but not necessarily the same one.
 // Greedy start + phases of the GPU matcher (kernels_matching.hpp) on a CSR already in device memory; the matched-row
 // count is left in a.counters[2].
-static int run_matching_phases(hipStream_t st, const MatchArgs &a, int *nph_out) {
+// The matcher augments ONE path per BFS tree and phase, so its set of augmenting paths is not maximal and the
+// O(sqrt n) phase bound of Hopcroft-Karp does not hold; every BFS layer costs a launch and a status read.  Chain-like
+// graphs could need O(n) layers times many phases: the phases / layers are budgeted, and when the budget runs out
+// *gave_up is set -- the caller finishes with the host matcher seeded by the matching found so far.
+static int run_matching_phases(hipStream_t st, const MatchArgs &a, int *nph_out, bool *gave_up) {
     const int n_rows = a.n_rows, n_cols = a.n_cols;
+    const long long root_n = (long long)std::sqrt((double)std::max(n_rows, 1)) + 1;
+    const long long max_phases = 4 * root_n + 64, max_layers = std::max<long long>(2048, 64 * root_n);
+    long long layers = 0;
+    *gave_up = false;
+    long long layer_budget = max_layers;
+    if (const char *e = std::getenv("MISSLAP_MATCHING_MAX_LAYERS")) layer_budget = std::atoll(e);  // (tests of the fallback)
     const int gV = blocks_for(std::max(n_rows, n_cols), 256), gW = blocks_for(n_rows, 4);
     hipLaunchKernelGGL(k_m_init, dim3(gV), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_m_greedy, dim3(gV), dim3(256), 0, st, a);
@@ -1042,6 +1148,10 @@ static int run_matching_phases(hipStream_t st, const MatchArgs &a, int *nph_out)
         int cnt[4] = {0, 0, 0, 0};
         bool augmented = false;
         for (int L = 0; L <= n_rows; ++L) {
+            if (++layers > layer_budget || nph >= max_phases) {
+                *gave_up = true;
+                break;
+            }
             HIP_TRY(hipMemsetAsync(a.counters + 1, 0, sizeof(int), st));
             hipLaunchKernelGGL(k_m_bfs_layer, dim3(gW), dim3(256), 0, st, a, L);
             HIP_TRY(hipMemcpyAsync(cnt, a.counters, sizeof(cnt), hipMemcpyDeviceToHost, st));
@@ -1054,7 +1164,7 @@ static int run_matching_phases(hipStream_t st, const MatchArgs &a, int *nph_out)
             if (cnt[1] == 0) break;  // the layering is exhausted: no augmenting path is left
         }
         HIP_TRY(hipGetLastError());
-        if (!augmented) break;
+        if (!augmented || *gave_up) break;
         ++nph;
     }
     HIP_TRY(hipMemsetAsync(a.counters + 2, 0, sizeof(int), st));
@@ -1111,16 +1221,35 @@ MISSLAP_API int misslap_matching_gpu(const int32_t *loc, int64_t nnz, int32_t n_
     const int gE = blocks_for(nnz, 256 * 4);
     hipLaunchKernelGGL(k_m_row_ptr, dim3(gE), dim3(256), 0, st, d_loc, (long long)nnz, n_rows, row_ptr, col, d_err);
     int nph = 0;
-    if ((rc = run_matching_phases(st, a, &nph))) return rc;
+    bool gave_up = false;
+    if ((rc = run_matching_phases(st, a, &nph, &gave_up))) return rc;
     int out[4] = {0, 0, 0, 0}, err = 0;
+    std::vector<int> mr, mc;
+    if (gave_up) {
+        mr.resize((size_t)n_rows);
+        mc.resize((size_t)n_cols);
+    }
+    int *lp = gave_up ? mr.data() : left_pairings, *rp = gave_up ? mc.data() : right_pairings;
     HIP_TRY(hipMemcpyAsync(out, a.counters, sizeof(out), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(&err, d_err, sizeof(int), hipMemcpyDeviceToHost, st));
-    if (left_pairings) HIP_TRY(hipMemcpyAsync(left_pairings, a.match_row, sizeof(int) * (size_t)n_rows, hipMemcpyDeviceToHost, st));
-    if (right_pairings) HIP_TRY(hipMemcpyAsync(right_pairings, a.match_col, sizeof(int) * (size_t)n_cols, hipMemcpyDeviceToHost, st));
+    if (lp) HIP_TRY(hipMemcpyAsync(lp, a.match_row, sizeof(int) * (size_t)n_rows, hipMemcpyDeviceToHost, st));
+    if (rp) HIP_TRY(hipMemcpyAsync(rp, a.match_col, sizeof(int) * (size_t)n_cols, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    tmp.drained = true;
     if (err) return fail(MISSLAP_ERR_INVALID, "loc rows must be sorted in ascending order");
     *size = out[2];
     if (phases) *phases = nph;
+    if (gave_up) {  // finish on the host from the matching found so far (same cardinality: both are maximum)
+        try {
+            HopcroftKarp hk(loc, nnz, n_rows, n_cols);
+            hk.seed(mr.data(), mc.data());
+            *size = hk.solve();
+            if (left_pairings) std::copy(hk.pair_u.begin(), hk.pair_u.end(), left_pairings);
+            if (right_pairings) std::copy(hk.pair_v.begin(), hk.pair_v.end(), right_pairings);
+        } catch (const std::bad_alloc &) {
+            return fail(MISSLAP_ERR_HIP, "out of host memory in misslap_matching_gpu");
+        }
+    }
     return MISSLAP_OK;
 }
 
@@ -1151,16 +1280,77 @@ MISSLAP_API int misslap_matching_of(misslap_solver *h, int32_t *size, int32_t *p
     }
     hipStream_t st = h->stream;
     int nph = 0;
-    if ((rc = run_matching_phases(st, a, &nph))) return rc;
+    bool gave_up = false;
+    if ((rc = run_matching_phases(st, a, &nph, &gave_up))) return rc;
     int out[4] = {0, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(out, a.counters, sizeof(out), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     *size = out[2];
     if (phases) *phases = nph;
+    if (gave_up) {  // the budget ran out: the handle's CSR and the matching so far go to the host matcher
+        try {
+            const size_t stride = h->f32 ? 2 : 1;
+            std::vector<int> rp((size_t)h->n_rows + 1), cols((size_t)h->nnz * stride), mr((size_t)h->n_rows), mc((size_t)h->n_cols);
+            HIP_TRY(hipMemcpy(rp.data(), h->row_ptr, sizeof(int) * rp.size(), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(cols.data(), a.col, sizeof(int) * cols.size(), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(mr.data(), a.match_row, sizeof(int) * mr.size(), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(mc.data(), a.match_col, sizeof(int) * mc.size(), hipMemcpyDeviceToHost));
+            rp[(size_t)h->n_rows] = (int)h->nnz;  // (the device array's last entry is written by the ingest as well)
+            HopcroftKarp hk(rp.data(), cols.data(), (int)stride, h->n_rows, h->n_cols);
+            hk.seed(mr.data(), mc.data());
+            *size = hk.solve();
+        } catch (const std::bad_alloc &) {
+            return fail(MISSLAP_ERR_HIP, "out of host memory in misslap_matching_of");
+        }
+    }
+    tmp.drained = true;
     return MISSLAP_OK;
 }
 
 MISSLAP_API const char *misslap_last_error(void) { return g_err.c_str(); }
+
+MISSLAP_API int misslap_trim_caches(int64_t *freed_bytes) {
+    int64_t freed = 0;
+    int keep_dev = 0;
+    const bool have_dev = hipGetDevice(&keep_dev) == hipSuccess;
+    {
+        BlockCache &bc = block_cache();
+        std::vector<BlockCache::Ent> take;
+        {
+            std::lock_guard<std::mutex> g(bc.m);
+            take.swap(bc.idle);
+            bc.held = 0;
+        }
+        for (const BlockCache::Ent &e : take) {
+            if (hipSetDevice(e.device) == hipSuccess) {
+                (void)hipDeviceSynchronize();  // nothing may still be running on a parked block
+                (void)hipFree(e.p);
+                freed += (int64_t)e.bytes;
+            }
+        }
+    }
+    {
+        HostResPool &hp = host_pool();
+        std::vector<std::pair<int, HostRes>> take;
+        {
+            std::lock_guard<std::mutex> g(hp.m);
+            take.swap(hp.idle);
+        }
+        for (auto &pr : take) {
+            if (hipSetDevice(pr.first) != hipSuccess) continue;
+            if (pr.second.stream) {
+                (void)hipStreamSynchronize(pr.second.stream);
+                (void)hipStreamDestroy(pr.second.stream);
+            }
+            if (pr.second.h_ctl) (void)hipHostFree(pr.second.h_ctl);
+            for (hipEvent_t e : pr.second.ev)
+                if (e) (void)hipEventDestroy(e);
+        }
+    }
+    if (have_dev) (void)hipSetDevice(keep_dev);
+    if (freed_bytes) *freed_bytes = freed;
+    return MISSLAP_OK;
+}
 
 MISSLAP_API int misslap_device_info(int32_t device, char *name, int32_t name_len, int32_t *compute_units,
                                     int64_t *hbm_bytes) {
@@ -1176,14 +1366,19 @@ MISSLAP_API int misslap_device_info(int32_t device, char *name, int32_t name_len
 }
 
 MISSLAP_API int misslap_create(misslap_solver **out, int64_t nnz, const int32_t *loc, const double *val,
-                               const misslap_options *opt) {
+                               const misslap_options *opt_in) {
     const double t0 = now_ms();
+    misslap_options o2;
+    int abi = 0;
+    int rc = normalise_options(opt_in, &o2, &abi);
+    if (rc) return rc;
+    const misslap_options *opt = &o2;
     if (!loc || !val) return fail(MISSLAP_ERR_INVALID, "null loc / val");
     if (nnz <= 0) return fail(MISSLAP_ERR_INVALID, "empty problem (nnz = %lld)", (long long)nnz);
-    if (opt && nnz >= nnz_limit(opt))
+    if (nnz >= nnz_limit(opt))
         return fail(MISSLAP_ERR_INVALID, "nnz must be < %lld (int32 row pointers)", (long long)nnz_limit(opt));
     misslap_solver *h = nullptr;
-    int rc = new_handle(out, opt, &h);
+    rc = new_handle(out, opt, abi, &h);
     if (rc) return rc;
     h->nnz = nnz;
     if ((rc = sync_device_inputs(opt))) {
@@ -1225,13 +1420,18 @@ MISSLAP_API int misslap_create(misslap_solver **out, int64_t nnz, const int32_t 
 }
 
 MISSLAP_API int misslap_create_dense(misslap_solver **out, int64_t n_rows, int64_t n_cols, const double *mat,
-                                     const misslap_options *opt, int64_t *nnz_out) {
+                                     const misslap_options *opt_in, int64_t *nnz_out) {
     const double t0 = now_ms();
+    misslap_options o2;
+    int abi = 0;
+    int rc = normalise_options(opt_in, &o2, &abi);
+    if (rc) return rc;
+    const misslap_options *opt = &o2;
     if (!mat) return fail(MISSLAP_ERR_INVALID, "null mat");
     if (n_rows <= 0 || n_cols <= 0 || n_rows > 0x7ffffffe || n_cols > 0x7ffffffe)
         return fail(MISSLAP_ERR_INVALID, "bad dense shape");
     misslap_solver *h = nullptr;
-    int rc = new_handle(out, opt, &h);
+    rc = new_handle(out, opt, abi, &h);
     if (rc) return rc;
     double *d_mat = nullptr, *d_val = nullptr;
     int *d_cnt = nullptr, *d_ptr = nullptr, *d_loc = nullptr;
@@ -1396,7 +1596,7 @@ MISSLAP_API int misslap_phase_end(misslap_solver *h, int32_t *finished) {
     return MISSLAP_OK;
 }
 
-MISSLAP_API int misslap_finish(misslap_solver *h, int32_t *person_to_object_out, misslap_meta *meta) {
+MISSLAP_API int misslap_finish(misslap_solver *h, int32_t *person_to_object_out, misslap_meta *meta_out) {
     if (!h) return fail(MISSLAP_ERR_INVALID, "null handle");
     HIP_TRY(hipSetDevice(h->device));
     int rc;
@@ -1424,10 +1624,41 @@ MISSLAP_API int misslap_finish(misslap_solver *h, int32_t *person_to_object_out,
     if (person_to_object_out)
         HIP_TRY(hipMemcpyAsync(person_to_object_out, h->p2o, sizeof(int) * (size_t)h->n_rows, hipMemcpyDeviceToHost,
                                h->stream));
+    // validity flags of the assignment (benchmarking.py:56-64), reduced on the device: k_validity
+    HIP_TRY(hipMemsetAsync(h->ctl->val_cnt, 0, sizeof(h->ctl->val_cnt), h->stream));
+    if (h->f32) {
+        EdgesF32 ed{h->edges32};
+        hipLaunchKernelGGL(k_validity<EdgesF32>, dim3(grid), dim3(256), 0, h->stream, h->ctl, ed, h->row_ptr, h->p2o, h->o2p,
+                           h->n_rows, h->n_cols, h->maximize);
+    } else {
+        EdgesF64 ed{h->col, h->val64};
+        hipLaunchKernelGGL(k_validity<EdgesF64>, dim3(grid), dim3(256), 0, h->stream, h->ctl, ed, h->row_ptr, h->p2o, h->o2p,
+                           h->n_rows, h->n_cols, h->maximize);
+    }
+    HIP_TRY(hipGetLastError());
     if ((rc = read_ctl(h))) return rc;
-    if (!meta) return MISSLAP_OK;
+    if (!meta_out) return MISSLAP_OK;
+    // how much the caller's struct holds: a version-1 caller (88-byte options at create) gets the version-1 layout
+    size_t out_bytes = sizeof(misslap_meta_v1);
+    if (h->abi >= 2) {
+        const int32_t sz = meta_out->struct_size;
+        if (sz < (int32_t)offsetof(misslap_meta, edges_scanned) || sz > 65536)
+            return fail(MISSLAP_ERR_INVALID, "misslap_meta.struct_size = %d: set it to sizeof(misslap_meta) before the call", sz);
+        out_bytes = std::min<size_t>((size_t)sz, sizeof(misslap_meta));
+    }
     const Ctl &c = *h->h_ctl;
+    misslap_meta full;
+    misslap_meta *meta = &full;
     std::memset(meta, 0, sizeof(*meta));
+    meta->struct_size = (int32_t)out_bytes;
+    meta->abi_version = MISSLAP_ABI_VERSION;
+    {
+        const unsigned long long distinct = c.val_cnt[0], n_neg = c.val_cnt[1], n_big = c.val_cnt[2], n_invalid = c.val_cnt[3];
+        const unsigned long long uniq = distinct + (n_neg ? 1ull : 0ull);  // np.unique counts -1 as one value
+        meta->complete_assignment = (uniq == (unsigned long long)h->n_rows ? 1 : 0) | (n_neg == 0 ? 2 : 0) | (n_big == 0 ? 4 : 0);
+        meta->valid_assignment = n_invalid == 0 ? 1 : 0;
+        meta->lines_active = h->cand != nullptr ? 1 : 0;
+    }
     meta->start_eps = h->start_eps;
     meta->final_eps = h->eps;
     meta->target_eps = h->target_eps;
@@ -1494,6 +1725,15 @@ MISSLAP_API int misslap_finish(misslap_solver *h, int32_t *person_to_object_out,
                 meta->tail_ms += ms;
             }
         }
+    }
+    if (h->abi >= 2) {
+        std::memcpy(meta_out, &full, out_bytes);
+    } else {  // version-1 layout: the same fields without the two leading words and the appended ones
+        misslap_meta_v1 v1;
+        static_assert(offsetof(misslap_meta, complete_assignment) - offsetof(misslap_meta, start_eps) == sizeof(misslap_meta_v1),
+                      "misslap_meta = {struct_size, abi_version} + the version-1 fields + appended fields");
+        std::memcpy(&v1, &full.start_eps, sizeof(v1));
+        std::memcpy(meta_out, &v1, sizeof(v1));
     }
     return MISSLAP_OK;
 }
@@ -1613,6 +1853,9 @@ MISSLAP_API int misslap_solve_sharded(misslap_solver *h, misslap_comm *comm, int
         return fail(MISSLAP_ERR_INVALID, "communicator is rank %d of %d, the handle was created as shard %d of %d",
                     comm->rank, comm->world, h->rank, h->world);
     if (!comm && h->world != 1) return fail(MISSLAP_ERR_INVALID, "a handle of %d shards needs a communicator", h->world);
+    if (comm && !comm->custom && comm->device != h->device)  // an all-reduce enqueued on another device's stream fails late or hangs
+        return fail(MISSLAP_ERR_INVALID, "the RCCL communicator lives on device %d, the handle on device %d", comm->device,
+                    h->device);
     HIP_TRY(hipSetDevice(h->device));
     const double t0 = now_ms();
     const misslap_round_ops o = handle_round_ops(h);

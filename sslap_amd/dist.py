@@ -23,7 +23,7 @@ Communicators:
                                                128-byte id to every rank (any transport the application has)
     Comm.from_torch_distributed(device)        the same, the id travels through torch.distributed
     Comm.custom(rank, world, max_cb, min_cb)   caller-provided all-reduces (ptr, count, stream) -- other transports
-    Comm.gloo_staged(rank, world)              rehearsal on ONE GPU: several ranks share cuda:0, the exchange is
+    Comm.gloo_staged(group=None)               rehearsal on ONE GPU: several ranks share cuda:0, the exchange is
                                                staged through the host with gloo (RCCL needs a GPU per rank)
 """
 import ctypes as C

@@ -50,6 +50,7 @@ int main(int argc, char **argv) {
     misslap_dims(h, &n, &m, &e);
     int32_t *sol = malloc(sizeof(int32_t) * (size_t)n);
     misslap_meta meta;
+    meta.struct_size = (int32_t)sizeof meta; /* ABI 2: the library writes at most this many bytes */
     if (misslap_solve(h, sol, &meta) != MISSLAP_OK) {
         fprintf(stderr, "solve: %s\n", misslap_last_error());
         return 6;

@@ -45,6 +45,11 @@ def golden_long():
 
 
 @pytest.fixture(scope="session")
+def golden_xlong():
+    return _load("xlong_cases")
+
+
+@pytest.fixture(scope="session")
 def golden_large():
     return _load("large_cases")[0]
 

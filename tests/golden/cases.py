@@ -45,9 +45,11 @@ def _full_double(n, density, seed):
     return loc, val
 
 
-def _dense(n, m, seed, integer_values):
+def _dense(n, m, seed, integer_values, common=0):
     """Every (i, j) present: rows of m edges (far longer than the 256 edges a wavefront keeps in registers and, at
-    m = 1500, than the 1024 of four passes).  Values as in synth.gen_sparse."""
+    m = 1500, than the 1024 of four passes).  Values as in synth.gen_sparse.  common = c > 0: every person likes the
+    same objects -- value = a column preference (weight c / 16) + personal noise, fp32-exact -- so that few objects
+    are fought over for many rounds even when there are far more objects than persons."""
     ii, jj = np.meshgrid(np.arange(n, dtype=np.int32), np.arange(m, dtype=np.int32), indexing="ij")
     loc = np.ascontiguousarray(np.stack([ii.ravel(), jj.ravel()], axis=1))
     h = synth._stream(seed, 3, n * m)
@@ -55,6 +57,14 @@ def _dense(n, m, seed, integer_values):
         val = (1 + (h >> np.uint64(33)) % np.uint64(integer_values)).astype(np.float64)
     else:
         val = ((h >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / (1 << 24)) * np.float32(100.0)).astype(np.float64)
+    if common:
+        hc = synth._stream(seed, 4, m)
+        if integer_values:
+            pref = ((hc >> np.uint64(33)) % np.uint64(integer_values * common)).astype(np.float64)
+        else:  # multiples of 2^-10 below 100 c / 16: the sum with a 24-bit noise value of < 100 stays fp32-exact? no --
+            # the sum is rounded to fp32 explicitly, which keeps the 8 B/edge layout
+            pref = (hc >> np.uint64(44)).astype(np.float64) * (100.0 * common / 16.0 / float(1 << 20))
+        val = (val + pref[jj.ravel()]).astype(np.float32).astype(np.float64)
     return loc, val
 
 
@@ -62,7 +72,7 @@ def synth_inputs(spec):
     """spec: dict(kind=..., ...) -> (loc, val)."""
     kind = spec["kind"]
     if kind == "dense":
-        return _dense(spec["n"], spec["m"], spec.get("seed", 1), spec.get("ints", 0))
+        return _dense(spec["n"], spec["m"], spec.get("seed", 1), spec.get("ints", 0), spec.get("common", 0))
     if kind == "sparse":
         loc, val = synth.gen_sparse(spec["n"], spec["m"], spec["density"], seed=spec.get("seed", 1),
                                     integer_values=spec.get("ints", 0))
@@ -145,6 +155,20 @@ LONG_TRACE_CASES = {
     "trace_dense1500": (dict(kind="dense", n=1500, m=1500, seed=14), dict(problem="min")),
 }
 
+# rows beyond the regimes above: 8 193..16 384 edges per row (the 512-thread line builder,
+# k_refresh_long<E, 512>) through the `mat=` entry, and rows of more than 16 384 edges (no lines at all, tail
+# threshold 40).  Full sol + meta from the real reference, plus short traces (rounds per case).
+XLONG_CASES = {
+    "dense9000_max_mat": (dict(kind="dense", n=9000, m=9000, seed=21), dict(problem="max"), "mat"),
+    "dense40x20000_max": (dict(kind="dense", n=40, m=20000, seed=22), dict(problem="max"), "locval"),
+    "dense300x17000_common_max": (dict(kind="dense", n=300, m=17000, seed=24, common=64), dict(problem="max"), "locval"),
+    "dense300x17000_int3_common_max": (dict(kind="dense", n=300, m=17000, seed=25, ints=3, common=8), dict(problem="max"), "locval"),
+}
+XLONG_TRACE_CASES = {
+    "trace_dense9000": (dict(kind="dense", n=9000, m=9000, seed=21), dict(problem="max"), 24),
+    "trace_dense300x17000_int3_common": (dict(kind="dense", n=300, m=17000, seed=25, ints=3, common=8), dict(problem="max"), 80),
+}
+
 # hash-only cases: the BASELINE.json configs (max_iter = 1e8)
 LARGE_CASES = {
     "C1": (dict(kind="config", name="C1"), dict(problem="max", max_iter=10**8)),
@@ -153,6 +177,8 @@ LARGE_CASES = {
     "C3": (dict(kind="config", name="C3"), dict(problem="max", max_iter=10**8)),
     "C4": (dict(kind="config", name="C4"), dict(problem="max", max_iter=10**8)),
     "C5": (dict(kind="config", name="C5"), dict(problem="max", max_iter=10**8)),
+    # not a BASELINE config: dense 8000 x 8000, the shape of the reference's `mat=` entry (bench.py --config D1)
+    "D1": (dict(kind="config", name="D1"), dict(problem="max", max_iter=10**8)),
 }
 
 

@@ -15,7 +15,7 @@ Runs only in the build container (needs /root/reference and Cython):
 
 Nothing of the reference (source, bytecode, binaries) is written into the repo;
 only inputs/outputs are.  Usage:
-    python tests/golden/make_golden.py [small] [trace] [demo] [long] [large] [C5] [matching]
+    python tests/golden/make_golden.py [small] [trace] [demo] [long] [xlong] [large] [D1] [C5] [matching]
 """
 import json
 import os
@@ -146,6 +146,34 @@ def do_long(ref_solve, versions):
     json.dump(manifest, open(os.path.join(HERE, "long_cases.json"), "w"), indent=1, sort_keys=True)
 
 
+def do_xlong(ref_solve, versions):
+    """Rows of 9 000 and 20 000 edges: full solutions + meta and short traces."""
+    out = {}
+    manifest = {"versions": versions, "cases": {}, "traces": {}}
+    for name, (spec, kw, entry) in cases.XLONG_CASES.items():
+        loc, val = cases.synth_inputs(spec)
+        ref, o, mutated, t_ref, t_orc = run_both(ref_solve, name, loc, val, kw, entry, spec)
+        out[name + "/sol"] = ref["sol"].astype(np.int32)
+        manifest["cases"][name] = dict(meta=meta_of(ref), input_sha256=synth.input_digest(loc, val),
+                                       val_mutated=mutated, obj_f64=o["extra"]["obj_f64"],
+                                       edges_scanned=o["extra"]["edges_scanned"],
+                                       reference_wall_s=round(t_ref, 2), oracle_wall_s=round(t_orc, 2))
+        print(f"xlong {name}: its={ref['meta']['its']} nred={ref['meta']['nreductions']} ok "
+              f"({t_ref:.1f}s ref, {t_orc:.1f}s oracle)", flush=True)
+    for name, (spec, kw, rounds) in cases.XLONG_TRACE_CASES.items():
+        loc, val = cases.synth_inputs(spec)
+        sols, its = [], []
+        for r in range(1, rounds + 1):
+            ref, o, _, _, _ = run_both(ref_solve, f"{name}@{r}", loc, val, dict(kw, max_iter=r), "locval", spec)
+            sols.append(ref["sol"].astype(np.int32))
+            its.append(ref["meta"]["its"])
+        out[name + "/p2o"] = np.stack(sols)
+        manifest["traces"][name] = dict(its=its, rounds=rounds, input_sha256=synth.input_digest(loc, val))
+        print(f"xlong trace {name}: {len(sols)} rounds ok", flush=True)
+    np.savez_compressed(os.path.join(HERE, "xlong_cases.npz"), **out)
+    json.dump(manifest, open(os.path.join(HERE, "xlong_cases.json"), "w"), indent=1, sort_keys=True)
+
+
 def do_demo(ref_solve, versions):
     """The reference's own seeded demo inputs (examples/test_auction.py:7-46) and a small instance
     of its benchmark recipe (benchmarking.py:17-45).  np.random streams are not portable, so the
@@ -256,6 +284,10 @@ if __name__ == "__main__":
         do_long(ref_solve, versions)
     if "large" in what:
         do_large(ref_solve, versions, ["C1", "C1_min", "C2", "C4", "C3"])
+    if "xlong" in what:
+        do_xlong(ref_solve, versions)
+    if "D1" in what:
+        do_large(ref_solve, versions, ["D1"])
     if "C5" in what:
         do_large(ref_solve, versions, ["C5"])
     if "matching" in what:

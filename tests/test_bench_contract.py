@@ -4,12 +4,22 @@ other.  Runs without a GPU: it checks the artefact, not the measurement."""
 import json
 import os
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _line(name):
     with open(os.path.join(ROOT, "profiles", name)) as f:
         return json.loads(f.read().strip().splitlines()[-1])
+
+
+def _latest_c3():
+    """The newest committed bench line of the headline config (profiles/rNN_bench_C3.json)."""
+    import glob
+    names = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_C3.json")))
+    assert names, "no committed bench line"
+    return os.path.basename(names[-1])
 
 
 def test_bench_line_has_the_contract_fields():
@@ -43,3 +53,71 @@ def test_bench_line_matches_the_reference_fixture():
     assert d["sol_sha256"] == g["sol_sha256"]
     assert d["rounds"] == g["meta"]["its"] and d["obj_f64"] == g["obj_f64"]
     assert d["edges_scanned_per_solve"] == g["edges_scanned"]
+
+
+def test_latest_bench_line_has_the_contract_fields_and_this_rounds_additions():
+    name = _latest_c3()
+    d = _line(name)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "bid_phase", "sol_sha256"):
+        assert k in d, k
+    assert d["unit"] == "Medges/s" and d["n_gpus"] == 1 and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert abs(r["algorithmic_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9 - r["achieved"]) < 0.01 * r["achieved"]
+    for k in ("traffic", "launches", "algorithmic_bytes_per_edge"):
+        assert k in r, k
+    bp = d["bid_phase"]
+    for k in ("fullscan_avg_us", "fullscan_frac_of_hbm_peak", "grid_all_launches", "k_tail"):
+        assert k in bp, k
+    assert bp["grid_all_launches"]["launches"] >= r["launches"] / d["steps"]
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and "whole_solve_medges_s" in c
+    assert abs(d["value"] - d["edges_scanned_per_solve"] * d["steps"] / (d["ms_per_step"] * d["steps"] * 1e-3) / 1e6) < 0.01 * d["value"]
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "large_cases.json")))["cases"]["C3"]
+    assert d["sol_sha256"] == g["sol_sha256"] and d["rounds"] == g["meta"]["its"] and d["obj_f64"] == g["obj_f64"]
+    if name >= "r03":  # SURVEY 8(d) additions of round 3: the second solve figure and the second peak
+        assert r["peak_measured_copy"] > 3000.0 and abs(r["frac_of_measured"] - r["achieved"] / r["peak_measured_copy"]) < 1e-3
+        h = d["solve_incl_h2d"]
+        assert h["solve_ms_incl_h2d"] > d["solve_ms"] and h["h2d_bytes"] == 16 * d["config"]["nnz"]
+        assert d["complete_assignment"] == [True, True, True] and d["valid_assignment"] is True
+
+
+def test_bench_gpus_n_without_a_launcher_spawns_the_ranks_before_touching_the_gpu():
+    """`python bench.py --gpus 2` with no WORLD_SIZE: the parent starts two fresh ranks (RANK / WORLD_SIZE / MASTER_*
+    set) and has not imported torch itself.  Without a GPU both ranks stop with the no-fallback message and the parent
+    relays the failure."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["MISSLAP_BENCH_TRACE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-cpu", "--config", "C1", "--mode", "replicas"], env=env, capture_output=True, text=True, timeout=600)
+    assert "spawning 2 ranks, torch_imported_in_parent=False" in r.stderr
+    import torch
+    if not torch.cuda.is_available():
+        assert r.returncode != 0 and r.stderr.count("bench.py needs a GPU") == 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["sharded", "replicas"])
+def test_bench_gpus_2_launches_itself_on_one_gpu_under_gloo(mode):
+    """The driver's form of the N > 1 run -- `python bench.py --gpus 2`, no launcher -- rehearsed on a one-GPU box:
+    MISSLAP_DIST_BACKEND=gloo lets the two ranks share cuda:0 (the exchange of the sharded mode is then staged through
+    the host).  One JSON line, the reference's assignment."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(MISSLAP_DIST_BACKEND="gloo", MISSLAP_BENCH_TRACE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--no-cpu", "--config", "C1", "--mode", mode], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "torch_imported_in_parent=False" in r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "large_cases.json")))["cases"]["C1"]
+    assert d["n_gpus"] == 2 and d["sol_sha256"] == g["sol_sha256"] and d["rounds"] == g["meta"]["its"]
+    assert d["scaling"] == ("weak" if mode == "replicas" else "strong")

@@ -31,8 +31,10 @@ def test_struct_layouts_match_header():
     """Compile a tiny C program against the header and compare sizeof / offsetof with ctypes."""
     import subprocess
     import tempfile
-    fields = {"misslap_options": ["max_iter", "tail_threshold", "rounds_per_sync"],
-              "misslap_meta": ["its", "obj_f64", "edges_scanned", "bid_ms", "tail_edges", "tiled_min_K", "merge_ms", "shard_edges", "cand_hits", "tail_stats"],
+    fields = {"misslap_options": ["max_iter", "tail_threshold", "rounds_per_sync", "tiled_min_K", "cand_mode",
+                                  "cand_refresh_min", "reserved"],
+              "misslap_meta": ["struct_size", "start_eps", "its", "obj_f64", "edges_scanned", "bid_ms", "tail_edges", "tiled_min_K", "merge_ms", "shard_edges", "cand_hits", "tail_stats",
+                               "complete_assignment", "valid_assignment", "lines_active"],
               "misslap_status": ["K", "error_bits", "rounds_per_sync", "shard_min_K"]}
     prog = ['#include <stdio.h>', '#include <stddef.h>', '#include "misslap.h"', 'int main(void){']
     for s, fs in fields.items():
@@ -51,6 +53,51 @@ def test_struct_layouts_match_header():
         assert int(out[s]) == C.sizeof(t), s
         for f in fields[s]:
             assert int(out[f"{s}.{f}"]) == getattr(t, f).offset, (s, f)
+
+
+def test_options_struct_size_versions_are_recognised():
+    """ABI 1 (88 bytes, knobs in reserved[]) and ABI 2 options pass the validation (and then fail for want of a GPU
+    here, or succeed on a GPU box); any other size, a non-zero reserved word or a bad knob is MISSLAP_ERR_INVALID."""
+    lib = _lib.load()
+    loc = np.array([[0, 0], [1, 1]], dtype=np.int32)
+    val = np.array([1.0, 2.0])
+
+    def create(buf):
+        h = C.c_void_p()
+        rc = lib.misslap_create(C.byref(h), 2, loc.ctypes.data, val.ctypes.data, C.cast(C.byref(buf), C.POINTER(_lib.Options)))
+        if rc == 0:
+            lib.misslap_destroy(h)
+        return rc, lib.misslap_last_error().decode()
+
+    class OptionsV1(C.Structure):
+        _fields_ = _lib.Options._fields_[:12] + [("reserved", C.c_int32 * 8)]
+    assert C.sizeof(OptionsV1) == 88
+    v1 = OptionsV1(struct_size=88, tail_threshold=-1, max_iter=10)
+    v1.reserved[7] = 5000 | (9 << 24)
+    rc, msg = create(v1)
+    assert rc in (0, _lib.ERR_NO_DEVICE), msg
+    v2 = _lib.Options(struct_size=C.sizeof(_lib.Options), tail_threshold=-1, max_iter=10)
+    rc, msg = create(v2)
+    assert rc in (0, _lib.ERR_NO_DEVICE), msg
+    short = _lib.Options(struct_size=_lib.Options.reserved.offset + 4, tail_threshold=-1, max_iter=10)  # a shorter ABI-2 struct
+    rc, msg = create(short)
+    assert rc in (0, _lib.ERR_NO_DEVICE), msg
+    for bad in (_lib.Options(struct_size=90), _lib.Options(struct_size=4096), _lib.Options(struct_size=0)):
+        rc, msg = create(bad)
+        assert rc == _lib.ERR_INVALID and "struct_size" in msg, (rc, msg)
+    nz = _lib.Options(struct_size=C.sizeof(_lib.Options))
+    nz.reserved[3] = 1
+    rc, msg = create(nz)
+    assert rc == _lib.ERR_INVALID and "reserved" in msg
+    rc, msg = create(_lib.Options(struct_size=C.sizeof(_lib.Options), cand_mode=7))
+    assert rc == _lib.ERR_INVALID and "cand_mode" in msg
+    rc, msg = create(_lib.Options(struct_size=C.sizeof(_lib.Options), tiled_shape=5))  # shape 4 was retired
+    assert rc in (_lib.ERR_INVALID, _lib.ERR_NO_DEVICE)
+
+
+def test_trim_caches_needs_no_gpu():
+    freed = C.c_int64(-1)
+    assert _lib.load().misslap_trim_caches(C.byref(freed)) == 0 and freed.value >= 0
 
 
 def test_no_cpu_fallback_without_gpu():

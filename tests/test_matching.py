@@ -182,3 +182,31 @@ def test_dense_front_end_guard_runs_on_the_handle(gpu_lib):
     bad[:, :25] = r.random((60, 25))  # 60 rows compete for 25 columns
     with pytest.raises(ValueError, match=r"Maximum matching possible only involves 25 out of 60 rows"):
         from_matrix(bad, problem="max", cardinality_check=True)
+
+
+@pytest.mark.gpu
+def test_gpu_matcher_falls_back_to_the_host_when_its_layer_budget_runs_out(gpu_lib, monkeypatch):
+    """the GPU matcher augments one path per BFS tree and phase, so chain- / ladder-like graphs can need
+    O(n) layers; the layers are budgeted and the host matcher finishes from the matching found so far.  A ladder
+    (row k -> columns k, k + 1) whose greedy start leaves one long augmenting path, with the budget forced low."""
+    from sslap_amd.check_feasible import matching_gpu
+    n = 3000
+    i = np.repeat(np.arange(n, dtype=np.int32), 2)
+    j = np.stack([np.arange(1, n + 1, dtype=np.int32), np.arange(n, dtype=np.int32)], axis=1).reshape(-1)
+    j[-2] = n - 1  # the last row only reaches column n - 1 (twice): one augmenting path through every vertex
+    ladder = np.ascontiguousarray(np.stack([i, j], axis=1))
+    for budget in ("4", None):
+        if budget is None:
+            monkeypatch.delenv("MISSLAP_MATCHING_MAX_LAYERS", raising=False)
+        else:
+            monkeypatch.setenv("MISSLAP_MATCHING_MAX_LAYERS", budget)
+        res = matching_gpu(ladder, n, n + 1)
+        assert res["size"] == cardinality(ladder, n, n + 1)
+        _valid_matching(ladder, res)
+    # the same through a solver handle's device-resident CSR (misslap_matching_of)
+    monkeypatch.setenv("MISSLAP_MATCHING_MAX_LAYERS", "3")
+    spec = dict(kind="thinned", n=900, m=900, density=0.01, seed=31, keep_mod=2)
+    loc = cases.matching_graph(spec)
+    from sslap_amd import AuctionSolver
+    s = AuctionSolver(loc, np.ones(loc.shape[0]), problem="max")
+    assert s.matching_cardinality() == cardinality(loc, 900, 900)
