@@ -83,36 +83,28 @@ def launch_ranks(n, argv):
         port = sk.getsockname()[1]
     if os.environ.get("MISSLAP_BENCH_TRACE"):
         print(f"bench.py parent: spawning {n} ranks, torch_imported_in_parent={'torch' in sys.modules}", file=sys.stderr)
+    import tempfile
     procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    deadline = time.time() + float(os.environ.get("MISSLAP_BENCH_TIMEOUT_S", 3000))
-    out = b""
-    try:
-        while True:
-            rcs = [p.poll() for p in procs]
-            if all(rc is not None for rc in rcs):
-                break
-            if any(rc not in (None, 0) for rc in rcs) or time.time() > deadline:
-                for p in procs:  # one rank failed (or the run hangs): the others would wait in a collective for ever
-                    if p.poll() is None:
-                        p.kill()
-                break
-            try:
-                out += procs[0].communicate(timeout=1.0)[0] or b""
-            except subprocess.TimeoutExpired:
-                pass
-    finally:
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
-    rest = procs[0].stdout.read() if procs[0].stdout and not procs[0].stdout.closed else b""
-    sys.stdout.write((out + (rest or b"")).decode())
-    sys.stdout.flush()
-    rcs = [p.wait() for p in procs]
+    with tempfile.TemporaryFile() as out0:  # rank 0's stdout (a file, not a pipe: nothing to drain while we wait)
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                          stdout=out0 if r == 0 else subprocess.DEVNULL))
+        deadline = time.time() + float(os.environ.get("MISSLAP_BENCH_TIMEOUT_S", 3000))
+        try:
+            while any(p.poll() is None for p in procs):
+                if any(p.poll() not in (None, 0) for p in procs) or time.time() > deadline:
+                    break  # one rank failed (or the run hangs): the others would wait in a collective for ever
+                time.sleep(0.2)
+        finally:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        rcs = [p.wait() for p in procs]
+        out0.seek(0)
+        sys.stdout.write(out0.read().decode())
+        sys.stdout.flush()
     raise SystemExit(0 if all(rc == 0 for rc in rcs) else next(rc for rc in rcs if rc != 0) or 1)
 
 

@@ -824,10 +824,15 @@ __device__ __forceinline__ void tail_team1_mode(const TailArgs &a, const E &ed, 
 // and nothing else: the solo / team code needs more than the 128 registers a 1024-thread workgroup leaves a
 // wavefront.  The host launches it ahead of the 512-thread kernel, which then finds K <= kTeamMax.
 // kTeamOnly (1024 threads as well): the rounds with 3..kTeamMax bidders, one slot per wavefront (tail_team1_mode).
+// kThreads = 128 ("duo / chain only", handles with lines): the rounds with K <= 2 and nothing else -- two wavefronts
+// for duo mode, wavefront 0 alone for the chain; the instance that carries every mode needs 185 VGPRs and spills 14
+// SGPRs, each spill a v_writelane / v_readlane pair inside a chain that is bound by its instruction count.
 template <class E, int kThreads, bool kTeamOnly = false>
 __global__ __launch_bounds__(kThreads) void k_tail(TailArgs a, E ed) {
     static_assert(!kTeamOnly || (kThreads == 2 * kTailMax && kThreads / kWave == kTeamMax), "one slot per wavefront");
     constexpr bool kBlockOnly = kThreads > kTailMax && !kTeamOnly;
+    constexpr bool kDuoOnly = kThreads == 2 * kWave;
+    static_assert(!kDuoOnly || !kTeamOnly, "roles are exclusive");
     __shared__ int sU[kTailMax];
     __shared__ unsigned long long sKey[kTailMax];
     __shared__ int sObj[kTailMax];
@@ -854,19 +859,21 @@ __global__ __launch_bounds__(kThreads) void k_tail(TailArgs a, E ed) {
     if (K == 0 || K > a.thr || nits >= max_iter) return;  // uniform
     if (kBlockOnly && K <= kTeamMax) return;
     if (kTeamOnly && (K <= 2 || K > kTeamMax)) return;
+    if (kDuoOnly && (K > 2 || !E::kCand || a.cand == nullptr)) return;
     // (budgeted launches: an instance that ran out of rounds leaves K to the NEXT launch's instance of the right role)
     if (!kBlockOnly && !kTeamOnly && a.round_budget > 0 && K > 2 && E::kCand && a.cand != nullptr) return;
     const int K0 = K;
     const long long nits0 = nits;
-    if (t < kTailMax) {
-        sU[t] = (t < K) ? a.U[t] : -1;
-        sStart[t] = (t < K) ? a.row_ptr[sU[t]] : 0;
+    for (int n = t; n < kTailMax; n += kThreads) {
+        sU[n] = (n < K) ? a.U[n] : -1;
+        sStart[n] = (n < K) ? a.row_ptr[sU[n]] : 0;
     }
-    for (int h = t; h < kHashSize; h += kThreads) {
-        hObj[h] = -1;
-        hKey[h] = 0ull;
-        hPos[h] = kPosNone;
-    }
+    if (!kDuoOnly)
+        for (int h = t; h < kHashSize; h += kThreads) {
+            hObj[h] = -1;
+            hKey[h] = 0ull;
+            hPos[h] = kPosNone;
+        }
     const double eps = (double)a.eps;
     TailStats st;
     st.edges = st.bids = st.hits = st.hit_edges = st.builds = 0ull;
@@ -909,6 +916,27 @@ __global__ __launch_bounds__(kThreads) void k_tail(TailArgs a, E ed) {
     };
     for (;;) {
         if (kBlockOnly && K <= kTeamMax) break;  // the next kernel takes over
+        if (kDuoOnly) {
+            // ---- K <= 2, lines: duo mode while two bidders are left (wavefronts 0 and 1, one bidder each), then
+            // wavefront 0 runs the single-bidder chain alone
+            mode_begin(0);
+            if (K == 2) tail_duo_mode(a, ed, sU, sStart, K, nits, max_iter, eps, st);
+            if (wave == 1) {
+                flush_stats();
+                return;
+            }
+            if (K == 1 && nits < max_iter) {
+                int pi = __builtin_amdgcn_readfirstlane(sU[0]), ps = __builtin_amdgcn_readfirstlane(sStart[0]);
+                tail_chain_mode(a, ed, pi, ps, K, nits, max_iter, eps, st);
+                if (lane == 0) {
+                    sU[0] = pi;
+                    sU[1] = -1;
+                    sStart[0] = ps;
+                }
+            }
+            mode_end(0);
+            break;  // K == 0 or nits == max_iter
+        }
         if (kTeamOnly) {
             if (K > 2 && nits < max_iter) {
                 mode_begin(1);
@@ -1220,7 +1248,7 @@ __global__ __launch_bounds__(kThreads) void k_tail(TailArgs a, E ed) {
         for (int k = 1; k <= 6; ++k) ctl->dbg[5 + k] += bacc[k];
 #endif
 
-    if (t < K0) a.U[t] = sU[t];
+    for (int n = t; n < K0; n += kThreads) a.U[n] = sU[n];
     flush_stats();
     if (t == 0) {
         ctl->K = K;

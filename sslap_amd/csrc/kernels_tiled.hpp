@@ -181,6 +181,30 @@ __global__ __launch_bounds__(256) void k_pack_seg4(const int *start, const int *
         seg4[k] = start[k] | (k < n ? (len[k] & 1) : 0);
 }
 
+// Overflow lists.  The tile loop of k_bid_tiled covers the first `cap` = 2 x lanes x depth edges of a (person, tile)
+// segment with its software-pipelined loads.  A longer segment (one in 37 at C3) used to be finished in a loop with a
+// load inside -- one exposed memory latency, behind the prefetches of the next step, in 58 % of all steps of a
+// wavefront and 40 % of its cycles (stamped build).  Now the edges beyond `cap` are listed per person -- their
+// tile-major positions, in stored order -- and looked at once, after the last tile, with prices from memory.
+__global__ __launch_bounds__(256) void k_ovf_count(const int *len, int n_rows, int T, int rb, int cap, int *ovf_cnt) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_rows; i += gridDim.x * blockDim.x) {
+        int c = 0;
+        for (int t = 0; t < T; ++t) c += max(len[tile_idx(i, t, T, rb)] - cap, 0);
+        ovf_cnt[i] = c;
+    }
+}
+__global__ __launch_bounds__(256) void k_ovf_fill(const int *len, const int *start, int n_rows, int T, int rb, int cap,
+                                                  const int *ovf_ptr, int *ovf_q) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_rows; i += gridDim.x * blockDim.x) {
+        int at = ovf_ptr[i];
+        for (int t = 0; t < T; ++t) {
+            const int idx = tile_idx(i, t, T, rb);
+            const int n = len[idx], s0 = start[idx];
+            for (int k = cap; k < n; ++k) ovf_q[at++] = s0 + k;
+        }
+    }
+}
+
 // pass 3: copy every edge to its tile-major position.  The copy is PACKED to 6 bytes per edge, two edges per 12-byte record
 //   { u16 slot0, u16 slot1, f32 val0, f32 val1 }
 // where slot = (col - tile * cols) + (tile & 1) * buf_stride is the index of the edge's price inside the kernel's
@@ -347,6 +371,13 @@ struct TiledArgs {
     int nnz;             // entries of the tile-major copy incl. padding (leftover loads are clamped below it)
     const int *order_person;  // bidders in person order and their list positions (partial rounds, see k_order_*);
     const int *order_pos;     // nullptr: list order (full scans: U is the identity)
+    const int *ovf_ptr;       // [n_rows + 1] overflow edges of a person: ovf_q[ovf_ptr[i] .. ovf_ptr[i + 1])
+    const int *ovf_q;         // ... their tile-major positions (k_ovf_fill); built for ovf_cap edges per segment
+    int ovf_cap;              // must equal 2 * lanes per person * loads per segment of the launch shape
+    // column-split shapes (kCS = 2): per-(column half, bidder slot) partial top-2, merged by k_tiled_merge
+    double2 *part_vw;         // [kCS][part_stride] {best value, second-best value}
+    int *part_g;              // [kCS][part_stride] tile-major position of the best edge (-1: no edge in that half)
+    int part_stride;
 };
 
 // All global loads of the tile loop are UNCONDITIONAL (masked-off lanes read a clamped, valid address and
@@ -367,8 +398,13 @@ struct TiledArgs {
 // TILE_COLS prices per LDS tile.  ABL (diagnostics only, results wrong): 1 = no LDS fill, 2 = no
 // per-element arithmetic, 3 = no edge loads, 4 = no barriers in the tile loop,
 // 5 = price look-ups without the arithmetic, 6 = arithmetic without the look-ups.
-template <int kTileThreads, int kTileRows, int kTileBatch, int kTileDepth, int kTileCols, int kLoaders, int ABL = 0, int kGL = 4>
+// kCS = 2 (column split): two workgroups share a slice of bidders and each sees HALF of the column tiles, i.e. half of
+// the price table -- per CU the tile fills (the whole table once per workgroup: 1.6 MB at C3, more than the 1.0 MB of
+// edges a CU streams) halve, and so do the barriers; a lane group then owns twice the persons (kTileRows = 8).  The two
+// partial top-2s of a bidder go to memory (20 bytes each) and k_tiled_merge forms the bid.
+template <int kTileThreads, int kTileRows, int kTileBatch, int kTileDepth, int kTileCols, int kLoaders, int ABL = 0, int kGL = 4, int kCS = 1>
 __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledArgs ta) {
+    static_assert(kCS == 1 || kCS == 2, "column split: none or two halves");
     static_assert(kGL == 4 || kGL == 8 || kGL == 16, "lanes per person: 4, 8 or 16 (one DPP row at most)");
     constexpr int kTileGroups = (kTileThreads - kLoaders * kWave) / kGL;  // kGL-lane groups; loader wavefronts own none
     // LDS (in doubles): buffer 0 at [0, kTileCols), the +inf slot at kTileCols, buffer 1 at [kBufDoubles, ...).
@@ -383,9 +419,10 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
     if (!round_live(ctl, a.thr) || ctl->K < ta.min_K) return;
     int lo, hi;
     shard_range(ctl->K, a.rank, a.world, a.shard_min_K, lo, hi);
-    // this workgroup's slice of list positions
-    const int per_wg = (hi - lo + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int p0 = lo + (int)blockIdx.x * per_wg;
+    // this workgroup's slice of list positions (and, with a column split, its half of the tiles)
+    const int n_slices = (int)gridDim.x / kCS, slice = (int)blockIdx.x / kCS, half = kCS > 1 ? (int)blockIdx.x % kCS : 0;
+    const int per_wg = (hi - lo + n_slices - 1) / n_slices;
+    const int p0 = lo + slice * per_wg;
     const int p1 = min(hi, p0 + per_wg);
     if (p0 >= p1) return;  // uniform over the workgroup
     const int t = threadIdx.x, lane = t & 63, gl = lane & (kGL - 1);
@@ -393,7 +430,8 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
     const double eps = (double)a.eps;
     const double ninf = -__builtin_huge_val();
     const int T = ta.T;
-    const int last = ta.nnz - 1;
+    const int t_lo = kCS > 1 ? min(T, half * ((T + kCS - 1) / kCS)) : 0;
+    const int t_hi = kCS > 1 ? min(T, t_lo + (T + kCS - 1) / kCS) : T;
     // The LDS-DMA pieces of a tile and a wavefront's own loads share one in-order counter (vmcnt): data of a
     // load issued AFTER a piece cannot be consumed before the piece has landed.  Two ways around it:
     //   kLoaders > 0: the last kLoaders wavefronts do nothing but the fills (wavefront specialisation);
@@ -428,6 +466,29 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
         sg[j] = -1;
     }
     if (t == 0) s_price[kTileCols] = __builtin_huge_val();
+#ifndef MISSLAP_TILED_SPLITBAR
+#define MISSLAP_TILED_SPLITBAR 0
+#endif
+    // MISSLAP_TILED_SPLITBAR: no workgroup barrier in the tile loop.  Two monotonic counters in LDS instead: `filled`
+    // counts (loader wavefront, tile) completions -- tile t has landed once filled >= kLoaders * (t + 1) -- and `done`
+    // counts (compute wavefront, tile) completions -- the buffer of tile t may be refilled (with tile t + 2) once
+    // done >= nCompute * (t + 1).  A compute wavefront then waits for ITS tile only, not for the slowest of sixteen
+    // wavefronts at every tile; wavefronts drift apart by up to one tile, which also takes them out of lockstep.
+    constexpr bool kSplit = MISSLAP_TILED_SPLITBAR && kLoaders > 0 && kDouble;
+    int *s_flag = reinterpret_cast<int *>(s_price + (kDouble ? kBufDoubles + kTileCols : kTileCols + 2)) + 3 * (kTileThreads / kWave);
+    auto flag_wait = [&](int which, int need) {  // every lane polls the same word (a broadcast read)
+        while (__hip_atomic_load(&s_flag[which], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");  // nothing of the tile is read (or refilled) ahead of the poll
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto flag_add = [&](int which) {
+        asm volatile("" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(&s_flag[which], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    if (kSplit) {
+        if (t == 0) s_flag[0] = s_flag[1] = 0;
+        __syncthreads();  // the only workgroup barrier: counters and the +inf slot are in place
+    }
     // an edge carries the slot of its price inside s_price (tile parity included, see k_tile_scatter)
     constexpr int kInfOff = kTileCols * 8;  // the +inf slot (behind buffer 0)
     // ... as an ABSOLUTE LDS address: s_price is the kernel's only LDS object and therefore starts at LDS address 0
@@ -473,11 +534,14 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
 #ifdef MISSLAP_TILED_LOADER_PRIO
         __builtin_amdgcn_s_setprio(MISSLAP_TILED_LOADER_PRIO);
 #endif
-        dma_fill(rot(0), me, kLoaders);
-        for (int tile = 0; tile < T; ++tile) {
+        if (t_lo < t_hi) dma_fill(rot(t_lo), me, kLoaders);
+        for (int tile = t_lo; tile < t_hi; ++tile) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my pieces of tile `tile` have landed
-            if (ABL != 4) __syncthreads();                    // ... and tile - 1 is no longer read
-            if (tile + 1 < T) {
+            if (kSplit) {
+                flag_add(0);
+                if (tile >= t_lo + 1 && tile + 1 < t_hi) flag_wait(1, (kWaves - kLoaders) * (tile - t_lo));  // tile - 1 is no longer read
+            } else if (ABL != 4) __syncthreads();             // ... and tile - 1 is no longer read
+            if (tile + 1 < t_hi) {
                 if (MISSLAP_TILED_THROTTLE >= 0) dma_fill_paced(rot(tile + 1), me, kLoaders);
                 else dma_fill(rot(tile + 1), me, kLoaders);
             }
@@ -489,9 +553,14 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
 #ifndef MISSLAP_TILED_PF
 #define MISSLAP_TILED_PF 1  // steps of edge loads in flight ahead of the one being consumed
 #endif
+    // The two raw table entries of a (person, tile) segment.  They are decoded (seg_s0 / seg_s1) only where a step
+    // USES them, steps after the load: decoded at the load site, the `& ~1` made every step wait, in its middle, for
+    // loads it had issued at its top (ISA: s_waitcnt vmcnt(3) / (2) behind the look-ups).
     struct Seg {
-        int s0[kTileBatch], s1[kTileBatch];
+        int x[kTileBatch], y[kTileBatch];
     };
+    auto seg_s0 = [](const Seg &g, int jj) { return g.x[jj] & ~1; };
+    auto seg_s1 = [](const Seg &g, int jj) { return (g.y[jj] & ~1) - (g.x[jj] & 1); };  // start + padded length - pad
     struct Edges {
         unsigned c[kTileBatch][kTileDepth];  // two 16-bit price slots
         int v0[kTileBatch][kTileDepth], v1[kTileBatch][kTileDepth];  // two fp32 values
@@ -508,8 +577,8 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
             const unsigned boff = (unsigned)tile_idx(pj >= 0 ? pj : 0, tl, T) << 2;
             typedef int v2i_t __attribute__((ext_vector_type(2), aligned(4)));  // this entry and the next one
             const v2i_t sp = *reinterpret_cast<const v2i_t *>(reinterpret_cast<const char *>(ta.seg4) + boff);
-            sg_.s0[jj] = sp.x & ~1;
-            sg_.s1[jj] = (sp.y & ~1) - (sp.x & 1);  // start + padded length - pad
+            sg_.x[jj] = sp.x;
+            sg_.y[jj] = sp.y;
         }
     };
     auto load_edges = [&](const Seg &sg_, Edges &e) {
@@ -518,11 +587,11 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
 #pragma unroll
             for (int d = 0; d < kTileDepth; ++d) {
                 if (ABL == 3) {
-                    e.c[jj][d] = (unsigned)(sg_.s0[jj] & 1023) * 0x10001u;
+                    e.c[jj][d] = (unsigned)(seg_s0(sg_, jj) & 1023) * 0x10001u;
                     e.v0[jj][d] = e.v1[jj][d] = gl;
                 } else {  // s0 is even: record s0 / 2; a group of kGL lanes covers 2 * kGL consecutive edges per load
                     typedef unsigned v3u_t __attribute__((ext_vector_type(3)));
-                    const unsigned boff = ((unsigned)sg_.s0[jj] >> 1) * 12u + (unsigned)(12 * gl);
+                    const unsigned boff = ((unsigned)seg_s0(sg_, jj) >> 1) * 12u + (unsigned)(12 * gl);
                     const char *src =  // + 12 * kGL * d bytes goes into the instruction's immediate offset
                         reinterpret_cast<const char *>(ta.tpk) + boff;
                     const v3u_t y = *reinterpret_cast<const v3u_t *>(src + 12 * kGL * d);
@@ -535,46 +604,81 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
     // Person rows beyond the workgroup's share are absent in every lane group (rows fill in order), so a round
     // with few bidders (K well below N: half of the launches of a solve) needs fewer steps per tile: the tile loop
     // is instantiated per number of person batches actually used.
+#ifdef MISSLAP_TILED_STAMP
+    // Diagnostic build (never the product): where a compute wavefront's cycles go -> Ctl::dbg[6..11], summed over all
+    // compute wavefronts of the launch: [6] total, [7] waiting at the tile barrier, [8] waiting for the step's edges
+    // (vmcnt), [9] look-ups + arithmetic of the step, [10] leftover loop, [11] number of wavefronts.
+    unsigned long long sacc[6] = {0, 0, 0, 0, 0, 0};
+    auto now = [&]() {
+        unsigned long long tt;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt)::"memory");
+        return tt;
+    };
+    const unsigned long long t_begin = now();
+#define MISSLAP_STAMP(K, EXPR)                      \
+    do {                                            \
+        __builtin_amdgcn_sched_barrier(0);          \
+        const unsigned long long t_a = now();       \
+        __builtin_amdgcn_sched_barrier(0);          \
+        EXPR;                                       \
+        __builtin_amdgcn_sched_barrier(0);          \
+        sacc[K] += now() - t_a;                     \
+        __builtin_amdgcn_sched_barrier(0);          \
+    } while (0)
+#else
+#define MISSLAP_STAMP(K, EXPR) \
+    do {                       \
+        EXPR;                  \
+    } while (0)
+#endif
     auto run_tiles = [&](auto nbe_) {
         constexpr int NBE = decltype(nbe_)::value;  // steps (person batches) per tile
-        Seg seg_cur, seg_nxt, seg_nx2;
-        Edges e_cur, e_nxt;
-        load_seg(0, 0, seg_cur);
-        load_seg(1 / NBE, 1 % NBE, seg_nxt);
-        load_edges(seg_cur, e_cur);
-#if MISSLAP_TILED_PF == 2
-        Seg seg_nx3;
-        Edges e_nx2;
-        load_seg(2 / NBE, 2 % NBE, seg_nx2);
-        load_edges(seg_nxt, e_nxt);
+#ifndef MISSLAP_TILED_SEGPF
+#define MISSLAP_TILED_SEGPF 0  // extra steps of lead of the segment-table loads over the edge loads that need them
 #endif
-        if (kLoaders == 0 && kDouble) dma_fill(rot(0), wave_u, kWaves);
-        for (int tile = 0; tile < (loader ? 0 : T); ++tile) {
+        // Queues of the pipeline: a step issues the edge loads of step s + kE -- their addresses come from the segment
+        // entries of that step, which must have landed at the top of step s -- and the segment loads of step s + kQ.
+        // kQ = kE + 1 makes those entries the youngest loads of the previous step; one more step of lead
+        // (MISSLAP_TILED_SEGPF = 1, + 16 VGPRs) and / or a second step of edges in flight (MISSLAP_TILED_PF = 2) were
+        // measured on the round-3 kernel: 91.4 / 90.8 us against 90.5 (C3 full scan in a solve) -- the wavefronts do not
+        // wait for their own loads (stamped build: 1-2 % of their cycles), they wait at the tile barrier and in the
+        // issue queue of the CU's memory path, which the fills and the edge loads share.
+        constexpr int kE = MISSLAP_TILED_PF, kQ = kE + 1 + MISSLAP_TILED_SEGPF;
+        Seg sq[kQ + 1];
+        Edges eq[kE + 1];
+#pragma unroll
+        for (int k = 0; k < kQ; ++k) load_seg(t_lo + k / NBE, k % NBE, sq[k]);
+#pragma unroll
+        for (int k = 0; k < kE; ++k) load_edges(sq[k], eq[k]);
+        Seg &seg_cur = sq[0];
+        Edges &e_cur = eq[0];
+        if (kLoaders == 0 && kDouble) dma_fill(rot(t_lo), wave_u, kWaves);
+        for (int tile = t_lo; tile < (loader ? t_lo : t_hi); ++tile) {
             if (!kDouble) {
                 __syncthreads();  // every lookup of the previous tile is done
                 dma_fill(rot(tile), wave_u, kWaves);
             }
             if (kLoaders == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my pieces of this tile
-            if (ABL != 4) __syncthreads();  // every piece of this tile has landed; the other buffer may be refilled
+            if (kSplit) MISSLAP_STAMP(1, flag_wait(0, kLoaders * (tile - t_lo + 1)));  // every piece of this tile has landed
+            else MISSLAP_STAMP(1, if (ABL != 4) __syncthreads());  // every piece of this tile has landed; the other buffer may be refilled
 #pragma unroll
             for (int b = 0; b < NBE; ++b) {
-                // issue: edges of the next step, segment pointers of the step after it
-                const int n2t = tile + (b + 2) / NBE, n2b = (b + 2) % NBE;
-#if MISSLAP_TILED_PF == 2
-                load_edges(seg_nx2, e_nx2);
-                load_seg(tile + (b + 3) / NBE, (b + 3) % NBE, seg_nx3);
-                (void)n2t, (void)n2b;
-#else
-                load_edges(seg_nxt, e_nxt);  // (a prefetch distance of two steps measured no faster)
-                load_seg(n2t, n2b, seg_nx2);
+                // issue: edges of step s + kE, segment entries of step s + kQ
+                load_edges(sq[kE], eq[kE]);
+                load_seg(tile + (b + kQ) / NBE, (b + kQ) % NBE, sq[kQ]);
+                if (kDouble && kLoaders == 0 && b == 0 && tile + 1 < t_hi) dma_fill(rot(tile + 1), wave_u, kWaves);
+#ifdef MISSLAP_TILED_STAMP
+                // this step's edges: everything but the loads just issued (edges of the next step + two segment entries
+                // per person of the step after it)
+                MISSLAP_STAMP(2, asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kTileBatch * kTileDepth * kE + kTileBatch * (kE + 1)) : "memory"));
+                const unsigned long long t_c = now();
 #endif
-                if (kDouble && kLoaders == 0 && b == 0 && tile + 1 < T) dma_fill(rot(tile + 1), wave_u, kWaves);
                 // consume step (tile, b): first ALL price look-ups of a depth range (independent ds_reads, one wait),
                 // then the arithmetic -- a look-up followed by its use costs one LDS latency per element
                 int rem[kTileBatch];  // real elements of the segment from this lane's first one on
 #pragma unroll
                 for (int jj = 0; jj < kTileBatch; ++jj)
-                    rem[jj] = (person[b * kTileBatch + jj] >= 0 ? seg_cur.s1[jj] - seg_cur.s0[jj] : 0) - 2 * gl;
+                    rem[jj] = (person[b * kTileBatch + jj] >= 0 ? seg_s1(seg_cur, jj) - seg_s0(seg_cur, jj) : 0) - 2 * gl;
                 auto consume = [&](const int dlo, const int dhi) {
                     double prs[kTileBatch][kTileDepth][2];
 #pragma unroll
@@ -596,7 +700,7 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
 #pragma unroll
                     for (int jj = 0; jj < kTileBatch; ++jj) {
                         const int j = b * kTileBatch + jj;
-                        const int q0 = seg_cur.s0[jj] + 2 * gl;
+                        const int q0 = seg_s0(seg_cur, jj) + 2 * gl;
 #pragma unroll
                         for (int d = dlo; d < dhi; ++d) {
                             if (ABL == 2) {
@@ -636,49 +740,23 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
                     for (int jj = 0; jj < kTileBatch; ++jj) more_d |= rem[jj] > 2 * kGL * kFastDepth;
                     if (__any(more_d)) consume(kFastDepth, kTileDepth);
                 }
-                // segments longer than 8 * kTileDepth edges: wave-uniform loop with the loads of the whole batch
-                // issued together (a per-segment `for` with a load inside costs one HBM latency per segment)
-                if (ABL == 0) {
-                    int qx[kTileBatch], s1x[kTileBatch];
-                    bool more = false;
-#pragma unroll
-                    for (int jj = 0; jj < kTileBatch; ++jj) {
-                        qx[jj] = seg_cur.s0[jj] + gl + 2 * kGL * kTileDepth;  // one edge per lane and pass from here on
-                        s1x[jj] = person[b * kTileBatch + jj] >= 0 ? seg_cur.s1[jj] : seg_cur.s0[jj];
-                        more |= qx[jj] < s1x[jj];
-                    }
-                    while (__any(more)) {
-                        int2 y[kTileBatch];  // {price slot, fp32 bits} of entry qx
-#pragma unroll
-                        for (int jj = 0; jj < kTileBatch; ++jj) {
-                            const int qc = min(qx[jj], last);
-                            y[jj].x = reinterpret_cast<const unsigned short *>(ta.tpk)[(qc >> 1) * 6 + (qc & 1)];
-                            y[jj].y = (int)ta.tpk[(qc >> 1) * 3 + 1 + (qc & 1)];
-                        }
-                        more = false;
-#pragma unroll
-                        for (int jj = 0; jj < kTileBatch; ++jj) {
-                            const int j = b * kTileBatch + jj;
-                            const bool ok = qx[jj] < s1x[jj];
-                            const double pr = lds_price(ok ? y[jj].x << 3 : kInfOff);
-                            const double v = (double)__int_as_float(y[jj].y) - pr;
-                            const bool ge = ok & (MISSLAP_TILED_ROT ? ((v > sv[j]) | ((v == sv[j]) & (qx[jj] > sg[j]))) : (v >= sv[j]));
-                            sw[j] = __builtin_fmax(sw[j], __builtin_fmin(v, sv[j]));
-                            sv[j] = __builtin_fmax(sv[j], v);
-                            sg[j] = ge ? qx[jj] : sg[j];
-                            qx[jj] += kGL;
-                            more |= qx[jj] < s1x[jj];
-                        }
-                    }
-                }
-                seg_cur = seg_nxt;
-                seg_nxt = seg_nx2;
-                e_cur = e_nxt;
-#if MISSLAP_TILED_PF == 2
-                seg_nx2 = seg_nx3;
-                e_nxt = e_nx2;
+#ifdef MISSLAP_TILED_STAMP
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned long long t_l = now();
+                sacc[3] += t_l - t_c;
 #endif
+                // (segments longer than 2 * kGL * kTileDepth edges: their tail is on the person's overflow list, looked
+                // at after the last tile -- no load inside the tile loop)
+#ifdef MISSLAP_TILED_STAMP
+                __builtin_amdgcn_sched_barrier(0);
+                sacc[4] += now() - t_l;
+#endif
+#pragma unroll
+                for (int k = 0; k < kQ; ++k) sq[k] = sq[k + 1];
+#pragma unroll
+                for (int k = 0; k < kE; ++k) eq[k] = eq[k + 1];
             }
+            if (kSplit) flag_add(1);  // my look-ups of this tile are done (LDS operations of a wavefront execute in order)
         }
     };
     {
@@ -690,6 +768,87 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
             run_tiles(std::integral_constant<int, (kNB > 2 ? 2 : 1)>{});
         else
             run_tiles(std::integral_constant<int, kNB>{});
+    }
+#ifdef MISSLAP_TILED_STAMP
+    if (!loader && lane == 0) {
+        atomicAdd(&a.ctl->dbg[6], now() - t_begin);
+        for (int k = 1; k <= 4; ++k) atomicAdd(&a.ctl->dbg[6 + k], sacc[k]);
+        atomicAdd(&a.ctl->dbg[11], 1ull);
+    }
+#endif
+    // overflow edges (see k_ovf_count): lane gl of a person's group takes entries gl, gl + kGL, ... of its list; the price
+    // comes from memory (the table the tiles were filled from), the update is the same with the tie rule spelled out
+    // -- these edges are met out of stored order, so among equal values the later stored POSITION must win (:351)
+    if (ABL == 0 && !loader) {
+        if (t == 0 && ta.ovf_cap != 2 * kGL * kTileDepth) atomicOr(&a.ctl->err, kErrLdsBase);
+        // (four persons at a time: with eight persons per lane group the lists of all of them together would not fit
+        // the registers next to the running top-2s)
+        constexpr int kOB = kTileRows < 4 ? kTileRows : 4;
+#pragma unroll
+        for (int j0 = 0; j0 < kTileRows; j0 += kOB) {
+            int oi[kOB], oe[kOB];
+            int ql[kOB], qh[kOB];  // (column split) the tile-major positions of my tiles inside the person's block
+            bool more = false;
+#pragma unroll
+            for (int jj = 0; jj < kOB; ++jj) {
+                const int j = j0 + jj;
+                const int pj = max(person[j], 0);
+                typedef int v2i_t __attribute__((ext_vector_type(2), aligned(4)));
+                const v2i_t pp = *reinterpret_cast<const v2i_t *>(ta.ovf_ptr + pj);
+                oi[jj] = pp.x + gl;
+                oe[jj] = person[j] >= 0 ? pp.y : pp.x;
+                more |= oi[jj] < oe[jj];
+                ql[jj] = qh[jj] = 0;
+                if (kCS > 1) {  // positions grow with (block, tile, person): tile t of a block starts at its first person's entry
+                    const int blk = pj / kTileRB;
+                    ql[jj] = ta.seg4[(blk * T + t_lo) * kTileRB] & ~1;
+                    qh[jj] = ta.seg4[(blk * T + t_hi) * kTileRB] & ~1;
+                }
+            }
+            while (__any(more)) {
+                int q[kOB], col[kOB], vb[kOB];
+                double pr[kOB];
+#pragma unroll
+                for (int jj = 0; jj < kOB; ++jj) q[jj] = ta.ovf_q[oi[jj] < oe[jj] ? oi[jj] : 0];
+#pragma unroll
+                for (int jj = 0; jj < kOB; ++jj) {
+                    col[jj] = ta.tcol[q[jj]];
+                    vb[jj] = (int)ta.tpk[(q[jj] >> 1) * 3 + 1 + (q[jj] & 1)];
+                }
+#pragma unroll
+                for (int jj = 0; jj < kOB; ++jj) pr[jj] = a.price[col[jj]];
+                more = false;
+#pragma unroll
+                for (int jj = 0; jj < kOB; ++jj) {
+                    const int j = j0 + jj;
+                    const bool ok = (oi[jj] < oe[jj]) & (kCS == 1 || ((q[jj] >= ql[jj]) & (q[jj] < qh[jj])));
+                    const double v = ok ? (double)__int_as_float(vb[jj]) - pr[jj] : ninf;  // vi = cost - p[j]   (:350)
+                    const bool ge = ok & ((v > sv[j]) | ((v == sv[j]) & (q[jj] > sg[j])));    // :351, by stored position
+                    sw[j] = __builtin_fmax(sw[j], __builtin_fmin(v, sv[j]));                // :353 / :357-358
+                    sv[j] = __builtin_fmax(sv[j], v);
+                    sg[j] = ge ? q[jj] : sg[j];
+                    oi[jj] += kGL;
+                    more |= oi[jj] < oe[jj];
+                }
+            }
+        }
+    }
+    if (kCS > 1) {  // the partial top-2 of my half of the tiles: one lane per person writes it
+        if (!loader) {
+#pragma unroll
+            for (int j = 0; j < kTileRows; ++j) {
+                const double V = group_max_f64<kGL>(sv[j]);
+                const int G = group_max_i32<kGL>(sv[j] == V ? sg[j] : -1);
+                const double Wj = group_max_f64<kGL>(sg[j] == G ? sw[j] : sv[j]);
+                const bool writer = G >= 0 ? sg[j] == G : gl == 0;  // (G < 0: the person has no edge in these tiles)
+                if (person[j] >= 0 && writer) {
+                    const size_t at = (size_t)half * ta.part_stride + (size_t)(p0 + j * kTileGroups + group);
+                    ta.part_vw[at] = make_double2(V, G >= 0 ? Wj : ninf);
+                    ta.part_g[at] = G;
+                }
+            }
+        }
+        return;
     }
     // merge the 8 lanes of each group, once per person (same three all-reduces as top2_wave_reduce)
     unsigned long long edges = 0;
@@ -751,6 +910,75 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
             te += s_e[w];
             tb += s_n[w];
         }
+        if (tb) {
+            atomicAdd(&a.ctl->edges, te);
+            if (a.world > 1 && a.ctl->K >= a.shard_min_K) atomicAdd(&a.ctl->shard_edges, te);
+            atomicAdd(&a.ctl->bids, (unsigned long long)tb);
+            if (a.launch_edges) atomicAdd(&a.launch_edges[a.launch_idx], te);
+        }
+    }
+}
+
+// The second launch of a column-split shape: one thread per bidder slot merges the two partial top-2s with the merge
+// operator of the reduction (the later stored position wins a tie: positions of a person grow with the tile), forms the
+// bid (:360), publishes it and feeds the per-object maximum exactly like the epilogue of the unsplit kernel.
+// (At most 128 workgroups of 1024 threads and ONE set of statistics atomics per workgroup: the counters are single
+// words, and ~10 000 same-address atomics -- one set per wavefront of a 782-block grid -- took longer than the scan.)
+__global__ __launch_bounds__(1024) void k_tiled_merge(RoundArgs a, TiledArgs ta) {
+    __shared__ unsigned long long s_e[16];
+    __shared__ int s_n[16], s_err[16];
+    const Ctl *ctl = a.ctl;
+    if (!round_live(ctl, a.thr) || ctl->K < ta.min_K) return;
+    int lo, hi;
+    shard_range(ctl->K, a.rank, a.world, a.shard_min_K, lo, hi);
+    const double eps = (double)a.eps;
+    unsigned long long edges = 0;
+    int nb = 0, err = 0;
+    for (int slot = lo + (int)(blockIdx.x * blockDim.x + threadIdx.x); slot < hi; slot += (int)(gridDim.x * blockDim.x)) {
+        const double2 A = ta.part_vw[slot], B = ta.part_vw[(size_t)ta.part_stride + slot];
+        const int ga = ta.part_g[slot], gb = ta.part_g[(size_t)ta.part_stride + slot];
+        const bool takeB = (gb >= 0) & ((ga < 0) | (B.x > A.x) | ((B.x == A.x) & (gb > ga)));
+        const int G = takeB ? gb : ga;
+        const double W = takeB ? __builtin_fmax(B.y, ga >= 0 ? A.x : -__builtin_huge_val())
+                               : __builtin_fmax(A.y, gb >= 0 ? B.x : -__builtin_huge_val());
+        const int person = (ta.order_person ? ta.order_person : a.U)[slot];
+        const int pos = ta.order_pos ? ta.order_pos[slot] : slot;
+        if (G < 0) {
+            err |= kErrRowGap;  // a bidder without a single edge: the ingest excludes it
+            continue;
+        }
+        const int col = ta.tcol[G];
+        const double cost = (double)__int_as_float((int)ta.tpk[(G >> 1) * 3 + 1 + (G & 1)]);
+        const double bid = (cost - W) + eps;  // :360
+        if (bid_is_bad(bid)) err |= kErrNegativeBid;
+        const unsigned long long key = bid_to_key(bid);
+        a.bid_key[pos] = key;
+        a.bid_obj[pos] = col;
+        atomicMax(&a.best_key[col], key);
+        edges += (unsigned long long)(a.row_ptr[person + 1] - a.row_ptr[person]);
+        nb += 1;
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        edges += ((unsigned long long)__shfl_xor((unsigned)(edges >> 32), off) << 32) |
+                 (unsigned long long)__shfl_xor((unsigned)(edges & 0xffffffffull), off);
+        nb += __shfl_xor(nb, off);
+        err |= __shfl_xor(err, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_e[threadIdx.x >> 6] = edges;
+        s_n[threadIdx.x >> 6] = nb;
+        s_err[threadIdx.x >> 6] = err;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long te = 0;
+        int tb = 0, terr = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) {
+            te += s_e[w];
+            tb += s_n[w];
+            terr |= s_err[w];
+        }
+        if (terr) atomicOr(&a.ctl->err, terr);
         if (tb) {
             atomicAdd(&a.ctl->edges, te);
             if (a.world > 1 && a.ctl->K >= a.shard_min_K) atomicAdd(&a.ctl->shard_edges, te);

@@ -101,25 +101,26 @@ constexpr int kDefaultRoundsPerSync = 16;
 constexpr int kRoundsPerSyncLargeK = 2;  // batch length while K > kRoundSmallMax
 constexpr int kMaxGridBlocks = 2048;  // 256 CUs x 8 resident 256-thread blocks
 constexpr int kNumTiledShapes = 10;
-// (shape 0 is the default: three loader wavefronts measured 1-2 % faster than one inside a solve; shape 4 -- eight
-// persons per 8-lane group, one load per segment -- spilled 34 VGPRs and was retired: selecting it is an error)
+// (shape 0: three loader wavefronts measured 1-2 % faster than one inside a solve; the round-2 shape 4 -- eight persons
+// per 8-lane group, one load per segment -- spilled 34 VGPRs and was retired: the index now names the column-split
+// variant of shape 0)
 // launch shapes of k_bid_tiled: {threads, persons per lane group, persons in flight, loads per segment,
-// prices per LDS tile, loader wavefronts, lanes per person}; see kernels_tiled.hpp
-const int kTiledShapes[kNumTiledShapes][7] = {
-    {1024, 4, 2, 2, kTileColsHalf, 3, 4}, {1024, 4, 2, 2, kTileColsHalf, 0, 4}, {1024, 4, 2, 3, kTileColsBig, 0, 4},
-    {1024, 4, 2, 2, kTileColsHalf, 1, 4}, {0, 0, 0, 0, 0, 0, 0} /* retired */, {1024, 4, 1, 2, kTileColsHalf, 1, 4},
-    {1024, 4, 2, 3, kTileColsHalf, 1, 4}, {1024, 4, 2, 2, kTileColsHalf, 2, 4},
-    // longer (person, tile) segments: 8 / 16 lanes per person, i.e. 32 / 64 edges per step without the leftover loop
-    {1024, 4, 2, 2, kTileColsHalf, 3, 8}, {1024, 4, 2, 2, kTileColsHalf, 3, 16}};
+// prices per LDS tile, loader wavefronts, lanes per person, column split}; see kernels_tiled.hpp
+const int kTiledShapes[kNumTiledShapes][8] = {
+    {1024, 4, 2, 2, kTileColsHalf, 3, 4, 1}, {1024, 4, 2, 2, kTileColsHalf, 0, 4, 1}, {1024, 4, 2, 3, kTileColsBig, 0, 4, 1},
+    {1024, 4, 2, 2, kTileColsHalf, 1, 4, 1}, {1024, 8, 2, 2, kTileColsHalf, 3, 4, 2}, {1024, 4, 1, 2, kTileColsHalf, 1, 4, 1},
+    {1024, 4, 2, 3, kTileColsHalf, 1, 4, 1}, {1024, 4, 2, 2, kTileColsHalf, 2, 4, 1},
+    // longer (person, tile) segments: 8 / 16 lanes per person, i.e. 32 / 64 edges per step
+    {1024, 4, 2, 2, kTileColsHalf, 3, 8, 1}, {1024, 4, 2, 2, kTileColsHalf, 3, 16, 1}};
 #define MISSLAP_FOR_TILED_SHAPES(X)                                                                                  \
-    X(0, 1024, 4, 2, 2, kTileColsHalf, 3, 4) X(1, 1024, 4, 2, 2, kTileColsHalf, 0, 4)                                \
-    X(2, 1024, 4, 2, 3, kTileColsBig, 0, 4) X(3, 1024, 4, 2, 2, kTileColsHalf, 1, 4)                                 \
-    X(5, 1024, 4, 1, 2, kTileColsHalf, 1, 4)                                                                         \
-    X(6, 1024, 4, 2, 3, kTileColsHalf, 1, 4) X(7, 1024, 4, 2, 2, kTileColsHalf, 2, 4)                                \
-    X(8, 1024, 4, 2, 2, kTileColsHalf, 3, 8) X(9, 1024, 4, 2, 2, kTileColsHalf, 3, 16)
+    X(0, 1024, 4, 2, 2, kTileColsHalf, 3, 4, 1) X(1, 1024, 4, 2, 2, kTileColsHalf, 0, 4, 1)                          \
+    X(2, 1024, 4, 2, 3, kTileColsBig, 0, 4, 1) X(3, 1024, 4, 2, 2, kTileColsHalf, 1, 4, 1)                           \
+    X(4, 1024, 8, 2, 2, kTileColsHalf, 3, 4, 2) X(5, 1024, 4, 1, 2, kTileColsHalf, 1, 4, 1)                          \
+    X(6, 1024, 4, 2, 3, kTileColsHalf, 1, 4, 1) X(7, 1024, 4, 2, 2, kTileColsHalf, 2, 4, 1)                          \
+    X(8, 1024, 4, 2, 2, kTileColsHalf, 3, 8, 1) X(9, 1024, 4, 2, 2, kTileColsHalf, 3, 16, 1)
 inline size_t tiled_lds_bytes(int tile_cols) {  // see the LDS map in k_bid_tiled; + statistics scratch
     const size_t doubles = tile_cols == kTileColsBig ? (size_t)tile_cols + 2 : 2 * (size_t)tile_cols + 128;
-    return doubles * sizeof(double) + 16 * 12;
+    return doubles * sizeof(double) + 16 * 12 + 16;  // + statistics scratch + the two tile counters
 }
 
 // Profiled launches (options.profile): the two events are handed to the launch itself (hipExtLaunchKernel), so they
@@ -198,6 +199,10 @@ struct misslap_solver {
     int2 *tiled = nullptr;
     int *seg4 = nullptr;  // k_bid_tiled's 4-byte segment table
     int *tcol = nullptr;  // real columns of the tile-major copy (k_bid_tiled stores LDS offsets in `tiled`)
+    int *ovf_ptr = nullptr, *ovf_q = nullptr;  // per-person lists of the edges beyond ovf_cap in a (person, tile) segment
+    int ovf_cap = 0;
+    double2 *part_vw = nullptr;  // column-split launch shapes: per-(column half, bidder slot) partial top-2 (k_tiled_merge)
+    int *part_g = nullptr;
     int n_tiled = 0;  // entries of `tiled` including the padding entries
     int T = 0;
     bool tiled_ok = false;
@@ -492,12 +497,14 @@ int launch_bid_tiled(misslap_solver *h) {
     const int *shp = kTiledShapes[h->tiled_shape];
     const int groups = (shp[0] - 64 * shp[5]) / shp[6];  // lane groups; loader wavefronts own no persons
     const int per_wg_max = groups * shp[1];
+    const int cs = shp[7];  // column split: `cs` workgroups share a slice of bidders, each with 1 / cs of the tiles
     long long grid = (share + per_wg_max - 1) / per_wg_max;
-    const long long resident = h->n_cus;  // one workgroup per CU: its two price tiles take the whole LDS
+    const long long resident = h->n_cus / cs;  // one workgroup per CU: its two price tiles take the whole LDS
     const long long spread = std::min<long long>(resident, (share + groups - 1) / groups);
     if (grid < spread) grid = spread;
+    grid *= cs;
     TiledArgs ta{reinterpret_cast<const unsigned *>(h->tiled), h->tcol, h->seg4, h->T, h->tiled_min_K, h->n_tiled,
-                 nullptr, nullptr};
+                 nullptr, nullptr, h->ovf_ptr, h->ovf_q, h->ovf_cap, h->part_vw, h->part_g, h->n_rows};
     // A partial round whose K the host knows: bidders in person order (kernels_tiled.hpp, k_order_*).  Scratch that
     // is idle during a bid phase: the compaction lists (the tie-break reads order_pos before they are rewritten),
     // the chunk counters, the objective's match counters.
@@ -525,11 +532,23 @@ int launch_bid_tiled(misslap_solver *h) {
     const size_t lds = tiled_lds_bytes(shp[4]);
     const dim3 g((unsigned)grid);
     switch (h->tiled_shape) {
-#define X(I, TH, R, B, D, TC, LD, GL) \
-    case I: MISSLAP_LAUNCH_TIMED(pr, (k_bid_tiled<TH, R, B, D, TC, LD, 0, GL>), g, dim3(TH), (unsigned)lds, h->stream, a, ta); break;
+#define X(I, TH, R, B, D, TC, LD, GL, CS) \
+    case I: MISSLAP_LAUNCH_TIMED(pr, (k_bid_tiled<TH, R, B, D, TC, LD, 0, GL, CS>), g, dim3(TH), (unsigned)lds, h->stream, a, ta); break;
         MISSLAP_FOR_TILED_SHAPES(X)
 #undef X
         default: return fail(MISSLAP_ERR_STATE, "bad tiled shape");
+    }
+    if (cs > 1) {
+        // the second launch of a column-split shape merges the halves' partial top-2s into the bids.  A profiled launch
+        // is timed from the begin of the scan kernel to the end of the merge kernel (the gap between them included).
+        const dim3 mg((unsigned)std::min<long long>(128, (share + 1023) / 1024)), mb(1024);
+        if (pr && !plain_events()) {
+            // (the scan kernel's own end timestamp went into pr->stop above; the merge launch overwrites it)
+            hipExtLaunchKernelGGL(k_tiled_merge, mg, mb, 0, h->stream, nullptr, pr->stop, 0, a, ta);
+        } else {
+            hipLaunchKernelGGL(k_tiled_merge, mg, mb, 0, h->stream, a, ta);
+            if (pr) (void)hipEventRecord(pr->stop, h->stream);
+        }
     }
     HIP_TRY(hipGetLastError());
     return MISSLAP_OK;
@@ -657,7 +676,8 @@ int launch_tail(misslap_solver *h) {
     const EdgesF64 e64{h->col, h->val64};
     // every line checked at today's prices (kernels_round.hpp); then the rounds with more than kTeamMax bidders, with
     // sixteen wavefronts (kernels_tail.hpp); then -- lines only -- the rounds with 3..kTeamMax bidders, one list slot
-    // per wavefront; then the rest
+    // per wavefront; then the rest: with lines the two-wavefront duo / chain instance, without them the 512-thread
+    // instance that holds every mode
 #define MISSLAP_LAUNCH_TAIL(E, ED)                                                                                       \
     do {                                                                                                                 \
         if (h->cand && h->line_maintenance)                                                                              \
@@ -675,7 +695,8 @@ int launch_tail(misslap_solver *h) {
             hipLaunchKernelGGL((k_tail<E, 2 * kTailMax>), dim3(1), dim3(2 * kTailMax), 0, h->stream, a, ED);             \
         if (h->K_ub > 2 && h->cand)                                                                                      \
             hipLaunchKernelGGL((k_tail<E, 2 * kTailMax, true>), dim3(1), dim3(2 * kTailMax), 0, h->stream, a, ED);       \
-        hipLaunchKernelGGL((k_tail<E, kTailMax>), dim3(1), dim3(kTailMax), 0, h->stream, a, ED);                         \
+        if (h->cand) hipLaunchKernelGGL((k_tail<E, 2 * kWave>), dim3(1), dim3(2 * kWave), 0, h->stream, a, ED);          \
+        else hipLaunchKernelGGL((k_tail<E, kTailMax>), dim3(1), dim3(kTailMax), 0, h->stream, a, ED);                    \
     } while (0)
     if (h->f32) MISSLAP_LAUNCH_TAIL(EdgesF32, e32);
     else MISSLAP_LAUNCH_TAIL(EdgesF64, e64);
@@ -835,8 +856,7 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
     // launch shape: options.reserved[1] = k + 1 picks shape k (tuning); 0 = by the average (person, tile) segment length
     const bool shape_auto = !(opt->tiled_shape >= 1 && opt->tiled_shape <= kNumTiledShapes);
     h->tiled_shape = shape_auto ? 0 : opt->tiled_shape - 1;
-    if (kTiledShapes[h->tiled_shape][0] == 0)
-        return fail(MISSLAP_ERR_INVALID, "k_bid_tiled launch shape %d was retired", h->tiled_shape);
+
     const int tiled_opt = opt->tiled_min_K;  // 0 default, < 0 never, > 0 minimum K for the full-scan engines
     size_t Mpad = M;
     const bool forced_engine = opt->tiled_force != 0 && tiled_opt > 0;  // tests / tuning: any size
@@ -878,12 +898,42 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
             hipLaunchKernelGGL(k_scan_sums, dim3(nchunks), dim3(1024), 0, h->stream, cnt, L, sums);
             hipLaunchKernelGGL(k_scan_of_sums, dim3(1), dim3(1024), 0, h->stream, sums, nchunks);
             hipLaunchKernelGGL(k_scan_apply, dim3(nchunks), dim3(1024), 0, h->stream, cnt, L, sums, start);
-            int unsorted = 0, total = 0;
+            // overflow lists (kernels_tiled.hpp, k_ovf_count): the edges of a (person, tile) segment beyond what the launch
+            // shape's pipelined loads cover.  `cnt` is free again: per-person counts, then their scan
+            const int *shp0 = kTiledShapes[h->tiled_shape];
+            h->ovf_cap = 2 * shp0[6] * shp0[3];
+            {
+                DevBlock blk;
+                blk.want(&h->ovf_ptr, N + 2);
+                h->blocks.emplace_back();
+                if ((rc = blk.commit(&h->blocks.back()))) return rc;
+            }
+            const int nch = (int)(((long long)N + 1 + kScanChunk - 1) / kScanChunk);
+            hipLaunchKernelGGL(k_ovf_count, dim3(blocks_for((long long)N, 256)), dim3(256), 0, h->stream, len, h->n_rows, T, rb,
+                               h->ovf_cap, cnt);
+            hipLaunchKernelGGL(k_scan_sums, dim3(nch), dim3(1024), 0, h->stream, cnt, (long long)N, sums);
+            hipLaunchKernelGGL(k_scan_of_sums, dim3(1), dim3(1024), 0, h->stream, sums, nch);
+            hipLaunchKernelGGL(k_scan_apply, dim3(nch), dim3(1024), 0, h->stream, cnt, (long long)N, sums, h->ovf_ptr);
+            int unsorted = 0, total = 0, n_ovf = 0;
             HIP_TRY(hipMemcpyAsync(&unsorted, flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(hipMemcpyAsync(&total, start + L, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipMemcpyAsync(&n_ovf, h->ovf_ptr + N, sizeof(int), hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(hipStreamSynchronize(h->stream));
-            if (!unsorted && total > 0 && total < 0x1ffffff0) {
+            // The engine pays where segments fit the pipelined loads.  Where more than 1 / 16 of the edges would sit on
+            // overflow lists (rows that are dense inside a tile: the `mat=` shapes) the wave-per-row scan is the better
+            // full-scan kernel anyway -- a dense row reads the price table in order -- and the second copy is not built.
+            const bool fits = forced || (long long)n_ovf * 16 <= (long long)nnz;
+            if (!unsorted && total > 0 && total < 0x1ffffff0 && fits) {
                 h->n_tiled = total;
+                {
+                    DevBlock blk;
+                    blk.want(&h->ovf_q, (size_t)n_ovf + 1);
+                    h->blocks.emplace_back();
+                    if ((rc = blk.commit(&h->blocks.back()))) return rc;
+                }
+                HIP_TRY(hipMemsetAsync(h->ovf_q, 0, sizeof(int), h->stream));  // (entry 0 is read by idle lanes)
+                hipLaunchKernelGGL(k_ovf_fill, dim3(blocks_for((long long)N, 256)), dim3(256), 0, h->stream, len, start,
+                                   h->n_rows, T, rb, h->ovf_cap, h->ovf_ptr, h->ovf_q);
                 {
                     DevBlock blk;
                     blk.want(&h->tiled, (size_t)total + 16);
@@ -912,9 +962,9 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
                     // per create, i.e. per device: the > 64 KB dynamic-LDS opt-in is a property of the function ON
                     // the current device, so a process-wide "done" flag would leave a second device without it
                     switch (h->tiled_shape) {
-#define X(I, TH, R, B, D, TC, LD, GL)                                                                               \
+#define X(I, TH, R, B, D, TC, LD, GL, CS)                                                                           \
     case I:                                                                                                          \
-        HIP_TRY(hipFuncSetAttribute((const void *)k_bid_tiled<TH, R, B, D, TC, LD, 0, GL>, at,                     \
+        HIP_TRY(hipFuncSetAttribute((const void *)k_bid_tiled<TH, R, B, D, TC, LD, 0, GL, CS>, at,                     \
                                     (int)tiled_lds_bytes(TC)));                                                      \
         break;
                         MISSLAP_FOR_TILED_SHAPES(X)
@@ -948,6 +998,10 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
         blk.want(&h->ctl, 1);
         blk.want(&h->contrib, N);
         blk.want(&h->nmatch, N);
+        if (h->tiled_ok && kTiledShapes[h->tiled_shape][7] > 1) {
+            blk.want(&h->part_vw, (size_t)kTiledShapes[h->tiled_shape][7] * N);
+            blk.want(&h->part_g, (size_t)kTiledShapes[h->tiled_shape][7] * N);
+        }
         if (h->profile) {
             h->launch_edges_cap = 1 << 20;
             blk.want(&h->launch_edges, (size_t)h->launch_edges_cap);
@@ -1687,7 +1741,7 @@ MISSLAP_API int misslap_finish(misslap_solver *h, int32_t *person_to_object_out,
     for (int k = 0; k < 6; ++k) meta->tail_stats[k] = (double)c.dbg[k];  // tail: rounds / 10-ns ticks per mode
     for (int k = 0; k < 4; ++k) meta->tail_stats[6 + k] = (double)c.dbg[12 + k];  // bids, line hits, builds, hit edges
 #if defined(MISSLAP_TAIL_STAMP) || defined(MISSLAP_TAIL_STAMP_SOLO) || defined(MISSLAP_TAIL_STAMP_TEAM) || \
-    defined(MISSLAP_TAIL_STAMP_BLOCK)
+    defined(MISSLAP_TAIL_STAMP_BLOCK) || defined(MISSLAP_TILED_STAMP)
     for (int k = 0; k < 6; ++k) meta->tail_stats[k] = (double)c.dbg[6 + k];  // diagnostic build: solo-round segments (cycles)
 #endif
     meta->cand_hits = c.cand_hits;
@@ -1901,7 +1955,8 @@ MISSLAP_API int misslap_debug_time_bid(misslap_solver *h, int32_t mode, int32_t 
         HIP_TRY(hipFuncSetAttribute((const void *)k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 1, 6>, at, ldsb));
         RoundArgs a = round_args(h);
         a.launch_edges = nullptr;
-        TiledArgs ta{reinterpret_cast<const unsigned *>(h->tiled), h->tcol, h->seg4, h->T, 1, h->n_tiled};
+        TiledArgs ta{reinterpret_cast<const unsigned *>(h->tiled), h->tcol, h->seg4, h->T, 1, h->n_tiled,
+                     nullptr, nullptr, h->ovf_ptr, h->ovf_q, h->ovf_cap, h->part_vw, h->part_g, h->n_rows};
         hipEvent_t t0, t1;
         HIP_TRY(hipEventCreate(&t0));
         HIP_TRY(hipEventCreate(&t1));
@@ -1910,8 +1965,8 @@ MISSLAP_API int misslap_debug_time_bid(misslap_solver *h, int32_t mode, int32_t 
             switch (mode) {
                 case 10:  // the product kernel in the handle's launch shape
                     switch (h->tiled_shape) {
-#define X(I, TH, R, B, D, TC, LD, GL) \
-    case I: hipLaunchKernelGGL((k_bid_tiled<TH, R, B, D, TC, LD, 0, GL>), g, dim3(TH), ldsb, h->stream, a, ta); break;
+#define X(I, TH, R, B, D, TC, LD, GL, CS) \
+    case I: hipLaunchKernelGGL((k_bid_tiled<TH, R, B, D, TC, LD, 0, GL, CS>), g, dim3(TH), ldsb, h->stream, a, ta); break;
                         MISSLAP_FOR_TILED_SHAPES(X)
 #undef X
                     }

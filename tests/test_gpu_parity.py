@@ -947,14 +947,14 @@ def test_rccl_world1_smoke(gpu_lib):
         solve_sharded(s, comm)
 
 
-@pytest.mark.parametrize("shape", [0, 7, 8, 9])
+@pytest.mark.parametrize("shape", [0, 4, 7, 8, 9])
 @pytest.mark.parametrize("spec,prob", [
     (dict(kind="sparse", n=6000, m=40000, density=0.001), "max"),           # ~10 edges per (person, tile) segment
     (dict(kind="sparse", n=5000, m=25000, density=0.004, ints=5), "min"),   # ~33 edges per segment, ties
     (dict(kind="sparse", n=4200, m=12000, density=0.01), "max"),            # ~60 edges per segment
 ])
 def test_tiled_kernel_shapes_round_by_round(spec, prob, shape, gpu_lib):
-    """Every lanes-per-person variant of k_bid_tiled (4 / 8 / 16 lanes: shapes 0, 7 / 8 / 9) on short, medium and long
+    """Every lanes-per-person variant of k_bid_tiled (4 / 8 / 16 lanes: shapes 0, 7 / 8 / 9; shape 4: the column split) on short, medium and long
     (person, tile) segments, forced for every grid round: full state vs the oracle."""
     loc, val = cases.synth_inputs(spec)
     for r in [1, 2, 3, 5, 8, 13, 30, 80]:
