@@ -193,14 +193,21 @@ __global__ __launch_bounds__(256) void k_ovf_count(const int *len, int n_rows, i
         ovf_cnt[i] = c;
     }
 }
+// An entry is self-contained -- {tile-major position, column, fp32 bits of the value, 0} -- so that the epilogue reads
+// its list with ONE sequential 16-byte load per edge and goes to memory once more, for the price (two random 4-byte
+// reads per edge into the tile-major arrays pulled a 128-byte line each: + 25 MB per full scan at C3).  Runs after
+// k_tile_scatter (it copies from the tile-major arrays).
 __global__ __launch_bounds__(256) void k_ovf_fill(const int *len, const int *start, int n_rows, int T, int rb, int cap,
-                                                  const int *ovf_ptr, int *ovf_q) {
+                                                  const int *ovf_ptr, const unsigned *tpk, const int *tcol, int4 *ovf) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_rows; i += gridDim.x * blockDim.x) {
         int at = ovf_ptr[i];
         for (int t = 0; t < T; ++t) {
             const int idx = tile_idx(i, t, T, rb);
             const int n = len[idx], s0 = start[idx];
-            for (int k = cap; k < n; ++k) ovf_q[at++] = s0 + k;
+            for (int k = cap; k < n; ++k) {
+                const int q = s0 + k;
+                ovf[at++] = make_int4(q, tcol[q], (int)tpk[(q >> 1) * 3 + 1 + (q & 1)], 0);
+            }
         }
     }
 }
@@ -372,7 +379,7 @@ struct TiledArgs {
     const int *order_person;  // bidders in person order and their list positions (partial rounds, see k_order_*);
     const int *order_pos;     // nullptr: list order (full scans: U is the identity)
     const int *ovf_ptr;       // [n_rows + 1] overflow edges of a person: ovf_q[ovf_ptr[i] .. ovf_ptr[i + 1])
-    const int *ovf_q;         // ... their tile-major positions (k_ovf_fill); built for ovf_cap edges per segment
+    const int4 *ovf;          // ... {tile-major position, column, value bits, 0} (k_ovf_fill); built for ovf_cap edges per segment
     int ovf_cap;              // must equal 2 * lanes per person * loads per segment of the launch shape
     // column-split shapes (kCS = 2): per-(column half, bidder slot) partial top-2, merged by k_tiled_merge
     double2 *part_vw;         // [kCS][part_stride] {best value, second-best value}
@@ -534,9 +541,35 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
 #ifdef MISSLAP_TILED_LOADER_PRIO
         __builtin_amdgcn_s_setprio(MISSLAP_TILED_LOADER_PRIO);
 #endif
+#ifndef MISSLAP_TILED_TOUCH
+#define MISSLAP_TILED_TOUCH 1  // tiles of lead of the L2 prefetch below (0 = off; C3: all launches of a solve 1.350 -> 1.324 ms)
+#endif
+        // L2 prefetch of the price tiles (speed only, never correctness).  All workgroups of an XCD fill the same tile
+        // at about the same time, prices are rewritten between the launches, so every tile fill begins with first-touch
+        // misses of that XCD's L2 -- one memory latency per tile that the double buffer (one tile of lead) does not
+        // cover when a tile's compute is short (partial rounds).  A loader wavefront therefore touches its share of
+        // the lines of tile t + MISSLAP_TILED_TOUCH (one 4-byte load per 128-byte line, 1 / 32 of the tile per
+        // workgroup of the XCD under round-robin dispatch) behind the fill of tile t + 1; the fill waits with
+        // vmcnt(1) -- loads return in order, the touch is the youngest and may stay in flight.
+        constexpr int kTileLines = kTileCols * 8 / 128;
+        const int nx = max(1, (int)gridDim.x / 8), xr = ((int)blockIdx.x / 8) % nx;
+        const int lines_per_wg = (kTileLines + nx - 1) / nx, lines_per_wave = (lines_per_wg + kLoaders - 1) / kLoaders;
+        int touch_prev = 0;
+        // (always ONE load per call, all lanes active, addresses clamped into the table: the vmcnt(1) below relies on
+        // exactly one load behind the pieces of a fill)
+        auto touch = [&](int tile) {
+            int r = 0;
+            const int line = min(xr * lines_per_wg + me * lines_per_wave + min(lane, lines_per_wave - 1), kTileLines - 1);
+            const char *src = reinterpret_cast<const char *>(a.price + (size_t)min(tile, T - 1) * kTileCols) + (size_t)line * 128;
+            asm volatile("global_load_dword %0, %1, off" : "=v"(r) : "v"(src) : "memory");
+            return r;
+        };
         if (t_lo < t_hi) dma_fill(rot(t_lo), me, kLoaders);
+        if (MISSLAP_TILED_TOUCH > 0) touch_prev = touch(t_lo + 1);
         for (int tile = t_lo; tile < t_hi; ++tile) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my pieces of tile `tile` have landed
+            // my pieces of tile `tile` have landed (a touch issued behind them may still be in flight)
+            if (MISSLAP_TILED_TOUCH > 0) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (kSplit) {
                 flag_add(0);
                 if (tile >= t_lo + 1 && tile + 1 < t_hi) flag_wait(1, (kWaves - kLoaders) * (tile - t_lo));  // tile - 1 is no longer read
@@ -545,6 +578,15 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
                 if (MISSLAP_TILED_THROTTLE >= 0) dma_fill_paced(rot(tile + 1), me, kLoaders);
                 else dma_fill(rot(tile + 1), me, kLoaders);
             }
+            if (MISSLAP_TILED_TOUCH > 0) {
+                // the previous touch is older than the pieces just waited for: it has landed, its register is free
+                asm volatile("" ::"v"(touch_prev));
+                touch_prev = touch(tile + 1 + MISSLAP_TILED_TOUCH);
+            }
+        }
+        if (MISSLAP_TILED_TOUCH > 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("" ::"v"(touch_prev));
         }
     }
     // Software pipeline over steps = (tile, batch of kTileBatch persons): while step s is consumed, the edges
@@ -806,17 +848,17 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
                 }
             }
             while (__any(more)) {
-                int q[kOB], col[kOB], vb[kOB];
+                int q[kOB], vb[kOB];
                 double pr[kOB];
+                int4 en[kOB];
 #pragma unroll
-                for (int jj = 0; jj < kOB; ++jj) q[jj] = ta.ovf_q[oi[jj] < oe[jj] ? oi[jj] : 0];
+                for (int jj = 0; jj < kOB; ++jj) en[jj] = ta.ovf[oi[jj] < oe[jj] ? oi[jj] : 0];
 #pragma unroll
                 for (int jj = 0; jj < kOB; ++jj) {
-                    col[jj] = ta.tcol[q[jj]];
-                    vb[jj] = (int)ta.tpk[(q[jj] >> 1) * 3 + 1 + (q[jj] & 1)];
+                    q[jj] = en[jj].x;
+                    vb[jj] = en[jj].z;
+                    pr[jj] = a.price[en[jj].y];
                 }
-#pragma unroll
-                for (int jj = 0; jj < kOB; ++jj) pr[jj] = a.price[col[jj]];
                 more = false;
 #pragma unroll
                 for (int jj = 0; jj < kOB; ++jj) {

@@ -199,7 +199,8 @@ struct misslap_solver {
     int2 *tiled = nullptr;
     int *seg4 = nullptr;  // k_bid_tiled's 4-byte segment table
     int *tcol = nullptr;  // real columns of the tile-major copy (k_bid_tiled stores LDS offsets in `tiled`)
-    int *ovf_ptr = nullptr, *ovf_q = nullptr;  // per-person lists of the edges beyond ovf_cap in a (person, tile) segment
+    int *ovf_ptr = nullptr;  // per-person lists of the edges beyond ovf_cap in a (person, tile) segment
+    int4 *ovf_q = nullptr;   // ... their entries {tile-major position, column, value bits, 0}
     int ovf_cap = 0;
     double2 *part_vw = nullptr;  // column-split launch shapes: per-(column half, bidder slot) partial top-2 (k_tiled_merge)
     int *part_g = nullptr;
@@ -931,9 +932,7 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
                     h->blocks.emplace_back();
                     if ((rc = blk.commit(&h->blocks.back()))) return rc;
                 }
-                HIP_TRY(hipMemsetAsync(h->ovf_q, 0, sizeof(int), h->stream));  // (entry 0 is read by idle lanes)
-                hipLaunchKernelGGL(k_ovf_fill, dim3(blocks_for((long long)N, 256)), dim3(256), 0, h->stream, len, start,
-                                   h->n_rows, T, rb, h->ovf_cap, h->ovf_ptr, h->ovf_q);
+                HIP_TRY(hipMemsetAsync(h->ovf_q, 0, sizeof(int4), h->stream));  // (entry 0 is read by idle lanes)
                 {
                     DevBlock blk;
                     blk.want(&h->tiled, (size_t)total + 16);
@@ -950,6 +949,9 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
                                    h->edges32, h->row_ptr, h->n_rows, T, tcols, rb, start, lrel, h->tiled,
                                    h->tcol, buf_stride);
                 hipLaunchKernelGGL(k_pack_seg4, dim3(blocks_for(L + 1, 256)), dim3(256), 0, h->stream, start, len, L, h->seg4);
+                hipLaunchKernelGGL(k_ovf_fill, dim3(blocks_for((long long)N, 256)), dim3(256), 0, h->stream, len, start,
+                                   h->n_rows, T, rb, h->ovf_cap, h->ovf_ptr, reinterpret_cast<const unsigned *>(h->tiled),
+                                   h->tcol, h->ovf_q);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipStreamSynchronize(h->stream));
                 h->tiled_ok = true;
