@@ -75,6 +75,10 @@ typedef struct misslap_options {
     int32_t cand_refresh_min;/* r + 1: a line hit with fewer than r live candidates is rebuilt by k_bid (0 = library
                                 default, 1 = never) */
     int32_t reserved[7];     /* must be zero */
+    void *input_stream;      /* input_on_device only: the hipStream_t the caller's buffers were produced on.  The library
+                                then orders its own stream behind that one with an event instead of waiting for the
+                                whole device (NULL: hipDeviceSynchronize before the inputs are read -- always safe, but
+                                it serialises every other stream of the caller) */
 } misslap_options;
 
 /* Result block of misslap_finish: the reference's `meta` dict (auction_.pyx:264,:297-304)
@@ -173,7 +177,8 @@ int misslap_create(misslap_solver **out, int64_t nnz, const int32_t *loc, const 
  * entries -- they are counted in 64 bits on the device, *nnz_out is exact).
  * options.input_on_device: `mat` (here) / `loc`, `val` (misslap_create) are device pointers.  The library then
  * waits for the whole device (hipDeviceSynchronize) before reading them, so buffers still being produced on any
- * stream of the caller are safe to pass. */
+ * stream of the caller are safe to pass -- or, with options.input_stream set, only for the work already enqueued on
+ * that stream (an event the solver's stream waits for). */
 int misslap_create_dense(misslap_solver **out, int64_t n_rows, int64_t n_cols, const double *mat,
                          const misslap_options *opt, int64_t *nnz_out);
 

@@ -21,6 +21,7 @@ class Options(C.Structure):
         ("shard_min_K", C.c_int32), ("cand_mode", C.c_int32), ("partial_in_list_order", C.c_int32),
         ("nnz_limit", C.c_int32), ("cand_build_max_K", C.c_int32), ("cand_refresh_min", C.c_int32),
         ("reserved", C.c_int32 * 7),
+        ("input_stream", C.c_void_p),
     ]
 
 

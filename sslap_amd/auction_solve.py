@@ -27,7 +27,8 @@ _ENV_TILED = "MISSLAP_TILED_MIN_K"  # 0 default, < 0 never use the LDS-tiled bid
 
 def _options(problem, eps_start, max_iter, device=None, tail_threshold=None, profile=None, force_f64=False,
              input_on_device=False, shard=None, rounds_per_sync=None, tiled_min_k=None, tiled_shape=None, shard_min_k=None,
-             engine=None, cand=None, nnz_limit=None, order_partial=None, cand_build_max_k=None, cand_refresh=None):
+             engine=None, cand=None, nnz_limit=None, order_partial=None, cand_build_max_k=None, cand_refresh=None,
+             input_stream=None):
     if problem not in ("min", "max"):
         # the reference treats every string other than 'min' as 'max' (auction_.pyx:236, :502)
         problem = "max" if problem != "min" else "min"
@@ -38,6 +39,8 @@ def _options(problem, eps_start, max_iter, device=None, tail_threshold=None, pro
     o.eps_start = float(np.float32(eps_start))
     o.max_iter = int(max_iter)
     o.input_on_device = 1 if input_on_device else 0
+    # the hipStream_t that produced device-resident inputs (None: the library waits for the whole device instead)
+    o.input_stream = None if input_stream is None else C.c_void_p(int(input_stream))
     o.tail_threshold = int(os.environ.get(_ENV_TAIL, -1)) if tail_threshold is None else int(tail_threshold)
     o.force_f64_values = 1 if force_f64 else 0
     o.profile = int(os.environ.get(_ENV_PROFILE, 0)) if profile is None else int(profile)

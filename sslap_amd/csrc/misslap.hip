@@ -1057,9 +1057,23 @@ int64_t nnz_limit(const misslap_options *opt) {
 }
 
 // Device-resident inputs: the library works on a private non-blocking stream, which is not ordered behind the
-// stream(s) that produced the caller's buffers.  Wait for the whole device once, before anything reads them.
-int sync_device_inputs(const misslap_options *opt) {
-    if (opt->input_on_device) HIP_TRY(hipDeviceSynchronize());
+// stream(s) that produced the caller's buffers.  With options.input_stream the solver's stream waits for an event
+// recorded on the producer's stream (nothing else of the caller is held up); without it the whole device is waited for
+// once, before anything reads the buffers.  (The few synchronous host reads of the inputs -- the last row index -- go
+// through hipMemcpy on the null stream and are therefore made after a wait for that event as well.)
+int sync_device_inputs(const misslap_options *opt, hipStream_t solver_stream) {
+    if (!opt->input_on_device) return MISSLAP_OK;
+    if (!opt->input_stream) {
+        HIP_TRY(hipDeviceSynchronize());
+        return MISSLAP_OK;
+    }
+    hipEvent_t ev = nullptr;
+    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ev, (hipStream_t)opt->input_stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(solver_stream, ev, 0);
+    if (e == hipSuccess) e = hipEventSynchronize(ev);  // host reads of the inputs below
+    (void)hipEventDestroy(ev);
+    if (e != hipSuccess) return fail(MISSLAP_ERR_HIP, "cannot order the solver behind options.input_stream: %s", hipGetErrorString(e));
     return MISSLAP_OK;
 }
 
@@ -1437,7 +1451,7 @@ MISSLAP_API int misslap_create(misslap_solver **out, int64_t nnz, const int32_t 
     rc = new_handle(out, opt, abi, &h);
     if (rc) return rc;
     h->nnz = nnz;
-    if ((rc = sync_device_inputs(opt))) {
+    if ((rc = sync_device_inputs(opt, h->stream))) {
         free_all(h);
         return rc;
     }
@@ -1499,7 +1513,7 @@ MISSLAP_API int misslap_create_dense(misslap_solver **out, int64_t n_rows, int64
         return code;
     };
     const size_t cells = (size_t)n_rows * (size_t)n_cols;
-    if ((rc = sync_device_inputs(opt))) return cleanup(rc);
+    if ((rc = sync_device_inputs(opt, h->stream))) return cleanup(rc);
     if ((rc = dev_alloc(&d_mat, cells))) return cleanup(rc);
     if ((rc = dev_alloc(&d_cnt, (size_t)n_rows))) return cleanup(rc);
     if ((rc = dev_alloc(&d_ptr, (size_t)n_rows + 1))) return cleanup(rc);

@@ -32,7 +32,7 @@ def test_struct_layouts_match_header():
     import subprocess
     import tempfile
     fields = {"misslap_options": ["max_iter", "tail_threshold", "rounds_per_sync", "tiled_min_K", "cand_mode",
-                                  "cand_refresh_min", "reserved"],
+                                  "cand_refresh_min", "reserved", "input_stream"],
               "misslap_meta": ["struct_size", "start_eps", "its", "obj_f64", "edges_scanned", "bid_ms", "tail_edges", "tiled_min_K", "merge_ms", "shard_edges", "cand_hits", "tail_stats",
                                "complete_assignment", "valid_assignment", "lines_active"],
               "misslap_status": ["K", "error_bits", "rounds_per_sync", "shard_min_K"]}

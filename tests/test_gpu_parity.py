@@ -188,6 +188,33 @@ def test_device_resident_input(gpu_lib):
     assert torch.equal(dv.cpu(), torch.from_numpy(val))  # device input untouched
 
 
+def test_device_resident_input_ordered_behind_the_producer_stream(gpu_lib):
+    """options.input_stream: the inputs are still being PRODUCED on a side stream when create is called (a long chain
+    of kernels in front of the copies that fill them); the solver's stream waits for an event on that stream instead
+    of for the whole device.  Wrong ordering would read zeros (rejected: rows unsorted / empty) or stale values."""
+    import torch
+    loc, val = synth.gen_sparse(3000, 3000, 0.01, seed=21)
+    ref = orc.auction_solve(loc=loc, val=val.copy(), problem="max", cardinality_check=False)
+    h_loc, h_val = torch.from_numpy(loc).pin_memory(), torch.from_numpy(val).pin_memory()
+    side = torch.cuda.Stream()
+    for _ in range(3):
+        dl = torch.zeros_like(h_loc, device="cuda")
+        dv = torch.zeros_like(h_val, device="cuda")
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            x = torch.randn(4096, 4096, device="cuda")
+            for _ in range(40):  # ~ tens of milliseconds of work ahead of the copies
+                x = x @ x
+                x = x / x.norm()
+            dl.copy_(h_loc, non_blocking=True)
+            dv.copy_(h_val, non_blocking=True)
+        s = AuctionSolver.from_device_pointers(dl.data_ptr(), dv.data_ptr(), loc.shape[0], problem="max",
+                                               input_stream=side.cuda_stream)
+        sol = s.solve()
+        assert np.array_equal(sol, ref["sol"]) and s.meta["its"] == ref["meta"]["its"]
+    torch.cuda.synchronize()
+
+
 # (n, density, seed, integer values, tail threshold, shard_min_k): every grid round sharded / a mix of sharded
 # and replicated rounds / library default (nothing sharded at this size) / the LDS-tiled kernel sharded
 _DIST_GPU_CASES = ((1500, 0.02, 1, 0, 0, -1), (1500, 0.02, 2, 4, 8, 300), (1500, 0.02, 3, 0, None, None),
