@@ -553,7 +553,7 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
         // vmcnt(1) -- loads return in order, the touch is the youngest and may stay in flight.
         constexpr int kTileLines = kTileCols * 8 / 128;
         const int nx = max(1, (int)gridDim.x / 8), xr = ((int)blockIdx.x / 8) % nx;
-        const int lines_per_wg = (kTileLines + nx - 1) / nx, lines_per_wave = (lines_per_wg + kLoaders - 1) / kLoaders;
+        const int lines_per_wg = (kTileLines + nx - 1) / nx, lines_per_wave = (lines_per_wg + kLoaders - 1) / (kLoaders > 0 ? kLoaders : 1);
         int touch_prev = 0;
         // (always ONE load per call, all lanes active, addresses clamped into the table: the vmcnt(1) below relies on
         // exactly one load behind the pieces of a fill)
