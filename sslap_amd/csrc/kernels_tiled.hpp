@@ -447,19 +447,6 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
     constexpr int kWaves = kTileThreads / kWave;
     const int wave_u = __builtin_amdgcn_readfirstlane(t >> 6);
     const bool loader = kLoaders > 0 && wave_u >= kWaves - kLoaders;
-
-#ifndef MISSLAP_TILED_ROT
-#define MISSLAP_TILED_ROT 0
-#endif
-    // Tile order.  ROT: the workgroups of one XCD (blockIdx % 8 under round-robin dispatch) start at tiles spread
-    // evenly over [0, T) and wrap around, so that every price tile is re-read every few microseconds and stays
-    // in the XCD's L2 (in lockstep all 32 workgroups read a tile once and the edge stream evicts it before the
-    // stragglers arrive).  Needs an even T (the buffer parity of a tile is baked into the edges).
-    const int t0 = (MISSLAP_TILED_ROT && (T & 1) == 0) ? (int)(((blockIdx.x >> 3) * (unsigned)T) >> 5) % T : 0;
-    auto rot = [&](int it) {
-        const int x = t0 + it;
-        return x >= T ? x - T : x;
-    };
     int person[kTileRows];
     double sv[kTileRows], sw[kTileRows];
     int sg[kTileRows];  // position of the lane's best element (its column / cost are re-read at the end)
@@ -473,29 +460,6 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
         sg[j] = -1;
     }
     if (t == 0) s_price[kTileCols] = __builtin_huge_val();
-#ifndef MISSLAP_TILED_SPLITBAR
-#define MISSLAP_TILED_SPLITBAR 0
-#endif
-    // MISSLAP_TILED_SPLITBAR: no workgroup barrier in the tile loop.  Two monotonic counters in LDS instead: `filled`
-    // counts (loader wavefront, tile) completions -- tile t has landed once filled >= kLoaders * (t + 1) -- and `done`
-    // counts (compute wavefront, tile) completions -- the buffer of tile t may be refilled (with tile t + 2) once
-    // done >= nCompute * (t + 1).  A compute wavefront then waits for ITS tile only, not for the slowest of sixteen
-    // wavefronts at every tile; wavefronts drift apart by up to one tile, which also takes them out of lockstep.
-    constexpr bool kSplit = MISSLAP_TILED_SPLITBAR && kLoaders > 0 && kDouble;
-    int *s_flag = reinterpret_cast<int *>(s_price + (kDouble ? kBufDoubles + kTileCols : kTileCols + 2)) + 3 * (kTileThreads / kWave);
-    auto flag_wait = [&](int which, int need) {  // every lane polls the same word (a broadcast read)
-        while (__hip_atomic_load(&s_flag[which], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
-        asm volatile("" ::: "memory");  // nothing of the tile is read (or refilled) ahead of the poll
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    auto flag_add = [&](int which) {
-        asm volatile("" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(&s_flag[which], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
-    if (kSplit) {
-        if (t == 0) s_flag[0] = s_flag[1] = 0;
-        __syncthreads();  // the only workgroup barrier: counters and the +inf slot are in place
-    }
     // an edge carries the slot of its price inside s_price (tile parity included, see k_tile_scatter)
     constexpr int kInfOff = kTileCols * 8;  // the +inf slot (behind buffer 0)
     // ... as an ABSOLUTE LDS address: s_price is the kernel's only LDS object and therefore starts at LDS address 0
@@ -517,30 +481,8 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
                                                  (__attribute__((address_space(3))) void *)(dst + piece * 128), 16, 0,
                                                  0);
     };
-#ifndef MISSLAP_TILED_THROTTLE
-#define MISSLAP_TILED_THROTTLE -1  // >= 0: a loader wavefront keeps at most this many + 1 pieces of a fill in flight
-#endif
-    // The CU's vector memory path returns in order: a fill issued as one burst (26 pieces per loader wavefront) sits
-    // in front of every edge load the compute wavefronts issue behind it.  A paced fill -- the next piece only when
-    // the oldest has landed but for MISSLAP_TILED_THROTTLE -- leaves room between its pieces; it has a whole tile's
-    // compute time to complete.
-    auto dma_fill_paced = [&](int tile, int first, int stride) {
-        constexpr int kPieces = kTileCols / 128;
-        const double *gsrc = a.price + (size_t)tile * kTileCols + 2 * lane;
-        double *dst = s_price + (kDouble ? (tile & 1) : 0) * kBufDoubles;
-        for (int piece = first; piece < kPieces; piece += stride) {
-            if (ABL != 1)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc + piece * 128),
-                                                 (__attribute__((address_space(3))) void *)(dst + piece * 128), 16, 0,
-                                                 0);
-            if (MISSLAP_TILED_THROTTLE >= 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MISSLAP_TILED_THROTTLE < 0 ? 0 : MISSLAP_TILED_THROTTLE) : "memory");
-        }
-    };
     if (loader) {
         const int me = wave_u - (kWaves - kLoaders);
-#ifdef MISSLAP_TILED_LOADER_PRIO
-        __builtin_amdgcn_s_setprio(MISSLAP_TILED_LOADER_PRIO);
-#endif
 #ifndef MISSLAP_TILED_TOUCH
 #define MISSLAP_TILED_TOUCH 1  // tiles of lead of the L2 prefetch below (0 = off; C3: all launches of a solve 1.350 -> 1.324 ms)
 #endif
@@ -564,20 +506,14 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
             asm volatile("global_load_dword %0, %1, off" : "=v"(r) : "v"(src) : "memory");
             return r;
         };
-        if (t_lo < t_hi) dma_fill(rot(t_lo), me, kLoaders);
+        if (t_lo < t_hi) dma_fill(t_lo, me, kLoaders);
         if (MISSLAP_TILED_TOUCH > 0) touch_prev = touch(t_lo + 1);
         for (int tile = t_lo; tile < t_hi; ++tile) {
             // my pieces of tile `tile` have landed (a touch issued behind them may still be in flight)
             if (MISSLAP_TILED_TOUCH > 0) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (kSplit) {
-                flag_add(0);
-                if (tile >= t_lo + 1 && tile + 1 < t_hi) flag_wait(1, (kWaves - kLoaders) * (tile - t_lo));  // tile - 1 is no longer read
-            } else if (ABL != 4) __syncthreads();             // ... and tile - 1 is no longer read
-            if (tile + 1 < t_hi) {
-                if (MISSLAP_TILED_THROTTLE >= 0) dma_fill_paced(rot(tile + 1), me, kLoaders);
-                else dma_fill(rot(tile + 1), me, kLoaders);
-            }
+            if (ABL != 4) __syncthreads();                    // ... and tile - 1 is no longer read
+            if (tile + 1 < t_hi) dma_fill(tile + 1, me, kLoaders);
             if (MISSLAP_TILED_TOUCH > 0) {
                 // the previous touch is older than the pieces just waited for: it has landed, its register is free
                 asm volatile("" ::"v"(touch_prev));
@@ -612,7 +548,7 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
     // `tiled` is allocated with 16 spare entries, so the unconditional loads of masked-off lanes (at most 15
     // entries past a segment start) need no clamp.
     auto load_seg = [&](int tile, int b, Seg &sg_) {
-        const int tl = rot(min(tile, T - 1));
+        const int tl = min(tile, T - 1);
 #pragma unroll
         for (int jj = 0; jj < kTileBatch; ++jj) {
             const int pj = person[b * kTileBatch + jj];
@@ -694,21 +630,20 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
         for (int k = 0; k < kE; ++k) load_edges(sq[k], eq[k]);
         Seg &seg_cur = sq[0];
         Edges &e_cur = eq[0];
-        if (kLoaders == 0 && kDouble) dma_fill(rot(t_lo), wave_u, kWaves);
+        if (kLoaders == 0 && kDouble) dma_fill(t_lo, wave_u, kWaves);
         for (int tile = t_lo; tile < (loader ? t_lo : t_hi); ++tile) {
             if (!kDouble) {
                 __syncthreads();  // every lookup of the previous tile is done
-                dma_fill(rot(tile), wave_u, kWaves);
+                dma_fill(tile, wave_u, kWaves);
             }
             if (kLoaders == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my pieces of this tile
-            if (kSplit) MISSLAP_STAMP(1, flag_wait(0, kLoaders * (tile - t_lo + 1)));  // every piece of this tile has landed
-            else MISSLAP_STAMP(1, if (ABL != 4) __syncthreads());  // every piece of this tile has landed; the other buffer may be refilled
+            MISSLAP_STAMP(1, if (ABL != 4) __syncthreads());  // every piece of this tile has landed; the other buffer may be refilled
 #pragma unroll
             for (int b = 0; b < NBE; ++b) {
                 // issue: edges of step s + kE, segment entries of step s + kQ
                 load_edges(sq[kE], eq[kE]);
                 load_seg(tile + (b + kQ) / NBE, (b + kQ) % NBE, sq[kQ]);
-                if (kDouble && kLoaders == 0 && b == 0 && tile + 1 < t_hi) dma_fill(rot(tile + 1), wave_u, kWaves);
+                if (kDouble && kLoaders == 0 && b == 0 && tile + 1 < t_hi) dma_fill(tile + 1, wave_u, kWaves);
 #ifdef MISSLAP_TILED_STAMP
                 // this step's edges: everything but the loads just issued (edges of the next step + two segment entries
                 // per person of the step after it)
@@ -760,10 +695,8 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
                                 // taking sg when sv is still -inf (rows whose objects all have an infinite price)
                                 const double v = (double)__int_as_float(vb) - prs[jj][d][h];  // vi = cost - p[j]   (:350)
                                 const int q = q0 + 2 * kGL * d + h;
-                                // in tile order a lane meets its elements in stored order and ">=" is the reference's
-                                // rule; with a rotated tile order the later STORED position must win a tie explicitly
-                                const bool ge = (2 * kGL * d + h < rem[jj]) &
-                                                (MISSLAP_TILED_ROT ? ((v > sv[j]) | ((v == sv[j]) & (q > sg[j]))) : (v >= sv[j]));  // :351
+                                // a lane meets its elements in stored order: ">=" is the reference's tie rule
+                                const bool ge = (2 * kGL * d + h < rem[jj]) & (v >= sv[j]);  // :351
                                 sw[j] = __builtin_fmax(sw[j], __builtin_fmin(v, sv[j]));      // :353 / :357-358
                                 sv[j] = __builtin_fmax(sv[j], v);
                                 sg[j] = ge ? q : sg[j];
@@ -798,7 +731,6 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
 #pragma unroll
                 for (int k = 0; k < kE; ++k) eq[k] = eq[k + 1];
             }
-            if (kSplit) flag_add(1);  // my look-ups of this tile are done (LDS operations of a wavefront execute in order)
         }
     };
     {
