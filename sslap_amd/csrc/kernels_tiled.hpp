@@ -381,11 +381,23 @@ struct TiledArgs {
     const int *ovf_ptr;       // [n_rows + 1] overflow edges of a person: ovf_q[ovf_ptr[i] .. ovf_ptr[i + 1])
     const int4 *ovf;          // ... {tile-major position, column, value bits, 0} (k_ovf_fill); built for ovf_cap edges per segment
     int ovf_cap;              // must equal 2 * lanes per person * loads per segment of the launch shape
-    // column-split shapes (kCS = 2): per-(column half, bidder slot) partial top-2, merged by k_tiled_merge
+    // column-split shapes (kCS > 1): per-(share of the tiles, bidder slot) partial top-2, merged by the workgroup of a
+    // slice that finishes last
     double2 *part_vw;         // [kCS][part_stride] {best value, second-best value}
-    int *part_g;              // [kCS][part_stride] tile-major position of the best edge (-1: no edge in that half)
+    int *part_g;              // [kCS][part_stride] tile-major position of the best edge (-1: no edge in that share)
     int part_stride;
+    int *split_cnt;           // [slices] workgroups of the slice that have published their partial result (0 between launches)
 };
+
+// hand-over of a column-split shape's partial results between workgroups (see the epilogue of k_bid_tiled)
+template <class T>
+__device__ __forceinline__ void split_store(T *p, T v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <class T>
+__device__ __forceinline__ T split_load(const T *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // All global loads of the tile loop are UNCONDITIONAL (masked-off lanes read a clamped, valid address and
 // their value is neutralised): a load inside an `if` makes hipcc wait for it (vmcnt(0)) before the branch
@@ -407,11 +419,11 @@ struct TiledArgs {
 // 5 = price look-ups without the arithmetic, 6 = arithmetic without the look-ups.
 // kCS = 2 (column split): two workgroups share a slice of bidders and each sees HALF of the column tiles, i.e. half of
 // the price table -- per CU the tile fills (the whole table once per workgroup: 1.6 MB at C3, more than the 1.0 MB of
-// edges a CU streams) halve, and so do the barriers; a lane group then owns twice the persons (kTileRows = 8).  The two
-// partial top-2s of a bidder go to memory (20 bytes each) and k_tiled_merge forms the bid.
+// edges a CU streams) halve, and so do the barriers; a lane group then owns twice the persons (kTileRows = 8).  The
+// partial top-2s of a bidder go to memory (20 bytes each); the workgroup of the slice that arrives last forms the bids.
 template <int kTileThreads, int kTileRows, int kTileBatch, int kTileDepth, int kTileCols, int kLoaders, int ABL = 0, int kGL = 4, int kCS = 1>
 __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledArgs ta) {
-    static_assert(kCS == 1 || kCS == 2, "column split: none or two halves");
+    static_assert(kCS == 1 || kCS == 2 || kCS == 4, "column split: none, halves or quarters of the tiles");
     static_assert(kGL == 4 || kGL == 8 || kGL == 16, "lanes per person: 4, 8 or 16 (one DPP row at most)");
     constexpr int kTileGroups = (kTileThreads - kLoaders * kWave) / kGL;  // kGL-lane groups; loader wavefronts own none
     // LDS (in doubles): buffer 0 at [0, kTileCols), the +inf slot at kTileCols, buffer 1 at [kBufDoubles, ...).
@@ -449,7 +461,12 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
     const bool loader = kLoaders > 0 && wave_u >= kWaves - kLoaders;
     int person[kTileRows];
     double sv[kTileRows], sw[kTileRows];
-    int sg[kTileRows];  // position of the lane's best element (its column / cost are re-read at the end)
+    int sg[kTileRows];  // position of the lane's best element ...
+    // ... and its column and cost.  They are NOT updated per element (two more selects in the inner loop): after a step
+    // that moved sg the winner is picked from the step's registers (see `note_best`).  Re-reading them at the end through
+    // the position -- two random 4-byte reads per bidder into the tile-major arrays -- pulled 51 MB of lines per full
+    // scan at C3 and put a memory latency in front of the bids.
+    int scol[kTileRows], scost[kTileRows];
 #pragma unroll
     for (int j = 0; j < kTileRows; ++j) {
         const int pos = p0 + j * kTileGroups + group;
@@ -458,6 +475,8 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
         sv[j] = ninf;
         sw[j] = ninf;
         sg[j] = -1;
+        scol[j] = 0;
+        scost[j] = 0;
     }
     if (t == 0) s_price[kTileCols] = __builtin_huge_val();
     // an edge carries the slot of its price inside s_price (tile parity included, see k_tile_scatter)
@@ -656,6 +675,7 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
 #pragma unroll
                 for (int jj = 0; jj < kTileBatch; ++jj)
                     rem[jj] = (person[b * kTileBatch + jj] >= 0 ? seg_s1(seg_cur, jj) - seg_s0(seg_cur, jj) : 0) - 2 * gl;
+                const int col0 = tile * kTileCols - (kDouble ? (tile & 1) * kBufDoubles : 0);  // column of slot 0 of this tile's buffer
                 auto consume = [&](const int dlo, const int dhi) {
                     double prs[kTileBatch][kTileDepth][2];
 #pragma unroll
@@ -678,6 +698,7 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
                     for (int jj = 0; jj < kTileBatch; ++jj) {
                         const int j = b * kTileBatch + jj;
                         const int q0 = seg_s0(seg_cur, jj) + 2 * gl;
+                        int sslot = -1;  // slot of the best element if it moved in this step
 #pragma unroll
                         for (int d = dlo; d < dhi; ++d) {
                             if (ABL == 2) {
@@ -700,8 +721,16 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
                                 sw[j] = __builtin_fmax(sw[j], __builtin_fmin(v, sv[j]));      // :353 / :357-358
                                 sv[j] = __builtin_fmax(sv[j], v);
                                 sg[j] = ge ? q : sg[j];
+                                if (kCS == 1 && ABL == 0) {
+                                    scost[j] = ge ? vb : scost[j];
+                                    sslot = ge ? (int)(h ? e_cur.c[jj][d] >> 16 : e_cur.c[jj][d] & 0xffffu) : sslot;
+                                }
                             }
                         }
+                        // note_best: a person whose best element moved takes its column and cost from the registers just
+                        // consumed -- element rel = 2 * kGL * d + h of my share of the segment; the slot of an edge is its
+                        // column relative to the tile (+ the buffer of the tile's parity, see k_tile_scatter)
+                        if (kCS == 1 && ABL == 0) scol[j] = sslot >= 0 ? col0 + sslot : scol[j];
                     }
                 };
                 // The first kFastDepth loads of a segment cover most segments and are consumed unconditionally; the
@@ -744,11 +773,40 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
             run_tiles(std::integral_constant<int, kNB>{});
     }
 #ifdef MISSLAP_TILED_STAMP
-    if (!loader && lane == 0) {
-        atomicAdd(&a.ctl->dbg[6], now() - t_begin);
+    // (MISSLAP_TILED_STAMP == 2: the epilogue instead -- [6] tile loop, [7] overflow lists, [8] column split: publish +
+    // count in, [9] the last arriver's loads + merge, [10] bids + statistics, [11] number of wavefronts)
+    unsigned long long t_e = now(), eacc[5] = {0, 0, 0, 0, 0};
+    if (!loader && lane == 0 && MISSLAP_TILED_STAMP + 0 < 2) {
+        atomicAdd(&a.ctl->dbg[6], t_e - t_begin);
         for (int k = 1; k <= 4; ++k) atomicAdd(&a.ctl->dbg[6 + k], sacc[k]);
         atomicAdd(&a.ctl->dbg[11], 1ull);
     }
+    eacc[0] = t_e - t_begin;
+#define MISSLAP_ESTAMP(K)                                    \
+    do {                                                     \
+        if (MISSLAP_TILED_STAMP + 0 >= 2) {                  \
+            __builtin_amdgcn_sched_barrier(0);               \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+            const unsigned long long t_n = now();            \
+            eacc[K] += t_n - t_e;                            \
+            t_e = t_n;                                       \
+            __builtin_amdgcn_sched_barrier(0);               \
+        }                                                    \
+    } while (0)
+#define MISSLAP_EFLUSH()                                                          \
+    do {                                                                          \
+        if (MISSLAP_TILED_STAMP + 0 >= 2 && t == 0 && (MISSLAP_TILED_STAMP + 0 == 2 || (hi - lo < ta.part_stride) == (MISSLAP_TILED_STAMP + 0 == 3))) {   /* wavefront 0 only; 3: partial rounds, 4: full scans */     \
+            for (int k = 0; k < 5; ++k) atomicAdd(&a.ctl->dbg[6 + k], eacc[k]);   \
+            atomicAdd(&a.ctl->dbg[11], 1ull);                                     \
+        }                                                                         \
+    } while (0)
+#else
+#define MISSLAP_ESTAMP(K) \
+    do {                  \
+    } while (0)
+#define MISSLAP_EFLUSH() \
+    do {                 \
+    } while (0)
 #endif
     // overflow edges (see k_ovf_count): lane gl of a person's group takes entries gl, gl + kGL, ... of its list; the price
     // comes from memory (the table the tiles were filled from), the update is the same with the tie rule spelled out
@@ -801,47 +859,112 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
                     sw[j] = __builtin_fmax(sw[j], __builtin_fmin(v, sv[j]));                // :353 / :357-358
                     sv[j] = __builtin_fmax(sv[j], v);
                     sg[j] = ge ? q[jj] : sg[j];
+                    scol[j] = ge ? en[jj].y : scol[j];
+                    scost[j] = ge ? vb[jj] : scost[j];
                     oi[jj] += kGL;
                     more |= oi[jj] < oe[jj];
                 }
             }
         }
     }
-    if (kCS > 1) {  // the partial top-2 of my half of the tiles: one lane per person writes it
-        if (!loader) {
-#pragma unroll
-            for (int j = 0; j < kTileRows; ++j) {
-                const double V = group_max_f64<kGL>(sv[j]);
-                const int G = group_max_i32<kGL>(sv[j] == V ? sg[j] : -1);
-                const double Wj = group_max_f64<kGL>(sg[j] == G ? sw[j] : sv[j]);
-                const bool writer = G >= 0 ? sg[j] == G : gl == 0;  // (G < 0: the person has no edge in these tiles)
-                if (person[j] >= 0 && writer) {
-                    const size_t at = (size_t)half * ta.part_stride + (size_t)(p0 + j * kTileGroups + group);
-                    ta.part_vw[at] = make_double2(V, G >= 0 ? Wj : ninf);
-                    ta.part_g[at] = G;
-                }
-            }
-        }
-        return;
-    }
-    // merge the 8 lanes of each group, once per person (same three all-reduces as top2_wave_reduce)
+    MISSLAP_ESTAMP(1);
+    // merge the kGL lanes of each group, once per person (same three all-reduces as top2_wave_reduce)
     unsigned long long edges = 0;
     int nb = 0, err = 0;
     int2 best[kTileRows];
     int rlen[kTileRows];
     double W[kTileRows];
-    bool mine[kTileRows];
+    int G[kTileRows];
+    bool mine[kTileRows];  // exactly one lane of the group
+    // statistics / hand-over scratch.  It lives BEHIND the price buffers in the dynamic allocation: a static __shared__
+    // array would be placed first and shift s_price off LDS address 0, which costs one v_add per price look-up (the
+    // edges carry absolute LDS offsets)
+    unsigned long long *s_e = reinterpret_cast<unsigned long long *>(s_price + (kDouble ? kBufDoubles + kTileCols : kTileCols + 2));
+    int *s_n = reinterpret_cast<int *>(s_e + kTileThreads / kWave);
+    if (kCS == 1) {
+#pragma unroll
+        for (int j = 0; j < kTileRows; ++j) {
+            const double V = group_max_f64<kGL>(sv[j]);
+            G[j] = group_max_i32<kGL>(sv[j] == V ? sg[j] : -1);
+            W[j] = group_max_f64<kGL>(sg[j] == G[j] ? sw[j] : sv[j]);
+            mine[j] = person[j] >= 0 && sg[j] == G[j] && G[j] >= 0;  // the lane that holds the best edge
+        }
+    } else {
+        // Column split: my top-2 covers my share of the tiles only.  Every workgroup of the slice publishes its partial
+        // results and counts itself in; the LAST one to arrive finds all of them complete, merges them (the merge
+        // operator of the reduction; positions of a person grow with the tile, so the later stored position wins a tie,
+        // :351) and forms the bids of the slice.  Nobody waits for anybody.
+#pragma unroll
+        for (int j = 0; j < kTileRows; ++j) {
+            const double V = group_max_f64<kGL>(sv[j]);
+            const int Gj = group_max_i32<kGL>(sv[j] == V ? sg[j] : -1);
+            const double Wj = group_max_f64<kGL>(sg[j] == Gj ? sw[j] : sv[j]);
+            mine[j] = person[j] >= 0 && gl == 0;
+            if (mine[j]) {
+                const size_t at = (size_t)half * ta.part_stride + (size_t)(p0 + j * kTileGroups + group);
+                split_store(reinterpret_cast<unsigned long long *>(ta.part_vw + at), (unsigned long long)__double_as_longlong(V));
+                split_store(reinterpret_cast<unsigned long long *>(ta.part_vw + at) + 1,
+                            (unsigned long long)__double_as_longlong(Gj >= 0 ? Wj : ninf));
+                split_store(ta.part_g + at, Gj);
+            }
+        }
+        // The XCDs' L2s are not coherent with each other.  A device-scope fence (__threadfence) would write back and
+        // invalidate the whole L2 of the XCD, per wavefront, under the other workgroups' price tiles (measured: the
+        // scan three times as long).  The partial results travel as device-scope atomic stores / loads instead (sc1:
+        // performed at the level all XCDs share), the arrival count is a device-scope atomic as well, and the order is
+        // made by hand: my stores have completed (vmcnt) before the barrier behind which thread 0 counts us in; the
+        // last arriver's loads are issued behind the barrier that hands it the count.
+        int *s_arrived = s_n + kTileThreads / kWave;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t == 0) *s_arrived = atomicAdd(&ta.split_cnt[slice], 1);
+        __syncthreads();
+        MISSLAP_ESTAMP(2);
+        if (*s_arrived != kCS - 1) {  // uniform over the workgroup
+            MISSLAP_EFLUSH();
+            return;
+        }
+        if (t == 0) ta.split_cnt[slice] = 0;  // for the next launch
+        double2 P[kCS][kTileRows];
+        int pg[kCS][kTileRows];
+#pragma unroll
+        for (int o = 0; o < kCS; ++o)
+#pragma unroll
+            for (int j = 0; j < kTileRows; ++j) {
+                const size_t at = (size_t)o * ta.part_stride + (size_t)min(p0 + j * kTileGroups + group, p1 - 1);
+                P[o][j].x = __longlong_as_double((long long)split_load(reinterpret_cast<const unsigned long long *>(ta.part_vw + at)));
+                P[o][j].y = __longlong_as_double((long long)split_load(reinterpret_cast<const unsigned long long *>(ta.part_vw + at) + 1));
+                pg[o][j] = split_load(ta.part_g + at);
+            }
+#pragma unroll
+        for (int j = 0; j < kTileRows; ++j) {
+            double V = P[0][j].x;
+            W[j] = P[0][j].y;
+            G[j] = pg[0][j];
+#pragma unroll
+            for (int o = 1; o < kCS; ++o) {
+                const double2 B = P[o][j];
+                const int gb = pg[o][j];
+                const bool take = (gb >= 0) & ((G[j] < 0) | (B.x > V) | ((B.x == V) & (gb > G[j])));
+                W[j] = take ? __builtin_fmax(B.y, G[j] >= 0 ? V : ninf) : __builtin_fmax(W[j], gb >= 0 ? B.x : ninf);
+                V = take ? B.x : V;
+                G[j] = take ? gb : G[j];
+            }
+            if (mine[j] && G[j] < 0) err |= kErrRowGap;  // a bidder without a single edge: the ingest excludes it
+            mine[j] = mine[j] && G[j] >= 0;
+        }
+    }
+    MISSLAP_ESTAMP(3);
 #pragma unroll
     for (int j = 0; j < kTileRows; ++j) {
-        const double V = group_max_f64<kGL>(sv[j]);
-        const int gsel = sv[j] == V ? sg[j] : -1;
-        const int G = group_max_i32<kGL>(gsel);
-        const double wsel = sg[j] == G ? sw[j] : sv[j];
-        W[j] = group_max_f64<kGL>(wsel);
-        mine[j] = person[j] >= 0 && sg[j] == G && G >= 0;  // exactly one lane of the group
         const int pj = max(person[j], 0);
-        best[j].x = ta.tcol[max(G, 0)];                    // unconditional loads, used under `mine`
-        best[j].y = (int)ta.tpk[(max(G, 0) >> 1) * 3 + 1 + (max(G, 0) & 1)];
+        if (kCS == 1) {  // `mine` is the lane that met the best edge
+            best[j].x = scol[j];
+            best[j].y = scost[j];
+        } else {         // any workgroup of the slice may hold it: through its position (unconditional loads, used under `mine`)
+            best[j].x = ta.tcol[max(G[j], 0)];
+            best[j].y = (int)ta.tpk[(max(G[j], 0) >> 1) * 3 + 1 + (max(G[j], 0) & 1)];
+        }
         rlen[j] = a.row_ptr[pj + 1] - a.row_ptr[pj];
     }
 #pragma unroll
@@ -860,11 +983,7 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
             nb += 1;
         }
     }
-    // statistics: one atomic per workgroup.  The scratch lives BEHIND the price buffers in the dynamic allocation:
-    // a static __shared__ array would be placed first and shift s_price off LDS address 0, which costs one
-    // v_add per price look-up (the edges carry absolute LDS offsets)
-    unsigned long long *s_e = reinterpret_cast<unsigned long long *>(s_price + (kDouble ? kBufDoubles + kTileCols : kTileCols + 2));
-    int *s_n = reinterpret_cast<int *>(s_e + kTileThreads / kWave);
+    // statistics: one atomic per workgroup
     for (int off = 32; off >= 1; off >>= 1) {
         edges += ((unsigned long long)__shfl_xor((unsigned)(edges >> 32), off) << 32) |
                  (unsigned long long)__shfl_xor((unsigned)(edges & 0xffffffffull), off);
@@ -891,75 +1010,8 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
             if (a.launch_edges) atomicAdd(&a.launch_edges[a.launch_idx], te);
         }
     }
-}
-
-// The second launch of a column-split shape: one thread per bidder slot merges the two partial top-2s with the merge
-// operator of the reduction (the later stored position wins a tie: positions of a person grow with the tile), forms the
-// bid (:360), publishes it and feeds the per-object maximum exactly like the epilogue of the unsplit kernel.
-// (At most 128 workgroups of 1024 threads and ONE set of statistics atomics per workgroup: the counters are single
-// words, and ~10 000 same-address atomics -- one set per wavefront of a 782-block grid -- took longer than the scan.)
-__global__ __launch_bounds__(1024) void k_tiled_merge(RoundArgs a, TiledArgs ta) {
-    __shared__ unsigned long long s_e[16];
-    __shared__ int s_n[16], s_err[16];
-    const Ctl *ctl = a.ctl;
-    if (!round_live(ctl, a.thr) || ctl->K < ta.min_K) return;
-    int lo, hi;
-    shard_range(ctl->K, a.rank, a.world, a.shard_min_K, lo, hi);
-    const double eps = (double)a.eps;
-    unsigned long long edges = 0;
-    int nb = 0, err = 0;
-    for (int slot = lo + (int)(blockIdx.x * blockDim.x + threadIdx.x); slot < hi; slot += (int)(gridDim.x * blockDim.x)) {
-        const double2 A = ta.part_vw[slot], B = ta.part_vw[(size_t)ta.part_stride + slot];
-        const int ga = ta.part_g[slot], gb = ta.part_g[(size_t)ta.part_stride + slot];
-        const bool takeB = (gb >= 0) & ((ga < 0) | (B.x > A.x) | ((B.x == A.x) & (gb > ga)));
-        const int G = takeB ? gb : ga;
-        const double W = takeB ? __builtin_fmax(B.y, ga >= 0 ? A.x : -__builtin_huge_val())
-                               : __builtin_fmax(A.y, gb >= 0 ? B.x : -__builtin_huge_val());
-        const int person = (ta.order_person ? ta.order_person : a.U)[slot];
-        const int pos = ta.order_pos ? ta.order_pos[slot] : slot;
-        if (G < 0) {
-            err |= kErrRowGap;  // a bidder without a single edge: the ingest excludes it
-            continue;
-        }
-        const int col = ta.tcol[G];
-        const double cost = (double)__int_as_float((int)ta.tpk[(G >> 1) * 3 + 1 + (G & 1)]);
-        const double bid = (cost - W) + eps;  // :360
-        if (bid_is_bad(bid)) err |= kErrNegativeBid;
-        const unsigned long long key = bid_to_key(bid);
-        a.bid_key[pos] = key;
-        a.bid_obj[pos] = col;
-        atomicMax(&a.best_key[col], key);
-        edges += (unsigned long long)(a.row_ptr[person + 1] - a.row_ptr[person]);
-        nb += 1;
-    }
-    for (int off = 32; off >= 1; off >>= 1) {
-        edges += ((unsigned long long)__shfl_xor((unsigned)(edges >> 32), off) << 32) |
-                 (unsigned long long)__shfl_xor((unsigned)(edges & 0xffffffffull), off);
-        nb += __shfl_xor(nb, off);
-        err |= __shfl_xor(err, off);
-    }
-    if ((threadIdx.x & 63) == 0) {
-        s_e[threadIdx.x >> 6] = edges;
-        s_n[threadIdx.x >> 6] = nb;
-        s_err[threadIdx.x >> 6] = err;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long te = 0;
-        int tb = 0, terr = 0;
-        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) {
-            te += s_e[w];
-            tb += s_n[w];
-            terr |= s_err[w];
-        }
-        if (terr) atomicOr(&a.ctl->err, terr);
-        if (tb) {
-            atomicAdd(&a.ctl->edges, te);
-            if (a.world > 1 && a.ctl->K >= a.shard_min_K) atomicAdd(&a.ctl->shard_edges, te);
-            atomicAdd(&a.ctl->bids, (unsigned long long)tb);
-            if (a.launch_edges) atomicAdd(&a.launch_edges[a.launch_idx], te);
-        }
-    }
+    MISSLAP_ESTAMP(4);
+    MISSLAP_EFLUSH();
 }
 
 }  // namespace misslap

@@ -120,7 +120,7 @@ const int kTiledShapes[kNumTiledShapes][8] = {
     X(8, 1024, 4, 2, 2, kTileColsHalf, 3, 8, 1) X(9, 1024, 4, 2, 2, kTileColsHalf, 3, 16, 1)
 inline size_t tiled_lds_bytes(int tile_cols) {  // see the LDS map in k_bid_tiled; + statistics scratch
     const size_t doubles = tile_cols == kTileColsBig ? (size_t)tile_cols + 2 : 2 * (size_t)tile_cols + 128;
-    return doubles * sizeof(double) + 16 * 12;  // + statistics scratch
+    return doubles * sizeof(double) + 16 * 12 + 16;  // + statistics scratch + the arrival word of a column-split shape
 }
 
 // Profiled launches (options.profile): the two events are handed to the launch itself (hipExtLaunchKernel), so they
@@ -202,8 +202,9 @@ struct misslap_solver {
     int *ovf_ptr = nullptr;  // per-person lists of the edges beyond ovf_cap in a (person, tile) segment
     int4 *ovf_q = nullptr;   // ... their entries {tile-major position, column, value bits, 0}
     int ovf_cap = 0;
-    double2 *part_vw = nullptr;  // column-split launch shapes: per-(column half, bidder slot) partial top-2 (k_tiled_merge)
+    double2 *part_vw = nullptr;  // column-split launch shapes: per-(share of the tiles, bidder slot) partial top-2
     int *part_g = nullptr;
+    int *split_cnt = nullptr;    // ... and the arrival counter of every slice 
     int n_tiled = 0;  // entries of `tiled` including the padding entries
     int T = 0;
     bool tiled_ok = false;
@@ -505,7 +506,7 @@ int launch_bid_tiled(misslap_solver *h) {
     if (grid < spread) grid = spread;
     grid *= cs;
     TiledArgs ta{reinterpret_cast<const unsigned *>(h->tiled), h->tcol, h->seg4, h->T, h->tiled_min_K, h->n_tiled,
-                 nullptr, nullptr, h->ovf_ptr, h->ovf_q, h->ovf_cap, h->part_vw, h->part_g, h->n_rows};
+                 nullptr, nullptr, h->ovf_ptr, h->ovf_q, h->ovf_cap, h->part_vw, h->part_g, h->n_rows, h->split_cnt};
     // A partial round whose K the host knows: bidders in person order (kernels_tiled.hpp, k_order_*).  Scratch that
     // is idle during a bid phase: the compaction lists (the tie-break reads order_pos before they are rewritten),
     // the chunk counters, the objective's match counters.
@@ -538,18 +539,6 @@ int launch_bid_tiled(misslap_solver *h) {
         MISSLAP_FOR_TILED_SHAPES(X)
 #undef X
         default: return fail(MISSLAP_ERR_STATE, "bad tiled shape");
-    }
-    if (cs > 1) {
-        // the second launch of a column-split shape merges the halves' partial top-2s into the bids.  A profiled launch
-        // is timed from the begin of the scan kernel to the end of the merge kernel (the gap between them included).
-        const dim3 mg((unsigned)std::min<long long>(128, (share + 1023) / 1024)), mb(1024);
-        if (pr && !plain_events()) {
-            // (the scan kernel's own end timestamp went into pr->stop above; the merge launch overwrites it)
-            hipExtLaunchKernelGGL(k_tiled_merge, mg, mb, 0, h->stream, nullptr, pr->stop, 0, a, ta);
-        } else {
-            hipLaunchKernelGGL(k_tiled_merge, mg, mb, 0, h->stream, a, ta);
-            if (pr) (void)hipEventRecord(pr->stop, h->stream);
-        }
     }
     HIP_TRY(hipGetLastError());
     return MISSLAP_OK;
@@ -1003,6 +992,7 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
         if (h->tiled_ok && kTiledShapes[h->tiled_shape][7] > 1) {
             blk.want(&h->part_vw, (size_t)kTiledShapes[h->tiled_shape][7] * N);
             blk.want(&h->part_g, (size_t)kTiledShapes[h->tiled_shape][7] * N);
+            blk.want(&h->split_cnt, (size_t)N / 256 + 1024);  // >= slices of any launch (a slice holds >= 256 bidders or the grid is one CU round)
         }
         if (h->profile) {
             h->launch_edges_cap = 1 << 20;
@@ -1013,6 +1003,7 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
     }
     HIP_TRY(hipMemsetAsync(h->price, 0, sizeof(double) * Mpad, h->stream));
     HIP_TRY(hipMemsetAsync(h->bid_rec, 0, sizeof(int4) * kRoundSmallMax, h->stream));
+    if (h->split_cnt) HIP_TRY(hipMemsetAsync(h->split_cnt, 0, sizeof(int) * ((size_t)N / 256 + 1024), h->stream));
     if (h->profile)
         HIP_TRY(hipMemsetAsync(h->launch_edges, 0, sizeof(unsigned long long) * h->launch_edges_cap, h->stream));
     if (!h->h_ctl) HIP_TRY(hipHostMalloc((void **)&h->h_ctl, 3 * sizeof(Ctl)));  // the mirror and the two trailing status copies
@@ -1972,7 +1963,7 @@ MISSLAP_API int misslap_debug_time_bid(misslap_solver *h, int32_t mode, int32_t 
         RoundArgs a = round_args(h);
         a.launch_edges = nullptr;
         TiledArgs ta{reinterpret_cast<const unsigned *>(h->tiled), h->tcol, h->seg4, h->T, 1, h->n_tiled,
-                     nullptr, nullptr, h->ovf_ptr, h->ovf_q, h->ovf_cap, h->part_vw, h->part_g, h->n_rows};
+                     nullptr, nullptr, h->ovf_ptr, h->ovf_q, h->ovf_cap, h->part_vw, h->part_g, h->n_rows, h->split_cnt};
         hipEvent_t t0, t1;
         HIP_TRY(hipEventCreate(&t0));
         HIP_TRY(hipEventCreate(&t1));
