@@ -42,6 +42,9 @@ struct RoundArgs {
     double *cand64;               // ... their fp64 costs (12 B/edge layout only, nullptr otherwise)
     int cand_build_max_K;         // k_bid uses and (re)builds lines only in rounds with K <= this
     int cand_refresh_min;         // ... and treats a hit that leaves fewer live candidates than this as a miss
+    unsigned long long *wg_stats; // k_bid_tiled's statistics, {edges, bids} per workgroup (plain stores: 256 workgroups
+    int n_wg_stats;               // ending together on the same two counters cost the scan 1.7 us); k_apply adds up the
+                                  // n_wg_stats slots the round's scan launch may have written and clears them
 };
 
 __device__ __forceinline__ bool round_live(const Ctl *c, int thr) {
@@ -402,6 +405,26 @@ __global__ __launch_bounds__(256) void k_tiebreak(RoundArgs a, const int *order_
 __global__ __launch_bounds__(256) void k_apply(RoundArgs a) {
     Ctl *ctl = a.ctl;
     if (!round_live(ctl, a.thr)) return;
+    if (a.n_wg_stats > 0 && blockIdx.x == 0 && threadIdx.x < kWave) {  // the scan's statistics (see RoundArgs::wg_stats)
+        unsigned long long e = 0, b = 0;
+        for (int k = threadIdx.x; k < a.n_wg_stats; k += kWave) {
+            const unsigned long long ek = a.wg_stats[2 * k], bk = a.wg_stats[2 * k + 1];
+            if (ek | bk) {
+                e += ek;
+                b += bk;
+                a.wg_stats[2 * k] = 0ull;
+                a.wg_stats[2 * k + 1] = 0ull;
+            }
+        }
+        for (int off = 32; off >= 1; off >>= 1) {
+            e += ((unsigned long long)__shfl_xor((unsigned)(e >> 32), off) << 32) | (unsigned long long)__shfl_xor((unsigned)(e & 0xffffffffull), off);
+            b += ((unsigned long long)__shfl_xor((unsigned)(b >> 32), off) << 32) | (unsigned long long)__shfl_xor((unsigned)(b & 0xffffffffull), off);
+        }
+        if (threadIdx.x == 0 && (e | b)) {
+            atomicAdd(&ctl->edges, e);
+            atomicAdd(&ctl->bids, b);
+        }
+    }
     int holes = 0;
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < a.n_cols; j += gridDim.x * blockDim.x) {
         const int n = a.best_pos[j];

@@ -459,6 +459,7 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
     constexpr int kWaves = kTileThreads / kWave;
     const int wave_u = __builtin_amdgcn_readfirstlane(t >> 6);
     const bool loader = kLoaders > 0 && wave_u >= kWaves - kLoaders;
+    const bool full = ctl->K == a.n_rows && !ta.order_person;  // uniform
     int person[kTileRows];
     double sv[kTileRows], sw[kTileRows];
     int sg[kTileRows];  // position of the lane's best element ...
@@ -470,7 +471,9 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
 #pragma unroll
     for (int j = 0; j < kTileRows; ++j) {
         const int pos = p0 + j * kTileGroups + group;
-        const int u = (ta.order_person ? ta.order_person : a.U)[min(pos, p1 - 1)];  // unconditional load (see the note above), masked afterwards
+        // (a full scan opens an eps-phase: K = N and the list is the identity, k_reset_phase -- one memory latency less
+        // in front of the first segment loads)
+        const int u = full ? pos : (ta.order_person ? ta.order_person : a.U)[min(pos, p1 - 1)];  // unconditional load (see the note above), masked afterwards
         person[j] = (pos < p1 && !loader) ? u : -1;
         sv[j] = ninf;
         sw[j] = ninf;
@@ -954,7 +957,7 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
             mine[j] = mine[j] && G[j] >= 0;
         }
     }
-    MISSLAP_ESTAMP(3);
+    if (kCS > 1) MISSLAP_ESTAMP(3);
 #pragma unroll
     for (int j = 0; j < kTileRows; ++j) {
         const int pj = max(person[j], 0);
@@ -967,6 +970,7 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
         }
         rlen[j] = a.row_ptr[pj + 1] - a.row_ptr[pj];
     }
+    if (kCS == 1) MISSLAP_ESTAMP(2);  // (unsplit shapes: [8] = the row lengths have landed, [9] = the bids' stores and atomics have retired)
 #pragma unroll
     for (int j = 0; j < kTileRows; ++j) {
         if (mine[j]) {
@@ -983,6 +987,7 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
             nb += 1;
         }
     }
+    if (kCS == 1) MISSLAP_ESTAMP(3);
     // statistics: one atomic per workgroup
     for (int off = 32; off >= 1; off >>= 1) {
         edges += ((unsigned long long)__shfl_xor((unsigned)(edges >> 32), off) << 32) |
@@ -1003,10 +1008,10 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
             te += s_e[w];
             tb += s_n[w];
         }
-        if (tb) {
-            atomicAdd(&a.ctl->edges, te);
+        if (tb) {  // (no other workgroup touches my slot; k_apply collects, see RoundArgs::wg_stats)
+            a.wg_stats[2 * blockIdx.x] += te;
+            a.wg_stats[2 * blockIdx.x + 1] += (unsigned long long)tb;
             if (a.world > 1 && a.ctl->K >= a.shard_min_K) atomicAdd(&a.ctl->shard_edges, te);
-            atomicAdd(&a.ctl->bids, (unsigned long long)tb);
             if (a.launch_edges) atomicAdd(&a.launch_edges[a.launch_idx], te);
         }
     }

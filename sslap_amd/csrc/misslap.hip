@@ -204,6 +204,9 @@ struct misslap_solver {
     int ovf_cap = 0;
     double2 *part_vw = nullptr;  // column-split launch shapes: per-(share of the tiles, bidder slot) partial top-2
     int *part_g = nullptr;
+    unsigned long long *wg_stats = nullptr;  // RoundArgs::wg_stats ({edges, bids} per workgroup of a scan launch)
+    int wg_stats_slots = 0;                  // ... allocated
+    int wg_stats_pending = 0;                // ... that the last scan launch may have written (collected by the next k_apply)
     int *split_cnt = nullptr;    // ... and the arrival counter of every slice 
     int n_tiled = 0;  // entries of `tiled` including the padding entries
     int T = 0;
@@ -423,6 +426,8 @@ RoundArgs round_args(misslap_solver *h) {
     a.shard_min_K = h->world > 1 ? h->shard_min_K : 0;
     a.eps = h->eps;
     a.launch_idx = 0;
+    a.wg_stats = h->wg_stats;
+    a.n_wg_stats = 0;
     a.gather_max_K = h->tiled_ok ? h->tiled_min_K : 0;
     a.cand = h->cand;
     a.cand64 = h->cand64;
@@ -531,6 +536,8 @@ int launch_bid_tiled(misslap_solver *h) {
         pr->fullscan = h->phase_fresh;  // K == N; with several ranks: this rank's share of the full scan
         pr->launch_idx = a.launch_idx = h->launch_idx++;
     }
+    if (grid > h->wg_stats_slots) return fail(MISSLAP_ERR_STATE, "scan grid %lld exceeds the statistics slots (%d)", grid, h->wg_stats_slots);
+    h->wg_stats_pending = std::max(h->wg_stats_pending, (int)grid);
     const size_t lds = tiled_lds_bytes(shp[4]);
     const dim3 g((unsigned)grid);
     switch (h->tiled_shape) {
@@ -622,6 +629,8 @@ int launch_apply(misslap_solver *h) {
     }
     h->K_exact = false;
     h->round_ordered = false;
+    a.n_wg_stats = h->wg_stats_pending;
+    h->wg_stats_pending = 0;
     hipLaunchKernelGGL(k_apply, dim3(blocks_for(h->n_cols, 256)), dim3(256), 0, h->stream, a);
     if (h->K_ub <= kCompactSmallMax) {
         hipLaunchKernelGGL(k_compact_small, dim3(1), dim3(1024), 0, h->stream, a);
@@ -989,6 +998,8 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
         blk.want(&h->ctl, 1);
         blk.want(&h->contrib, N);
         blk.want(&h->nmatch, N);
+        h->wg_stats_slots = (int)std::min<size_t>(N / 64 + 4096, 1u << 22);
+        blk.want(&h->wg_stats, 2 * (size_t)h->wg_stats_slots);
         if (h->tiled_ok && kTiledShapes[h->tiled_shape][7] > 1) {
             blk.want(&h->part_vw, (size_t)kTiledShapes[h->tiled_shape][7] * N);
             blk.want(&h->part_g, (size_t)kTiledShapes[h->tiled_shape][7] * N);
@@ -1003,6 +1014,7 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
     }
     HIP_TRY(hipMemsetAsync(h->price, 0, sizeof(double) * Mpad, h->stream));
     HIP_TRY(hipMemsetAsync(h->bid_rec, 0, sizeof(int4) * kRoundSmallMax, h->stream));
+    HIP_TRY(hipMemsetAsync(h->wg_stats, 0, sizeof(unsigned long long) * 2 * (size_t)h->wg_stats_slots, h->stream));
     if (h->split_cnt) HIP_TRY(hipMemsetAsync(h->split_cnt, 0, sizeof(int) * ((size_t)N / 256 + 1024), h->stream));
     if (h->profile)
         HIP_TRY(hipMemsetAsync(h->launch_edges, 0, sizeof(unsigned long long) * h->launch_edges_cap, h->stream));
