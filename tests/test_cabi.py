@@ -91,8 +91,10 @@ def test_options_struct_size_versions_are_recognised():
     assert rc == _lib.ERR_INVALID and "reserved" in msg
     rc, msg = create(_lib.Options(struct_size=C.sizeof(_lib.Options), cand_mode=7))
     assert rc == _lib.ERR_INVALID and "cand_mode" in msg
-    rc, msg = create(_lib.Options(struct_size=C.sizeof(_lib.Options), tiled_shape=5))  # shape 4 was retired
-    assert rc in (_lib.ERR_INVALID, _lib.ERR_NO_DEVICE)
+    rc, msg = create(_lib.Options(struct_size=C.sizeof(_lib.Options), tiled_shape=99))  # beyond the shape table
+    assert rc == _lib.ERR_INVALID and "tiled_shape" in msg
+    rc, msg = create(_lib.Options(struct_size=C.sizeof(_lib.Options), tiled_shape=5))  # a valid shape (the column split): only the GPU is missing
+    assert rc in (0, _lib.ERR_NO_DEVICE), msg
 
 
 def test_trim_caches_needs_no_gpu():

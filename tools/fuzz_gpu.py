@@ -35,7 +35,7 @@ for seed in range(first, first + count):
                cand=[None, None, None, False][(seed // 5) % 4])
     if gpu["tiled_min_k"] == 1:
         gpu["engine"] = 1  # build the tile-major copy whatever the size
-        gpu["tiled_shape"] = [None, 4, 8, 9, 7][(seed // 4) % 5]  # launch shape (4: the column split + merge kernel)
+        gpu["tiled_shape"] = [None, 4, 8, 9, 7][(seed // 4) % 5]  # launch shape (4: the column split, merge fused into the scan)
     gpu = {k: v for k, v in gpu.items() if v is not None}
     o = orc.from_sparse(loc, val.copy(), **kw)
     osol = o.solve()
