@@ -254,28 +254,33 @@ static void bid_and_assign(oracle_solver *s) {
     free(bids);
 }
 
-/* auction_.pyx:443-485 eCE_satisfied(eps) with tol = 1e-7 (:16) */
-static int eCE_satisfied(const oracle_solver *s, float eps_f) {
-    if (s->num_unassigned > 0) return 0;
+/* auction_.pyx:443-485 eCE_satisfied(eps) with tol = 1e-7 (:16), on plain arrays: the loop of the reference for ANY
+ * state with everybody assigned (tests put the GPU's eCE pass next to it at every end of an eps-phase) */
+ORACLE_API int oracle_ece_arrays(int64_t num_rows, const int *i_starts_stops, const int *flat_j, const double *val,
+                                 const double *p, const int *person_to_object, float eps_f) {
     const double tol = 1e-7;
     const double eps = (double)eps_f;
-    for (size_t i = 0; i < (size_t)s->num_rows; ++i) {
-        size_t num_objects = (size_t)s->j_counts[i];
-        size_t start = (size_t)s->i_starts_stops[i];
-        size_t j = (size_t)s->person_to_object[i];
-        double choice_cost = 0.0;
+    double choice_cost = 0.0; /* NOT reset per row: the reference declares it once (:450) */
+    for (size_t i = 0; i < (size_t)num_rows; ++i) {
+        size_t start = (size_t)i_starts_stops[i];
+        size_t num_objects = (size_t)i_starts_stops[i + 1] - start;
+        size_t j = (size_t)person_to_object[i];
         for (size_t idx = 0; idx < num_objects; ++idx) { /* :467-471 (last match) */
             size_t g = start + idx;
-            if ((size_t)s->flat_j[g] == j) choice_cost = s->val[g];
+            if ((size_t)flat_j[g] == j) choice_cost = val[g];
         }
-        double LHS = choice_cost - s->p[j] + tol; /* :475 */
+        double LHS = choice_cost - p[j] + tol; /* :475 */
         for (size_t idx = 0; idx < num_objects; ++idx) {
             size_t g = start + idx;
-            double v = s->val[g] - s->p[s->flat_j[g]];
+            double v = val[g] - p[flat_j[g]];
             if (LHS < v - eps) return 0; /* :482 */
         }
     }
     return 1;
+}
+static int eCE_satisfied(const oracle_solver *s, float eps_f) {
+    if (s->num_unassigned > 0) return 0; /* :446-447 */
+    return oracle_ece_arrays(s->num_rows, s->i_starts_stops, s->flat_j, s->val, s->p, s->person_to_object, eps_f);
 }
 
 /* auction_.pyx:433-439 */

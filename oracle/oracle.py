@@ -56,6 +56,8 @@ def lib():
             f = getattr(L, name)
             f.argtypes = [C.c_void_p]
             f.restype = C.POINTER(typ)
+        L.oracle_ece_arrays.restype = C.c_int
+        L.oracle_ece_arrays.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float]
         L.oracle_dense_to_coo.restype = C.c_int64
         L.oracle_dense_to_coo.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
         _LIB = L
@@ -120,6 +122,20 @@ class OracleSolver:
                           t_bid=float(m.t_bid), t_total=float(m.t_total), final_eps_f32=float(m.final_eps),
                           start_eps_f32=float(m.start_eps))
         return np.ctypeslib.as_array(lib().oracle_person_to_object(self._h), (self.N,)).copy()
+
+
+def ece_satisfied(loc, val, problem, prices, person_to_object, eps):
+    """eCE_satisfied(eps) (auction_.pyx:443-485) for a state with everybody assigned, given as arrays: the caller's
+    loc / val (val in the caller's sign; the solver works on -val for 'min', :236-237), prices, person_to_object."""
+    loc = np.ascontiguousarray(loc, dtype=np.int32)
+    n = int(loc[:, 0].max()) + 1
+    row_ptr = np.searchsorted(loc[:, 0], np.arange(n + 1)).astype(np.int32)  # rows are sorted (cumulative_idxs, :33-48)
+    cols = np.ascontiguousarray(loc[:, 1])
+    v = np.ascontiguousarray(val if problem == "max" else -val, dtype=np.float64)
+    p = np.ascontiguousarray(prices, dtype=np.float64)
+    p2o = np.ascontiguousarray(person_to_object, dtype=np.int32)
+    return bool(lib().oracle_ece_arrays(n, row_ptr.ctypes.data, cols.ctypes.data, v.ctypes.data, p.ctypes.data,
+                                        p2o.ctypes.data, float(np.float32(eps))))
 
 
 def from_matrix(mat, problem="min", eps_start=0.0, max_iter=1000000, fast=False, cardinality_check=True):

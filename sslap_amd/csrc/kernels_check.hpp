@@ -1,31 +1,125 @@
-// kernels_check.hpp -- full-CSR reductions that run once per eps-phase / once per solve:
-// the eps-complementary-slackness test (auction_.pyx:443-485) and the objective (:489-523).
+// kernels_check.hpp -- full-CSR reductions that run once per eps-phase / once per solve: the
+// eps-complementary-slackness test (auction_.pyx:443-485), the objective (:489-523) and the validity flags of the
+// reference's benchmark harness (benchmarking.py:56-64).
 #pragma once
 #include "device_common.hpp"
 
 namespace misslap {
 
-// eCE_satisfied(eps), one wavefront per person (only called with K == 0: everybody assigned).
+// ---- what a pass over the rows of the CSR has to find, per person ------------------------------------------------
+// eCE_satisfied (auction_.pyx:443-485), get_obj (:489-523) and the validity flags of the reference's benchmark harness
+// (benchmarking.py:56-64) all look for the same stored entry -- (i, p2o[i]), the LAST one if it is stored more than
+// once -- and the eCE test needs the row maximum of (val_k - p[col_k]) on top.  So one pass serves all three:
 //   choice_cost = value of the LAST stored entry of row i whose column is p2o[i]      (:467-471)
 //   LHS = (choice_cost - p[j]) + tol                                                  (:475)
 //   violated if for some entry k of the row  LHS < (val_k - p[col_k]) - eps           (:482)
-// x -> fl(x - eps) is monotone, so "some k" is equivalent to testing the row maximum of
-// (val_k - p[col_k]) only; choice and maximum are found in ONE pass over the row.
+// x -> fl(x - eps) is monotone, so "some k" is equivalent to testing the row maximum only.
+//
+// Where the answer comes from.  The test is ONE bit over all rows, and at the end of every eps-phase but the last it
+// fails for 40-100 % of them (counted on C1-C4 at every end of a phase: the first failing row is row 0 or 1 every time).  So
+// the host first launches the pass on a small SAMPLE of the rows (k_ece on the first kEceSampleRows persons, a few
+// microseconds); the full pass that follows starts by reading the flag and returns at once when the sample has
+// already failed.  Only a check that passes -- the last phase's and the one behind meta['eCE'] -- pays a full scan,
+// and that scan runs on the bandwidth engine where the handle has the tile-major layout (k_bid_tiled, MODE 1).
+constexpr int kEceSampleRows = 4096;
+
+// Sums of the final pass, kept per lane and flushed once per wavefront (flush_final).
+struct FinalAcc {
+    int distinct = 0, n_neg = 0, n_big = 0, n_inv = 0, dups = 0, min_exp = 1 << 20;
+    double abs_sum = 0.0;
+    bool bad = false;
+};
+struct FinalOut {
+    int fin;          // 0: eCE test only; 1: also the objective's contributions and the validity counters
+    int maximize;
+    const int *o2p;
+    double *contrib;  // [n_rows]
+    int *nmatch;      // [n_rows]
+    int n_rows, n_cols;
+};
+// The column the passes look for: p2o[i], with numpy's index wrap-around for the validity flags (sol[i] = -1 selects
+// the LAST column: benchmarking.py:59 indexes mat[arange(size), sol]); -1 when that is no column at all.
+__device__ __forceinline__ int wanted_column(int j, int n_cols) {
+    const int c = j < 0 ? n_cols + j : j;
+    return (c >= 0 && c < n_cols) ? c : -1;
+}
+// One person, by the ONE lane that knows the result of the row pass: j = p2o[i]; found / cnt / cost = the last stored
+// entry (i, wanted_column(j)), how often it is stored, its (sign-flipped) stored value; vmax = the row maximum of
+// val - price; pj = price of the wanted column.
+__device__ __forceinline__ void final_person(FinalAcc &acc, const FinalOut &fo, int i, int j, bool found, int cnt,
+                                             double cost, double vmax, double pj, double eps) {
+    const double tol = 1e-7;  // auction_.pyx:16
+    // an assigned column that is not in the row cannot happen (the reference would reuse the previous row's cost)
+    acc.bad |= !found || ((cost - pj) + tol) < (vmax - eps);
+    if (!fo.fin) return;
+    // get_obj (:508-521): unassigned persons are skipped; the stored values are sign-flipped for 'min'
+    const int n = j != -1 ? cnt : 0;
+    const double cv = (n == 1) ? (fo.maximize ? cost : -cost) : 0.0;  // rows with n > 1 are re-added by k_obj_sum
+    fo.contrib[i] = cv;
+    fo.nmatch[i] = n;
+    acc.dups += n > 1;
+    if (cv != 0.0) {  // binary exponent of the lowest set bit of cv
+        const unsigned long long b = (unsigned long long)__double_as_longlong(cv) & 0x7fffffffffffffffull;
+        const int ex = (int)(b >> 52);
+        const unsigned long long mant = (b & 0xfffffffffffffull) | (ex ? (1ull << 52) : 0ull);
+        const int q = (ex ? ex - 1075 : -1074) + (__ffsll((long long)mant) - 1);
+        acc.min_exp = q < acc.min_exp ? q : acc.min_exp;
+        acc.abs_sum += cv < 0.0 ? -cv : cv;
+    }
+    // validity flags (benchmarking.py:56-64), counters in Ctl::val_cnt:
+    //   [0] persons i with an object j >= 0 that names i as its owner: the number of DISTINCT objects in sol whenever
+    //       the two maps are consistent -- np.unique(sol).size minus the -1 value
+    //   [1] persons with sol[i] < 0        [2] persons with sol[i] >= n_rows
+    //   [3] persons whose selected entry is missing or negative in the caller's sign (of several stored entries
+    //       (i, c) the last one counts: a dense matrix built from loc / val keeps the last assignment)
+    acc.n_inv += !(found && dense_entry_valid(fo.maximize ? cost : -cost));
+    acc.n_neg += j < 0;
+    acc.n_big += j >= fo.n_rows;
+    acc.distinct += (j >= 0 && j < fo.n_cols && fo.o2p[j] == i);
+}
+// wave-wide sums of the accumulators, one set of atomics per wavefront
+__device__ __forceinline__ void flush_final(Ctl *ctl, const FinalOut &fo, FinalAcc acc) {
+    if (__ballot(acc.bad) && lane_id() == 0) atomicOr(&ctl->ece_fail, 1);
+    if (!fo.fin) return;
+    for (int off = 32; off >= 1; off >>= 1) {
+        acc.distinct += __shfl_xor(acc.distinct, off);
+        acc.n_neg += __shfl_xor(acc.n_neg, off);
+        acc.n_big += __shfl_xor(acc.n_big, off);
+        acc.n_inv += __shfl_xor(acc.n_inv, off);
+        acc.dups += __shfl_xor(acc.dups, off);
+        acc.min_exp = min(acc.min_exp, __shfl_xor(acc.min_exp, off));
+        acc.abs_sum += shfl_xor_f64(acc.abs_sum, off);  // (any order: only a bound, see k_obj_sum)
+    }
+    if (lane_id() != 0) return;
+    if (acc.distinct) atomicAdd(&ctl->val_cnt[0], (unsigned long long)acc.distinct);
+    if (acc.n_neg) atomicAdd(&ctl->val_cnt[1], (unsigned long long)acc.n_neg);
+    if (acc.n_big) atomicAdd(&ctl->val_cnt[2], (unsigned long long)acc.n_big);
+    if (acc.n_inv) atomicAdd(&ctl->val_cnt[3], (unsigned long long)acc.n_inv);
+    if (acc.dups) atomicAdd(&ctl->dup_rows, acc.dups);
+    if (acc.abs_sum != 0.0) {
+        atomicMin(&ctl->obj_minexp, acc.min_exp);
+        atomicAdd(&ctl->obj_abs, acc.abs_sum);
+    }
+}
+
+// The pass on the row-major CSR, one wavefront per person (handles without the tile-major layout, and the sample).
+// Branch-free: every load is unconditional (clamped index), a masked-off element has value -inf and matches nothing.
+// fo.fin = 0 (eCE only): every wavefront stops as soon as any row has failed.
 template <class E>
 __global__ __launch_bounds__(256) void k_ece(Ctl *ctl, E ed, const int *row_ptr, const double *price,
-                                             const int *p2o, int n_rows, float eps_f) {
+                                             const int *p2o, int n_rows, float eps_f, FinalOut fo) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const double tol = 1e-7;  // auction_.pyx:16
     const double eps = (double)eps_f;
     const double ninf = -__builtin_huge_val();
+    FinalAcc acc;
     for (int i = blockIdx.x * 4 + wave; i < n_rows; i += gridDim.x * 4) {
-        // The answer is one bit.  Once any row has failed, the rest of the pass is pointless -- and at the end of
-        // every eps-phase but the last the test fails for most rows: 200 000 atomicOr on one word cost 1.1 ms.
-        if (__atomic_load_n(&ctl->ece_fail, __ATOMIC_RELAXED)) return;  // wave-uniform
+        if (!fo.fin && __atomic_load_n(&ctl->ece_fail, __ATOMIC_RELAXED)) break;  // wave-uniform
         const int s = row_ptr[i], e = row_ptr[i + 1];
         const int j = p2o[i];
-        double vmax = ninf;
-        int gsel = -1;
+        const int want = wanted_column(j, fo.n_cols);
+        const double pj = price[max(want, 0)];
+        double vmax = ninf, asel = 0.0;
+        int gsel = -1, cnt = 0;
         for (int base = s; base < e; base += 4 * kWave) {  // four 64-edge chunks in flight, like wave_bid
             int c[4];
             double a[4], pr[4];
@@ -36,139 +130,32 @@ __global__ __launch_bounds__(256) void k_ece(Ctl *ctl, E ed, const int *row_ptr,
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int g = base + u * kWave + lane;
-                if (g < e) {
-                    const double v = a[u] - pr[u];
-                    vmax = v > vmax ? v : vmax;
-                    if (c[u] == j) gsel = g;  // ascending g per lane: keeps the last match
-                }
+                const bool ok = g < e;
+                const double v = ok ? a[u] - pr[u] : ninf;
+                vmax = __builtin_fmax(vmax, v);
+                const bool m = ok & (c[u] == want);  // ascending g per lane: keeps the last match
+                gsel = m ? g : gsel;
+                asel = m ? a[u] : asel;
+                cnt += m;
             }
         }
         vmax = wave_max_f64(vmax);
-        gsel = wave_max_i32(gsel);
-        if (lane == 0) {
-            bool bad = true;  // an assigned column that is not in the row cannot happen
-            if (gsel >= 0) {
-                int c;
-                double choice_cost;
-                ed.load(gsel, c, choice_cost);
-                const double lhs = (choice_cost - price[j]) + tol;
-                bad = lhs < (vmax - eps);
-            }
-            if (bad) atomicOr(&ctl->ece_fail, 1);
-        }
+        const int gmax = wave_max_i32(gsel);
+        for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off);
+        const int sl = __ffsll((long long)__ballot(gsel == gmax)) - 1;  // (gmax = -1: any lane, the value is unused)
+        const double cost = readlane_f64(asel, sl);
+        if (lane == 0) final_person(acc, fo, i, j, gmax >= 0, cnt, cost, vmax, pj, eps);
     }
+    flush_final(ctl, fo, acc);
 }
 
-// Validity flags of the returned assignment, as the reference's benchmark harness forms them on the host
-// (benchmarking.py:56-64: complete_assignment = (np.unique(sol).size == size, (sol >= 0).all(), (sol < size).all()),
-// valid_assignment = (mat[arange(size), sol] >= 0).all(), size = number of rows), reduced here so that `sol` is the
-// only O(N) copy-out.  One wavefront per person; counters in Ctl::val_cnt (zeroed by the host before the launch):
-//   [0] persons i with an object j = sol[i] >= 0 that names i as its owner (o2p[j] == i): the number of DISTINCT
-//       objects in sol whenever the two maps are consistent -- np.unique(sol).size minus the -1 value
-//   [1] persons with sol[i] < 0        [2] persons with sol[i] >= n_rows
-//   [3] persons whose selected entry is missing or negative in the caller's sign.  numpy wraps a negative index
-//       around (sol[i] = -1 selects the LAST column), and so does this kernel; of several stored entries (i, c) the
-//       last one counts (a dense matrix built from loc / val keeps the last assignment).
-template <class E>
-__global__ __launch_bounds__(256) void k_validity(Ctl *ctl, E ed, const int *row_ptr, const int *p2o, const int *o2p,
-                                                  int n_rows, int n_cols, int maximize) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int distinct = 0, n_neg = 0, n_big = 0, n_inv = 0;
-    for (int i = blockIdx.x * 4 + wave; i < n_rows; i += gridDim.x * 4) {
-        const int j = p2o[i];
-        const int c = j < 0 ? n_cols + j : j;  // numpy index wrap-around
-        int gsel = -1;
-        const int s = row_ptr[i], e = row_ptr[i + 1];
-        for (int g = s + lane; g < e; g += kWave) {
-            int cc;
-            double v;
-            ed.load(g, cc, v);
-            if (cc == c) gsel = g;
-        }
-        gsel = wave_max_i32(gsel);
-        if (lane == 0) {
-            bool ok = false;
-            if (gsel >= 0) {
-                int cc;
-                double v;
-                ed.load(gsel, cc, v);
-                const double orig = maximize ? v : -v;  // the stored values are sign-flipped for 'min'
-                ok = dense_entry_valid(orig);
-            }
-            n_inv += !ok;
-            n_neg += j < 0;
-            n_big += j >= n_rows;
-            distinct += (j >= 0 && j < n_cols && o2p[j] == i);
-        }
-    }
-    if (lane == 0) {
-        if (distinct) atomicAdd(&ctl->val_cnt[0], (unsigned long long)distinct);
-        if (n_neg) atomicAdd(&ctl->val_cnt[1], (unsigned long long)n_neg);
-        if (n_big) atomicAdd(&ctl->val_cnt[2], (unsigned long long)n_big);
-        if (n_inv) atomicAdd(&ctl->val_cnt[3], (unsigned long long)n_inv);
-    }
-}
-
-__global__ void k_obj_reset(Ctl *ctl) {
+// everything the final pass accumulates into, in one launch
+__global__ void k_final_reset(Ctl *ctl) {
+    ctl->ece_fail = 0;
+    ctl->dup_rows = 0;
     ctl->obj_abs = 0.0;
     ctl->obj_minexp = 1 << 20;
-}
-
-// get_obj, step 1 (parallel): the contribution of every person, in row order inside the row:
-// contrib[i] = +val / -val of the stored entry (i, p2o[i]) ('max' / 'min'; val is the sign-flipped
-// copy, so obj -= val restores the caller's sign, :518-521).  Rows whose assigned column is stored
-// more than once are flagged and re-added sequentially in step 2.
-template <class E>
-__global__ __launch_bounds__(256) void k_obj_rows(Ctl *ctl, E ed, const int *row_ptr, const int *p2o,
-                                                  int n_rows, int maximize, double *contrib, int *nmatch) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    double abs_sum = 0.0;      // lane 0: bound material for the order-independence test of k_obj_sum
-    int min_exp = 1 << 20;
-    for (int i = blockIdx.x * 4 + wave; i < n_rows; i += gridDim.x * 4) {
-        const int j = p2o[i];
-        int cnt = 0, gsel = -1;
-        if (j != -1) {  // :508
-            const int s = row_ptr[i], e = row_ptr[i + 1];
-            for (int g = s + lane; g < e; g += kWave) {
-                int c;
-                double v;
-                ed.load(g, c, v);
-                if (c == j) {
-                    cnt += 1;
-                    gsel = g;
-                }
-            }
-        }
-        for (int off = 32; off >= 1; off >>= 1) {
-            cnt += __shfl_xor(cnt, off);
-            const int g2 = __shfl_xor(gsel, off);
-            gsel = g2 > gsel ? g2 : gsel;
-        }
-        if (lane == 0) {
-            double cv = 0.0;
-            if (cnt == 1) {
-                int c;
-                double v;
-                ed.load(gsel, c, v);
-                cv = maximize ? v : -v;
-            }
-            contrib[i] = cv;
-            nmatch[i] = cnt;
-            if (cnt > 1) atomicAdd(&ctl->dup_rows, 1);
-            if (cv != 0.0) {  // binary exponent of the lowest set bit of cv
-                const unsigned long long b = (unsigned long long)__double_as_longlong(cv) & 0x7fffffffffffffffull;
-                const int ex = (int)(b >> 52);
-                const unsigned long long mant = (b & 0xfffffffffffffull) | (ex ? (1ull << 52) : 0ull);
-                const int q = (ex ? ex - 1075 : -1074) + (__ffsll((long long)mant) - 1);
-                min_exp = q < min_exp ? q : min_exp;
-                abs_sum += cv < 0.0 ? -cv : cv;
-            }
-        }
-    }
-    if (lane == 0 && abs_sum != 0.0) {
-        atomicMin(&ctl->obj_minexp, min_exp);
-        atomicAdd(&ctl->obj_abs, abs_sum);
-    }
+    for (int k = 0; k < 4; ++k) ctl->val_cnt[k] = 0ull;
 }
 
 // get_obj, step 2: the reference adds in person order into ONE double (:491, :519-521); floating-point

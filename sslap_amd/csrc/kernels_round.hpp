@@ -400,12 +400,11 @@ __global__ __launch_bounds__(256) void k_tiebreak(RoundArgs a, const int *order_
     }
 }
 
-// One thread per object.  All writes of one round are disjoint: winners are distinct unassigned
-// persons, evicted owners are distinct assigned persons, and a winner's slot in U is its own.
-__global__ __launch_bounds__(256) void k_apply(RoundArgs a) {
-    Ctl *ctl = a.ctl;
-    if (!round_live(ctl, a.thr)) return;
-    if (a.n_wg_stats > 0 && blockIdx.x == 0 && threadIdx.x < kWave) {  // the scan's statistics (see RoundArgs::wg_stats)
+// ASSIGN (auction_.pyx:388-427).  All writes of one round are disjoint: winners are distinct unassigned persons,
+// evicted owners are distinct assigned persons, and a winner's slot in U is its own.
+// the scan's statistics (see RoundArgs::wg_stats), by the first wavefront of the apply launch
+__device__ __forceinline__ void collect_wg_stats(const RoundArgs &a, Ctl *ctl) {
+    if (a.n_wg_stats > 0 && blockIdx.x == 0 && threadIdx.x < kWave) {
         unsigned long long e = 0, b = 0;
         for (int k = threadIdx.x; k < a.n_wg_stats; k += kWave) {
             const unsigned long long ek = a.wg_stats[2 * k], bk = a.wg_stats[2 * k + 1];
@@ -425,35 +424,62 @@ __global__ __launch_bounds__(256) void k_apply(RoundArgs a) {
             atomicAdd(&ctl->bids, b);
         }
     }
+}
+// list position n has won object j: price, eviction, assignment; returns 1 if the slot becomes a hole
+__device__ __forceinline__ int apply_winner_of(const RoundArgs &a, Ctl *ctl, int j, int n) {
+    const int i = a.U[n];
+    PriceRec r;
+    r.price = key_to_bid(a.best_key[j]);     // p[j] = best_bids[j]   (:397)
+    r.owner = i;
+    r.ostart = a.row_ptr[i];
+    // (never with eps above the rounding error of a price update; only the candidate lines rely on it)
+    if (a.cand != nullptr && r.price < a.price[j]) atomicOr(&ctl->err, kErrPriceFell);
+    a.rec[j] = r;
+    a.price[j] = r.price;
+    const int prev = a.o2p[j];               // :401
+    a.p2o[i] = j;                            // :417
+    a.o2p[j] = i;                            // :418
+    a.best_key[j] = 0ull;                    // :421-422
+    a.best_pos[j] = kPosNone;
+    if (prev != -1) {
+        a.p2o[prev] = -1;                    // :404
+        a.U[n] = prev;                       // :409 evicted owner inherits the slot
+        return 0;
+    }
+    a.U[n] = -1;                             // :412 hole
+    return 1;
+}
+__device__ __forceinline__ void count_holes(Ctl *ctl, int holes) {  // one atomic per wavefront
+    for (int off = 32; off >= 1; off >>= 1) holes += __shfl_xor(holes, off);
+    if ((threadIdx.x & 63) == 0 && holes) atomicAdd(&ctl->nholes, holes);
+}
+// One thread per object: instead of the reference's O(M) sequential walk (:394).
+__global__ __launch_bounds__(256) void k_apply(RoundArgs a) {
+    Ctl *ctl = a.ctl;
+    if (!round_live(ctl, a.thr)) return;
+    collect_wg_stats(a, ctl);
     int holes = 0;
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < a.n_cols; j += gridDim.x * blockDim.x) {
         const int n = a.best_pos[j];
-        if (n != kPosNone) {
-            const int i = a.U[n];
-            PriceRec r;
-            r.price = key_to_bid(a.best_key[j]);     // p[j] = best_bids[j]   (:397)
-            r.owner = i;
-            r.ostart = a.row_ptr[i];
-            if (r.price < a.price[j]) atomicOr(&ctl->err, kErrPriceFell);  // (never with eps above the rounding error)
-            a.rec[j] = r;
-            a.price[j] = r.price;
-            const int prev = a.o2p[j];               // :401
-            if (prev != -1) {
-                a.p2o[prev] = -1;                    // :404
-                a.U[n] = prev;                       // :409 evicted owner inherits the slot
-            } else {
-                a.U[n] = -1;                         // :412 hole
-                holes += 1;
-            }
-            a.p2o[i] = j;                            // :417
-            a.o2p[j] = i;                            // :418
-            a.best_key[j] = 0ull;                    // :421-422
-            a.best_pos[j] = kPosNone;
-        }
+        if (n != kPosNone) holes += apply_winner_of(a, ctl, j, n);
     }
-    // one atomic per wavefront
-    for (int off = 32; off >= 1; off >>= 1) holes += __shfl_xor(holes, off);
-    if ((threadIdx.x & 63) == 0 && holes) atomicAdd(&ctl->nholes, holes);
+    count_holes(ctl, holes);
+}
+// One thread per BIDDER, for rounds with far fewer bidders than objects (every list position below K has bid in this
+// round, so bid_obj[n] is this round's -- on every rank only in rounds that are not sharded): position n has won the
+// object it bid on iff k_tiebreak left n in best_pos.  A loser that reads best_pos after the winner has reset it sees
+// "none", which is not its position either.
+__global__ __launch_bounds__(256) void k_apply_bidders(RoundArgs a) {
+    Ctl *ctl = a.ctl;
+    if (!round_live(ctl, a.thr)) return;
+    collect_wg_stats(a, ctl);
+    const int K = ctl->K;
+    int holes = 0;
+    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < K; n += gridDim.x * blockDim.x) {
+        const int j = a.bid_obj[n];
+        if (a.best_pos[j] == n) holes += apply_winner_of(a, ctl, j, n);
+    }
+    count_holes(ctl, holes);
 }
 
 // push_all_left: the k-th empty slot in [0, K') receives the k-th person found in [K', K).

@@ -79,12 +79,13 @@ __global__ __launch_bounds__(256) void k_sync_clear_p2o(int *p2o, int n_rows) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_rows; i += gridDim.x * blockDim.x) p2o[i] = -1;
 }
 __global__ __launch_bounds__(256) void k_sync_from_rec(Ctl *ctl, const PriceRec *rec, double *price, int *o2p, int *p2o,
-                                                       int n_cols) {
+                                                       int n_cols, int lines) {
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n_cols; j += gridDim.x * blockDim.x) {
         const PriceRec r = rec[j];
         // price[] still holds the prices the tail kernels started from: a price may only have risen since (the
-        // candidate lines rely on it; a net fall means eps is below the rounding error of a price update)
-        if (r.price < price[j]) atomicOr(&ctl->err, kErrPriceFell);
+        // candidate lines rely on it; a net fall means eps is below the rounding error of a price update).  A handle
+        // WITHOUT lines does not depend on the invariant -- there a falling price is what the reference computes too
+        if (lines && r.price < price[j]) atomicOr(&ctl->err, kErrPriceFell);
         price[j] = r.price;
         o2p[j] = r.owner;
         if (r.owner >= 0) p2o[r.owner] = j;

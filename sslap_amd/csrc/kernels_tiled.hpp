@@ -24,6 +24,7 @@
 #include <type_traits>
 
 #include "device_common.hpp"
+#include "kernels_check.hpp"
 #include "kernels_round.hpp"
 
 // (non-temporal edge loads were measured twice, on the 8- and the 6-byte layout: 5-20 % slower, removed)
@@ -360,6 +361,14 @@ __device__ __forceinline__ int group16_max_i32(int v) {
     return v;
 }
 template <int kGL>
+__device__ __forceinline__ int group_sum_i32(int v) {  // sum over the kGL lanes of a group, in every lane
+    v += dpp_i32<kDppXor1>(v);
+    v += dpp_i32<kDppXor2>(v);
+    if (kGL >= 8) v += dpp_i32<kDppHalfMirror>(v);
+    if (kGL >= 16) v += dpp_i32<kDppMirror>(v);
+    return v;
+}
+template <int kGL>
 __device__ __forceinline__ double group_max_f64(double v) {
     return kGL == 4 ? group4_max_f64(v) : kGL == 8 ? group8_max_f64(v) : group16_max_f64(v);
 }
@@ -387,6 +396,7 @@ struct TiledArgs {
     int *part_g;              // [kCS][part_stride] tile-major position of the best edge (-1: no edge in that share)
     int part_stride;
     int *split_cnt;           // [slices] workgroups of the slice that have published their partial result (0 between launches)
+    FinalOut fo;              // MODE 1 (the eCE / objective / validity pass, kernels_check.hpp): where its results go
 };
 
 // hand-over of a column-split shape's partial results between workgroups (see the epilogue of k_bid_tiled)
@@ -421,9 +431,16 @@ __device__ __forceinline__ T split_load(const T *p) {
 // the price table -- per CU the tile fills (the whole table once per workgroup: 1.6 MB at C3, more than the 1.0 MB of
 // edges a CU streams) halve, and so do the barriers; a lane group then owns twice the persons (kTileRows = 8).  The
 // partial top-2s of a bidder go to memory (20 bytes each); the workgroup of the slice that arrives last forms the bids.
-template <int kTileThreads, int kTileRows, int kTileBatch, int kTileDepth, int kTileCols, int kLoaders, int ABL = 0, int kGL = 4, int kCS = 1>
+//
+// MODE 1: the same engine as the pass over ALL rows that eCE_satisfied (auction_.pyx:443-485), get_obj (:489-523) and
+// the validity flags need (kernels_check.hpp): instead of a running top-2 a lane keeps the running maximum of
+// val - price and the last stored edge whose column is the person's object -- the column is known before the scan, so
+// inside the tile that holds it the edge is recognised by its 16-bit price slot, with no column arithmetic per
+// element.  No bids, no statistics; the result of a person is handled by final_person().  a.eps = the eps of the test.
+template <int kTileThreads, int kTileRows, int kTileBatch, int kTileDepth, int kTileCols, int kLoaders, int ABL = 0, int kGL = 4, int kCS = 1, int MODE = 0>
 __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledArgs ta) {
     static_assert(kCS == 1 || kCS == 2 || kCS == 4, "column split: none, halves or quarters of the tiles");
+    static_assert(MODE == 0 || (MODE == 1 && kCS == 1 && ABL == 0), "the check pass runs on the unsplit shapes");
     static_assert(kGL == 4 || kGL == 8 || kGL == 16, "lanes per person: 4, 8 or 16 (one DPP row at most)");
     constexpr int kTileGroups = (kTileThreads - kLoaders * kWave) / kGL;  // kGL-lane groups; loader wavefronts own none
     // LDS (in doubles): buffer 0 at [0, kTileCols), the +inf slot at kTileCols, buffer 1 at [kBufDoubles, ...).
@@ -435,9 +452,15 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
     static_assert(kTileRows % kTileBatch == 0 && kTileRows / kTileBatch >= 2, "ROWS = BATCH * (>= 2 steps)");
     extern __shared__ __attribute__((aligned(16))) double s_price[];  // 2 * kBufDoubles
     const Ctl *ctl = a.ctl;
-    if (!round_live(ctl, a.thr) || ctl->K < ta.min_K) return;
     int lo, hi;
-    shard_range(ctl->K, a.rank, a.world, a.shard_min_K, lo, hi);
+    if (MODE == 0) {
+        if (!round_live(ctl, a.thr) || ctl->K < ta.min_K) return;
+        shard_range(ctl->K, a.rank, a.world, a.shard_min_K, lo, hi);
+    } else {  // every person; an eCE-only pass has nothing left to find once any row has failed (the sample pass)
+        if (!ta.fo.fin && ctl->ece_fail) return;
+        lo = 0;
+        hi = a.n_rows;
+    }
     // this workgroup's slice of list positions (and, with a column split, its half of the tiles)
     const int n_slices = (int)gridDim.x / kCS, slice = (int)blockIdx.x / kCS, half = kCS > 1 ? (int)blockIdx.x % kCS : 0;
     const int per_wg = (hi - lo + n_slices - 1) / n_slices;
@@ -459,7 +482,7 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
     constexpr int kWaves = kTileThreads / kWave;
     const int wave_u = __builtin_amdgcn_readfirstlane(t >> 6);
     const bool loader = kLoaders > 0 && wave_u >= kWaves - kLoaders;
-    const bool full = ctl->K == a.n_rows && !ta.order_person;  // uniform
+    const bool full = MODE == 1 || (ctl->K == a.n_rows && !ta.order_person);  // uniform
     int person[kTileRows];
     double sv[kTileRows], sw[kTileRows];
     int sg[kTileRows];  // position of the lane's best element ...
@@ -468,6 +491,10 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
     // the position -- two random 4-byte reads per bidder into the tile-major arrays -- pulled 51 MB of lines per full
     // scan at C3 and put a memory latency in front of the bids.
     int scol[kTileRows], scost[kTileRows];
+    // MODE 1 keeps in the same registers: sv = running maximum, sg = position of the last match (-1: none), scost = its
+    // value bits; and per person the tile of the wanted column, its price slot there as an LDS byte offset, the number
+    // of matches
+    int wtile[kTileRows], wslot8[kTileRows], mcnt[kTileRows];
 #pragma unroll
     for (int j = 0; j < kTileRows; ++j) {
         const int pos = p0 + j * kTileGroups + group;
@@ -480,6 +507,18 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
         sg[j] = -1;
         scol[j] = 0;
         scost[j] = 0;
+        wtile[j] = -1;
+        wslot8[j] = 0;
+        mcnt[j] = 0;
+    }
+    if (MODE == 1) {
+#pragma unroll
+        for (int j = 0; j < kTileRows; ++j) {
+            const int c = wanted_column(a.p2o[max(person[j], 0)], a.n_cols);
+            const int cc = max(c, 0), tj = cc / kTileCols;
+            wtile[j] = (c >= 0 && person[j] >= 0) ? tj : -1;
+            wslot8[j] = ((cc - tj * kTileCols) + (kDouble ? (tj & 1) * kBufDoubles : 0)) << 3;  // as k_tile_scatter forms it
+        }
     }
     if (t == 0) s_price[kTileCols] = __builtin_huge_val();
     // an edge carries the slot of its price inside s_price (tile parity included, see k_tile_scatter)
@@ -702,6 +741,7 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
                         const int j = b * kTileBatch + jj;
                         const int q0 = seg_s0(seg_cur, jj) + 2 * gl;
                         int sslot = -1;  // slot of the best element if it moved in this step
+                        const int want8 = (MODE == 1 && tile == wtile[j]) ? wslot8[j] : -1;  // (MODE 1) no slot offset is negative
 #pragma unroll
                         for (int d = dlo; d < dhi; ++d) {
                             if (ABL == 2) {
@@ -719,6 +759,15 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
                                 // taking sg when sv is still -inf (rows whose objects all have an infinite price)
                                 const double v = (double)__int_as_float(vb) - prs[jj][d][h];  // vi = cost - p[j]   (:350)
                                 const int q = q0 + 2 * kGL * d + h;
+                                if (MODE == 1) {  // (:467-471, :480-482) a lane meets its elements in stored order: the last match stays
+                                    const int a8 = (int)((h ? e_cur.c[jj][d] >> 16 : e_cur.c[jj][d] & 0xffffu) << 3);
+                                    const bool m = (2 * kGL * d + h < rem[jj]) & (a8 == want8);
+                                    sv[j] = __builtin_fmax(sv[j], v);  // a masked-off element has v = -inf
+                                    sg[j] = m ? q : sg[j];
+                                    scost[j] = m ? vb : scost[j];
+                                    mcnt[j] += m;
+                                    continue;
+                                }
                                 // a lane meets its elements in stored order: ">=" is the reference's tie rule
                                 const bool ge = (2 * kGL * d + h < rem[jj]) & (v >= sv[j]);  // :351
                                 sw[j] = __builtin_fmax(sw[j], __builtin_fmin(v, sv[j]));      // :353 / :357-358
@@ -858,6 +907,18 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
                     const int j = j0 + jj;
                     const bool ok = (oi[jj] < oe[jj]) & (kCS == 1 || ((q[jj] >= ql[jj]) & (q[jj] < qh[jj])));
                     const double v = ok ? (double)__int_as_float(vb[jj]) - pr[jj] : ninf;  // vi = cost - p[j]   (:350)
+                    if (MODE == 1) {  // these edges are met out of stored order: the later stored POSITION is the last match
+                        const int wcol = wtile[j] * kTileCols + (wslot8[j] >> 3) - (kDouble ? (wtile[j] & 1) * kBufDoubles : 0);
+                        const bool m = ok & (wtile[j] >= 0) & (en[jj].y == wcol);
+                        const bool later = m & (q[jj] > sg[j]);
+                        sv[j] = __builtin_fmax(sv[j], v);
+                        sg[j] = later ? q[jj] : sg[j];
+                        scost[j] = later ? vb[jj] : scost[j];
+                        mcnt[j] += m;
+                        oi[jj] += kGL;
+                        more |= oi[jj] < oe[jj];
+                        continue;
+                    }
                     const bool ge = ok & ((v > sv[j]) | ((v == sv[j]) & (q[jj] > sg[j])));    // :351, by stored position
                     sw[j] = __builtin_fmax(sw[j], __builtin_fmin(v, sv[j]));                // :353 / :357-358
                     sv[j] = __builtin_fmax(sv[j], v);
@@ -871,6 +932,30 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
         }
     }
     MISSLAP_ESTAMP(1);
+    if (MODE == 1) {
+        // one lane per person -- the one that holds the last match, lane 0 of the group when there is none -- finishes
+        // the person (kernels_check.hpp); the price of the wanted column comes from memory, requested for all persons
+        // of the lane group before the first is used
+        if (loader) return;
+        int pj_[kTileRows];
+        double wp[kTileRows];
+#pragma unroll
+        for (int j = 0; j < kTileRows; ++j) {
+            pj_[j] = a.p2o[max(person[j], 0)];
+            wp[j] = a.price[max(wanted_column(pj_[j], a.n_cols), 0)];
+        }
+        FinalAcc acc;
+#pragma unroll
+        for (int j = 0; j < kTileRows; ++j) {
+            const double V = group_max_f64<kGL>(sv[j]);
+            const int Q = group_max_i32<kGL>(sg[j]);
+            const int n = group_sum_i32<kGL>(mcnt[j]);
+            const bool me = person[j] >= 0 && (Q >= 0 ? sg[j] == Q : gl == 0);
+            if (me) final_person(acc, ta.fo, person[j], pj_[j], Q >= 0, n, (double)__int_as_float(scost[j]), V, wp[j], eps);
+        }
+        flush_final(a.ctl, ta.fo, acc);
+        return;
+    }
     // merge the kGL lanes of each group, once per person (same three all-reduces as top2_wave_reduce)
     unsigned long long edges = 0;
     int nb = 0, err = 0;

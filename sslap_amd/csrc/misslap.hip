@@ -233,6 +233,7 @@ struct misslap_solver {
     int cand_refresh_min = kDefaultCandRefresh;
     bool round_ordered = false;  // the current round's bidders were taken in person order (k_order_*, partial tiled rounds)
     bool order_partial = true;   // ... which options.reserved[5] = 1 turns off (A/B, parity tests)
+    int apply_bidders_ratio = 2;  // k_apply_bidders while K * ratio <= M (env MISSLAP_APPLY_BIDDERS_RATIO: A/B; huge = never)
     bool profile_all = false;  // profile >= 2: events around every k_bid launch, not only the full scans
     int rounds_per_sync = kDefaultRoundsPerSync;
     int rank = 0, world = 1;
@@ -511,7 +512,7 @@ int launch_bid_tiled(misslap_solver *h) {
     if (grid < spread) grid = spread;
     grid *= cs;
     TiledArgs ta{reinterpret_cast<const unsigned *>(h->tiled), h->tcol, h->seg4, h->T, h->tiled_min_K, h->n_tiled,
-                 nullptr, nullptr, h->ovf_ptr, h->ovf_q, h->ovf_cap, h->part_vw, h->part_g, h->n_rows, h->split_cnt};
+                 nullptr, nullptr, h->ovf_ptr, h->ovf_q, h->ovf_cap, h->part_vw, h->part_g, h->n_rows, h->split_cnt, FinalOut{}};
     // A partial round whose K the host knows: bidders in person order (kernels_tiled.hpp, k_order_*).  Scratch that
     // is idle during a bid phase: the compaction lists (the tie-break reads order_pos before they are rewritten),
     // the chunk counters, the objective's match counters.
@@ -631,7 +632,11 @@ int launch_apply(misslap_solver *h) {
     h->round_ordered = false;
     a.n_wg_stats = h->wg_stats_pending;
     h->wg_stats_pending = 0;
-    hipLaunchKernelGGL(k_apply, dim3(blocks_for(h->n_cols, 256)), dim3(256), 0, h->stream, a);
+    // by the bidders where they are few against the objects (every rank holds every bid only in unsharded rounds)
+    if ((h->world == 1 || h->K_ub < h->shard_min_K) && (long long)h->K_ub * h->apply_bidders_ratio <= h->n_cols)
+        hipLaunchKernelGGL(k_apply_bidders, dim3(blocks_for(h->K_ub, 256)), dim3(256), 0, h->stream, a);
+    else
+        hipLaunchKernelGGL(k_apply, dim3(blocks_for(h->n_cols, 256)), dim3(256), 0, h->stream, a);
     if (h->K_ub <= kCompactSmallMax) {
         hipLaunchKernelGGL(k_compact_small, dim3(1), dim3(1024), 0, h->stream, a);
     } else {
@@ -704,12 +709,64 @@ int launch_tail(misslap_solver *h) {
     // the tail keeps only the price records current: rebuild price / o2p / p2o from them
     hipLaunchKernelGGL(k_sync_clear_p2o, dim3(blocks_for(h->n_rows, 256)), dim3(256), 0, h->stream, h->p2o, h->n_rows);
     hipLaunchKernelGGL(k_sync_from_rec, dim3(blocks_for(h->n_cols, 256)), dim3(256), 0, h->stream, h->ctl, h->rec, h->price,
-                       h->o2p, h->p2o, h->n_cols);
+                       h->o2p, h->p2o, h->n_cols, h->cand != nullptr ? 1 : 0);
     HIP_TRY(hipGetLastError());
     h->phase_fresh = false;
     return MISSLAP_OK;
 }
 
+// The pass over all rows behind eCE_satisfied / get_obj / the validity flags (kernels_check.hpp) runs on the
+// full-scan engine where the handle has the tile-major copy in a shape the check instances cover: lanes per person of
+// that shape (the overflow lists are built for 2 x lanes x 2 loads per segment), 0 = the pass on the row-major CSR.
+int check_lanes(const misslap_solver *h) {
+    if (!h->tiled_ok) return 0;
+    const int *shp = kTiledShapes[h->tiled_shape];
+    return (shp[3] == 2 && shp[4] == kTileColsHalf) ? shp[6] : 0;
+}
+#define MISSLAP_FOR_CHECK_LANES(X) X(4) X(8) X(16)
+#define MISSLAP_CHECK_KERNEL(GL) k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 3, 0, GL, 1, 1>
+
+// rows [0, n_rows) on the row-major CSR (the sample of run_ece; every row where there is no tile-major copy)
+int launch_rows_gather(misslap_solver *h, float eps, const FinalOut &fo, int n_rows) {
+    const int grid = blocks_for(n_rows, 4);
+    if (h->f32) {
+        EdgesF32 ed{h->edges32};
+        hipLaunchKernelGGL(k_ece<EdgesF32>, dim3(grid), dim3(256), 0, h->stream, h->ctl, ed, h->row_ptr, h->price,
+                           h->p2o, n_rows, eps, fo);
+    } else {
+        EdgesF64 ed{h->col, h->val64};
+        hipLaunchKernelGGL(k_ece<EdgesF64>, dim3(grid), dim3(256), 0, h->stream, h->ctl, ed, h->row_ptr, h->price,
+                           h->p2o, n_rows, eps, fo);
+    }
+    HIP_TRY(hipGetLastError());
+    return MISSLAP_OK;
+}
+// every row, on the engine the handle has
+int launch_rows_all(misslap_solver *h, float eps, const FinalOut &fo) {
+    const int gl = check_lanes(h);
+    if (!gl) return launch_rows_gather(h, eps, fo, h->n_rows);
+    RoundArgs a = round_args(h);
+    a.eps = eps;
+    a.launch_edges = nullptr;
+    TiledArgs ta{reinterpret_cast<const unsigned *>(h->tiled), h->tcol, h->seg4, h->T, 0, h->n_tiled,
+                 nullptr, nullptr, h->ovf_ptr, h->ovf_q, h->ovf_cap, nullptr, nullptr, h->n_rows, nullptr, fo};
+    const int groups = (1024 - 64 * 3) / gl, per_wg_max = groups * 4;
+    long long grid = ((long long)h->n_rows + per_wg_max - 1) / per_wg_max;
+    const long long spread = std::min<long long>(h->n_cus, ((long long)h->n_rows + groups - 1) / groups);
+    if (grid < spread) grid = spread;
+    const size_t lds = tiled_lds_bytes(kTileColsHalf);
+    switch (gl) {
+#define X(GL) \
+    case GL: hipLaunchKernelGGL((MISSLAP_CHECK_KERNEL(GL)), dim3((unsigned)grid), dim3(1024), (unsigned)lds, h->stream, a, ta); break;
+        MISSLAP_FOR_CHECK_LANES(X)
+#undef X
+    }
+    HIP_TRY(hipGetLastError());
+    return MISSLAP_OK;
+}
+
+// eCE_satisfied(eps), auction_.pyx:443-485.  The sample pass first (kernels_check.hpp: a failing test fails within the
+// first few rows), then every row -- a launch that returns at once when the sample has set the flag.
 int run_ece(misslap_solver *h, float eps, int *ok) {
     int rc = read_ctl(h);
     if (rc) return rc;
@@ -719,17 +776,10 @@ int run_ece(misslap_solver *h, float eps, int *ok) {
     }
     h->ctl_fresh = false;
     HIP_TRY(hipMemsetAsync(&h->ctl->ece_fail, 0, sizeof(int), h->stream));
-    const int grid = blocks_for(h->n_rows, 4);
-    if (h->f32) {
-        EdgesF32 ed{h->edges32};
-        hipLaunchKernelGGL(k_ece<EdgesF32>, dim3(grid), dim3(256), 0, h->stream, h->ctl, ed, h->row_ptr, h->price,
-                           h->p2o, h->n_rows, eps);
-    } else {
-        EdgesF64 ed{h->col, h->val64};
-        hipLaunchKernelGGL(k_ece<EdgesF64>, dim3(grid), dim3(256), 0, h->stream, h->ctl, ed, h->row_ptr, h->price,
-                           h->p2o, h->n_rows, eps);
-    }
-    HIP_TRY(hipGetLastError());
+    const FinalOut fo{0, h->maximize, h->o2p, h->contrib, h->nmatch, h->n_rows, h->n_cols};
+    const int sample = std::min(h->n_rows, kEceSampleRows);
+    if ((rc = launch_rows_gather(h, eps, fo, sample))) return rc;
+    if (sample < h->n_rows && (rc = launch_rows_all(h, eps, fo))) return rc;
     rc = read_ctl(h);
     if (rc) return rc;
     *ok = h->h_ctl->ece_fail ? 0 : 1;
@@ -970,6 +1020,15 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
                         MISSLAP_FOR_TILED_SHAPES(X)
 #undef X
                     }
+                    switch (check_lanes(h)) {  // the check pass on the same engine (launch_rows_all)
+#define X(GL)                                                                                                        \
+    case GL:                                                                                                         \
+        HIP_TRY(hipFuncSetAttribute((const void *)MISSLAP_CHECK_KERNEL(GL), at, (int)tiled_lds_bytes(kTileColsHalf)));  \
+        break;
+                        MISSLAP_FOR_CHECK_LANES(X)
+#undef X
+                        default: break;
+                    }
                 }
             }
             HIP_TRY(hipStreamSynchronize(h->stream));  // the temporaries are released at scope exit
@@ -1145,6 +1204,7 @@ int new_handle(misslap_solver **out, const misslap_options *opt, int abi, missla
     h->maximize = opt->maximize ? 1 : 0;
     h->thr = opt->tail_threshold >= 0 ? opt->tail_threshold : -1;  // -1: resolved in build_from_device_coo
     h->order_partial = opt->partial_in_list_order == 0;
+    if (const char *e = std::getenv("MISSLAP_APPLY_BIDDERS_RATIO")) h->apply_bidders_ratio = std::max(1, std::atoi(e));
     if (opt->cand_build_max_K > 0) h->cand_build_max_K = opt->cand_build_max_K;
     if (opt->cand_refresh_min > 0) h->cand_refresh_min = opt->cand_refresh_min - 1;
     h->rounds_per_sync = opt->rounds_per_sync > 0 ? opt->rounds_per_sync : kDefaultRoundsPerSync;
@@ -1673,23 +1733,20 @@ MISSLAP_API int misslap_finish(misslap_solver *h, int32_t *person_to_object_out,
     if (!h) return fail(MISSLAP_ERR_INVALID, "null handle");
     HIP_TRY(hipSetDevice(h->device));
     int rc;
-    int ece = 0;
-    if ((rc = run_ece(h, h->target_eps, &ece))) return rc;  // :297 / :300
-    h->ctl_fresh = false;  // (the objective kernels below write the control block)
-    // objective (:302, :489-523)
-    HIP_TRY(hipMemsetAsync(&h->ctl->dup_rows, 0, sizeof(int), h->stream));
-    hipLaunchKernelGGL(k_obj_reset, dim3(1), dim3(1), 0, h->stream, h->ctl);
-    const int grid = blocks_for(h->n_rows, 4);
+    if ((rc = read_ctl(h))) return rc;
+    const bool complete = h->h_ctl->K == 0;  // eCE_satisfied is False while anybody is unassigned (auction_.pyx:446-447)
+    h->ctl_fresh = false;
+    // ONE pass over the rows for meta['eCE'] / soln_found (:297, :300), the objective (:302, :489-523) and the validity
+    // flags of the assignment (benchmarking.py:56-64): all three look for the stored entry (i, sol[i])
+    hipLaunchKernelGGL(k_final_reset, dim3(1), dim3(1), 0, h->stream, h->ctl);
+    const FinalOut fo{1, h->maximize, h->o2p, h->contrib, h->nmatch, h->n_rows, h->n_cols};
+    if ((rc = launch_rows_all(h, h->target_eps, fo))) return rc;
     if (h->f32) {
         EdgesF32 ed{h->edges32};
-        hipLaunchKernelGGL(k_obj_rows<EdgesF32>, dim3(grid), dim3(256), 0, h->stream, h->ctl, ed, h->row_ptr, h->p2o,
-                           h->n_rows, h->maximize, h->contrib, h->nmatch);
         hipLaunchKernelGGL(k_obj_sum<EdgesF32>, dim3(1), dim3(1024), 0, h->stream, h->ctl, ed, h->row_ptr, h->p2o,
                            h->n_rows, h->maximize, h->contrib, h->nmatch);
     } else {
         EdgesF64 ed{h->col, h->val64};
-        hipLaunchKernelGGL(k_obj_rows<EdgesF64>, dim3(grid), dim3(256), 0, h->stream, h->ctl, ed, h->row_ptr, h->p2o,
-                           h->n_rows, h->maximize, h->contrib, h->nmatch);
         hipLaunchKernelGGL(k_obj_sum<EdgesF64>, dim3(1), dim3(1024), 0, h->stream, h->ctl, ed, h->row_ptr, h->p2o,
                            h->n_rows, h->maximize, h->contrib, h->nmatch);
     }
@@ -1697,19 +1754,8 @@ MISSLAP_API int misslap_finish(misslap_solver *h, int32_t *person_to_object_out,
     if (person_to_object_out)
         HIP_TRY(hipMemcpyAsync(person_to_object_out, h->p2o, sizeof(int) * (size_t)h->n_rows, hipMemcpyDeviceToHost,
                                h->stream));
-    // validity flags of the assignment (benchmarking.py:56-64), reduced on the device: k_validity
-    HIP_TRY(hipMemsetAsync(h->ctl->val_cnt, 0, sizeof(h->ctl->val_cnt), h->stream));
-    if (h->f32) {
-        EdgesF32 ed{h->edges32};
-        hipLaunchKernelGGL(k_validity<EdgesF32>, dim3(grid), dim3(256), 0, h->stream, h->ctl, ed, h->row_ptr, h->p2o, h->o2p,
-                           h->n_rows, h->n_cols, h->maximize);
-    } else {
-        EdgesF64 ed{h->col, h->val64};
-        hipLaunchKernelGGL(k_validity<EdgesF64>, dim3(grid), dim3(256), 0, h->stream, h->ctl, ed, h->row_ptr, h->p2o, h->o2p,
-                           h->n_rows, h->n_cols, h->maximize);
-    }
-    HIP_TRY(hipGetLastError());
     if ((rc = read_ctl(h))) return rc;
+    const int ece = complete && !h->h_ctl->ece_fail ? 1 : 0;
     if (!meta_out) return MISSLAP_OK;
     // how much the caller's struct holds: a version-1 caller (88-byte options at create) gets the version-1 layout
     size_t out_bytes = sizeof(misslap_meta_v1);
@@ -1975,7 +2021,7 @@ MISSLAP_API int misslap_debug_time_bid(misslap_solver *h, int32_t mode, int32_t 
         RoundArgs a = round_args(h);
         a.launch_edges = nullptr;
         TiledArgs ta{reinterpret_cast<const unsigned *>(h->tiled), h->tcol, h->seg4, h->T, 1, h->n_tiled,
-                     nullptr, nullptr, h->ovf_ptr, h->ovf_q, h->ovf_cap, h->part_vw, h->part_g, h->n_rows, h->split_cnt};
+                     nullptr, nullptr, h->ovf_ptr, h->ovf_q, h->ovf_cap, h->part_vw, h->part_g, h->n_rows, h->split_cnt, FinalOut{}};
         hipEvent_t t0, t1;
         HIP_TRY(hipEventCreate(&t0));
         HIP_TRY(hipEventCreate(&t1));

@@ -27,13 +27,16 @@ def _single_entry_rows(n, density, seed, n_single):
     return np.ascontiguousarray(loc[keep]), np.ascontiguousarray(val[keep])
 
 
-def _with_duplicates(n, density, seed, integer_values):
-    """Instance where some (i, j) entries appear twice with different values."""
+def _with_duplicates(n, density, seed, integer_values, adjacent=False):
+    """Instance where some (i, j) entries appear twice with different values (the second copy at the end of the row;
+    adjacent=True: right behind the first one, which keeps the rows column-sorted)."""
     loc, val = synth.gen_sparse(n, n, density, seed=seed, integer_values=integer_values)
     pick = np.nonzero(synth._stream(seed, 78, loc.shape[0]) % np.uint64(7) == 0)[0]
     loc2 = np.concatenate([loc, loc[pick]], axis=0)
     val2 = np.concatenate([val, val[pick] + 1.0], axis=0)
     order = np.argsort(loc2[:, 0], kind="stable")
+    if adjacent:
+        order = np.lexsort((np.arange(loc2.shape[0]), loc2[:, 1], loc2[:, 0]))
     return np.ascontiguousarray(loc2[order]), np.ascontiguousarray(val2[order])
 
 
@@ -83,7 +86,7 @@ def synth_inputs(spec):
     elif kind == "single":
         loc, val = _single_entry_rows(spec["n"], spec["density"], spec.get("seed", 1), spec["n_single"])
     elif kind == "dups":
-        loc, val = _with_duplicates(spec["n"], spec["density"], spec.get("seed", 1), spec["ints"])
+        loc, val = _with_duplicates(spec["n"], spec["density"], spec.get("seed", 1), spec["ints"], spec.get("adjacent", False))
     elif kind == "f64":
         loc, val = _full_double(spec["n"], spec["density"], spec.get("seed", 1))
     elif kind == "config":

@@ -1016,3 +1016,88 @@ def test_integration_md_sharded_binding_stub_works(gpu_lib):
     sol = ns["solve_sharded"](loc, val.copy(), 0, 1, 0, lambda uid: uid, problem="max")
     ref = orc.auction_solve(loc=loc, val=val.copy(), problem="max", cardinality_check=False)
     assert np.array_equal(sol, ref["sol"])
+
+
+def _drive_to_phase_end(g):
+    """rounds of the stepwise API until everybody is assigned (the end of an eps-phase)"""
+    for _ in range(10**7):
+        st = g.status()
+        if st.K == 0:
+            return st
+        if st.K > g.tail_threshold:
+            g.round_bid()
+            g.round_tiebreak()
+            g.round_apply()
+        else:
+            g.run_tail()
+    raise AssertionError("the phase did not end")
+
+
+@pytest.mark.parametrize("label,spec,prob,kw", [
+    # the pass on the full-scan engine (tile-major copy): 4 / 8 / 16 lanes per person, several column tiles
+    ("tiled4", dict(kind="sparse", n=6000, m=40000, density=0.001), "max", dict(tiled_min_k=1, engine=1)),
+    ("tiled8", dict(kind="sparse", n=5000, m=25000, density=0.004, ints=5), "min", dict(tiled_min_k=1, engine=1, tiled_shape=8)),
+    ("tiled16", dict(kind="sparse", n=4200, m=12000, density=0.01), "max", dict(tiled_min_k=1, engine=1, tiled_shape=9)),
+    ("tiled_default", dict(kind="sparse", n=9000, m=9000, density=0.004), "max", dict()),
+    # the same entry stored more than once: the LAST one is the choice (auction_.pyx:467-471)
+    ("dups", dict(kind="dups", n=150, density=0.06, ints=6), "max", dict()),
+    ("tiled_dups", dict(kind="dups", n=5000, density=0.004, ints=9, adjacent=True), "max", dict(tiled_min_k=1, engine=1)),
+    # 12 B/edge layout (values that are not fp32-exact): the pass on the row-major CSR
+    ("f64", dict(kind="f64", n=4500, density=0.004), "min", dict()),
+    ("forced_f64", dict(kind="sparse", n=6000, m=6000, density=0.003), "max", dict(force_f64=True)),
+    # fewer rows than the sample: the sample IS the pass
+    ("small", dict(kind="sparse", n=300, m=300, density=0.05), "max", dict()),
+    ("rect", dict(kind="sparse", n=5000, m=7500, density=0.004), "max", dict(tail_threshold=0)),
+])
+def test_ece_pass_equals_the_reference_loop_at_every_phase_end(label, spec, prob, kw, gpu_lib):
+    """misslap_check_ece (sample pass + full pass, on the full-scan engine where the handle has the tile-major copy)
+    against eCE_satisfied of the reference (auction_.pyx:443-485, restated on arrays in the oracle) at the state the GPU
+    holds at the end of every eps-phase -- states that fail the test and the final one that passes -- for a range of
+    eps: the phase's own, the target, zero, negative, huge."""
+    loc, val = cases.synth_inputs(spec)
+    g = from_sparse(loc, val.copy(), problem=prob, max_iter=10**7, cardinality_check=False, **kw)
+    seen = set()
+    for phase in range(40):
+        st = _drive_to_phase_end(g)
+        assert st.K == 0
+        s = g.state()
+        for eps in (st.target_eps, st.eps, 0.0, -1.0, 1e-3, 1e-6, 3.0e38, np.float32(st.eps) * np.float32(4)):
+            want = orc.ece_satisfied(loc, val, prob, s["p"], s["p2o"], eps)
+            got = g.check_ece(eps)
+            assert got == want, (label, phase, eps)
+            seen.add(want)
+        if g.phase_end():
+            break
+    assert seen == {True, False}
+    # ... and the fused final pass: eCE, objective, validity flags from ONE scan
+    sol = g.finish()
+    assert g.gpu["tiled_active"] == int(label.startswith("tiled"))
+    ref = orc.auction_solve(loc=loc, val=val.copy(), problem=prob, cardinality_check=False, max_iter=10**7)
+    assert np.array_equal(sol, ref["sol"]) and g.meta["eCE"] == ref["meta"]["eCE"] == 1
+    assert g.meta["soln_found"] == ref["meta"]["soln_found"] and g.gpu["obj_f64"] == ref["extra"]["obj_f64"]
+    assert g.gpu["complete_assignment"][1:] == (True, True) and g.gpu["valid_assignment"]
+
+
+@pytest.mark.parametrize("thr", [None, 0, 16])
+def test_falling_prices_without_lines_equal_the_reference(thr, gpu_lib):
+    """Costs of ~2^50 over four binades against eps down to 0.15 / N: a price update fl(fl(c - w) + eps) rounds DOWN
+    now and then, i.e. prices FALL (the reference then cycles until max_iter).  The precision guard has switched the
+    candidate lines off for such a handle, nothing else depends on rising prices, so the solve must neither fail
+    (kErrPriceFell is raised only for handles with lines) nor differ from the reference in a single bit."""
+    n, max_iter = 300, 5000
+    loc, _ = synth.gen_sparse(n, n, 0.05, seed=10)
+    val = 2.0 ** 47 * (1.0 + 15.0 * np.random.RandomState(10).random_sample(loc.shape[0]))
+    o = orc.from_sparse(loc, val.copy(), problem="max", max_iter=max_iter, cardinality_check=False)
+    prev, falls = o.state()["p"], 0
+    while not o.step():
+        p = o.state()["p"]
+        falls += int((p < prev).sum())
+        prev = p
+    assert falls > 100  # the instance does what it is here for
+    so = o.state()
+    g = from_sparse(loc, val.copy(), problem="max", max_iter=max_iter, cardinality_check=False, tail_threshold=thr)
+    sol = g.solve()
+    assert g.gpu["lines_active"] == 0 and g.meta["its"] == max_iter == so["its"]
+    sg = g.state()
+    assert np.array_equal(sg["p"].view(np.uint64), so["p"].view(np.uint64))
+    assert np.array_equal(sg["p2o"], so["p2o"]) and np.array_equal(sol, so["p2o"]) and np.array_equal(sg["U"], so["U"])
