@@ -21,7 +21,16 @@ namespace misslap {
 // microseconds); the full pass that follows starts by reading the flag and returns at once when the sample has
 // already failed.  Only a check that passes -- the last phase's and the one behind meta['eCE'] -- pays a full scan,
 // and that scan runs on the bandwidth engine where the handle has the tile-major layout (k_bid_tiled, MODE 1).
-constexpr int kEceSampleRows = 4096;
+constexpr int kEceSampleRows = 512;
+
+// Results of the final pass per WORKGROUP (plain stores, no contention: thousands of wavefronts ending together on the
+// same seven words cost the pass more than its scan -- 5 ns per same-address atomic); k_obj_sum adds the slots up.
+struct __attribute__((aligned(64))) FinSlot {
+    unsigned long long distinct, n_neg, n_big, n_inv, dups;
+    long long min_exp;
+    double abs_sum;
+    unsigned long long pad;
+};
 
 // Sums of the final pass, kept per lane and flushed once per wavefront (flush_final).
 struct FinalAcc {
@@ -36,6 +45,7 @@ struct FinalOut {
     double *contrib;  // [n_rows]
     int *nmatch;      // [n_rows]
     int n_rows, n_cols;
+    FinSlot *slots;   // [gridDim.x] of the launch (fin = 1)
 };
 // The column the passes look for: p2o[i], with numpy's index wrap-around for the validity flags (sol[i] = -1 selects
 // the LAST column: benchmarking.py:59 indexes mat[arange(size), sol]); -1 when that is no column at all.
@@ -77,10 +87,15 @@ __device__ __forceinline__ void final_person(FinalAcc &acc, const FinalOut &fo, 
     acc.n_big += j >= fo.n_rows;
     acc.distinct += (j >= 0 && j < fo.n_cols && fo.o2p[j] == i);
 }
-// wave-wide sums of the accumulators, one set of atomics per wavefront
-__device__ __forceinline__ void flush_final(Ctl *ctl, const FinalOut &fo, FinalAcc acc) {
-    if (__ballot(acc.bad) && lane_id() == 0) atomicOr(&ctl->ece_fail, 1);
-    if (!fo.fin) return;
+// The one bit of the eCE test: set by whoever finds a violated row and does not see it set already (a plain store of
+// 1 by any number of writers; every wavefront of a failing pass adding an atomic to the same word cost the sample
+// pass 20 us).
+__device__ __forceinline__ void flag_ece_failure(Ctl *ctl, bool bad) {
+    if (__ballot(bad) && lane_id() == 0 && !__hip_atomic_load(&ctl->ece_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        __hip_atomic_store(&ctl->ece_fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// wave-wide sums of the accumulators (valid in every lane)
+__device__ __forceinline__ void wave_sum_final(FinalAcc &acc) {
     for (int off = 32; off >= 1; off >>= 1) {
         acc.distinct += __shfl_xor(acc.distinct, off);
         acc.n_neg += __shfl_xor(acc.n_neg, off);
@@ -90,15 +105,36 @@ __device__ __forceinline__ void flush_final(Ctl *ctl, const FinalOut &fo, FinalA
         acc.min_exp = min(acc.min_exp, __shfl_xor(acc.min_exp, off));
         acc.abs_sum += shfl_xor_f64(acc.abs_sum, off);  // (any order: only a bound, see k_obj_sum)
     }
-    if (lane_id() != 0) return;
-    if (acc.distinct) atomicAdd(&ctl->val_cnt[0], (unsigned long long)acc.distinct);
-    if (acc.n_neg) atomicAdd(&ctl->val_cnt[1], (unsigned long long)acc.n_neg);
-    if (acc.n_big) atomicAdd(&ctl->val_cnt[2], (unsigned long long)acc.n_big);
-    if (acc.n_inv) atomicAdd(&ctl->val_cnt[3], (unsigned long long)acc.n_inv);
-    if (acc.dups) atomicAdd(&ctl->dup_rows, acc.dups);
-    if (acc.abs_sum != 0.0) {
-        atomicMin(&ctl->obj_minexp, acc.min_exp);
-        atomicAdd(&ctl->obj_abs, acc.abs_sum);
+}
+// ... of a workgroup: every wavefront (all of them must call) leaves its sums in `scratch` (LDS, 8 doubles per
+// wavefront, free to be overwritten), thread 0 writes the workgroup's slot
+__device__ __forceinline__ void flush_final_wg(const FinalOut &fo, FinalAcc acc, double *scratch) {
+    wave_sum_final(acc);
+    const int wave = threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
+    if (lane_id() == 0) {
+        unsigned long long *w = reinterpret_cast<unsigned long long *>(scratch) + 8 * wave;
+        w[0] = (unsigned long long)acc.distinct;
+        w[1] = (unsigned long long)acc.n_neg;
+        w[2] = (unsigned long long)acc.n_big;
+        w[3] = (unsigned long long)acc.n_inv;
+        w[4] = (unsigned long long)acc.dups;
+        w[5] = (unsigned long long)(long long)acc.min_exp;
+        scratch[8 * wave + 6] = acc.abs_sum;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        FinSlot r{0, 0, 0, 0, 0, 1 << 20, 0.0, 0};
+        for (int k = 0; k < nw; ++k) {
+            const unsigned long long *w = reinterpret_cast<const unsigned long long *>(scratch) + 8 * k;
+            r.distinct += w[0];
+            r.n_neg += w[1];
+            r.n_big += w[2];
+            r.n_inv += w[3];
+            r.dups += w[4];
+            r.min_exp = min(r.min_exp, (long long)w[5]);
+            r.abs_sum += scratch[8 * k + 6];
+        }
+        fo.slots[blockIdx.x] = r;
     }
 }
 
@@ -146,17 +182,12 @@ __global__ __launch_bounds__(256) void k_ece(Ctl *ctl, E ed, const int *row_ptr,
         const double cost = readlane_f64(asel, sl);
         if (lane == 0) final_person(acc, fo, i, j, gmax >= 0, cnt, cost, vmax, pj, eps);
     }
-    flush_final(ctl, fo, acc);
+    flag_ece_failure(ctl, acc.bad);
+    __shared__ double s_fin[8 * 4];
+    if (fo.fin) flush_final_wg(fo, acc, s_fin);  // (uniform over the launch)
 }
 
-// everything the final pass accumulates into, in one launch
-__global__ void k_final_reset(Ctl *ctl) {
-    ctl->ece_fail = 0;
-    ctl->dup_rows = 0;
-    ctl->obj_abs = 0.0;
-    ctl->obj_minexp = 1 << 20;
-    for (int k = 0; k < 4; ++k) ctl->val_cnt[k] = 0ull;
-}
+__global__ void k_final_reset(Ctl *ctl) { ctl->ece_fail = 0; }
 
 // get_obj, step 2: the reference adds in person order into ONE double (:491, :519-521); floating-point
 // addition is not associative, so the sum is reproduced sequentially by a single lane.
@@ -167,11 +198,68 @@ __global__ void k_final_reset(Ctl *ctl) {
 // similar magnitude, the usual case, qualify: q >= -20 or so against sums below 2^30).
 template <class E>
 __global__ __launch_bounds__(1024) void k_obj_sum(Ctl *ctl, E ed, const int *row_ptr, const int *p2o, int n_rows,
-                                                  int maximize, const double *contrib, const int *nmatch) {
+                                                  int maximize, const double *contrib, const int *nmatch,
+                                                  const FinSlot *slots, int n_slots) {
     if (blockIdx.x != 0) return;
-    if (ctl->dup_rows == 0) {  // uniform
-        const int q = ctl->obj_minexp;
-        const bool order_free = q >= (1 << 20) || (q > -1000 && 2.0 * ctl->obj_abs < __builtin_ldexp(1.0, q + 52));
+    // the workgroups' results of the final pass (kernels_check.hpp, FinSlot) -> the control block
+    __shared__ double s_fin[8 * 16];
+    __shared__ FinSlot s_tot;
+    {
+        unsigned long long d = 0, ng = 0, nb = 0, ni = 0, du = 0;  // (64-bit sums: the per-lane accumulators are ints)
+        long long me = 1 << 20;
+        double ab = 0.0;
+        for (int k = threadIdx.x; k < n_slots; k += 1024) {
+            const FinSlot r = slots[k];
+            d += r.distinct;
+            ng += r.n_neg;
+            nb += r.n_big;
+            ni += r.n_inv;
+            du += r.dups;
+            me = min(me, r.abs_sum != 0.0 ? r.min_exp : (long long)(1 << 20));  // (a zeroed slot: a workgroup without rows)
+            ab += r.abs_sum;
+        }
+        for (int off = 32; off >= 1; off >>= 1) {
+            auto sx = [&](unsigned long long v) {
+                return ((unsigned long long)__shfl_xor((unsigned)(v >> 32), off) << 32) | (unsigned long long)__shfl_xor((unsigned)(v & 0xffffffffull), off);
+            };
+            d += sx(d);
+            ng += sx(ng);
+            nb += sx(nb);
+            ni += sx(ni);
+            du += sx(du);
+            me = min(me, (long long)sx((unsigned long long)me));
+            ab += shfl_xor_f64(ab, off);
+        }
+        const int wave = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) {
+            unsigned long long *w = reinterpret_cast<unsigned long long *>(s_fin) + 8 * wave;
+            w[0] = d, w[1] = ng, w[2] = nb, w[3] = ni, w[4] = du, w[5] = (unsigned long long)me;
+            s_fin[8 * wave + 6] = ab;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            FinSlot r{0, 0, 0, 0, 0, 1 << 20, 0.0, 0};
+            for (int k = 0; k < 16; ++k) {
+                const unsigned long long *w = reinterpret_cast<const unsigned long long *>(s_fin) + 8 * k;
+                r.distinct += w[0], r.n_neg += w[1], r.n_big += w[2], r.n_inv += w[3], r.dups += w[4];
+                r.min_exp = min(r.min_exp, (long long)w[5]);
+                r.abs_sum += s_fin[8 * k + 6];
+            }
+            s_tot = r;
+            ctl->val_cnt[0] = r.distinct;
+            ctl->val_cnt[1] = r.n_neg;
+            ctl->val_cnt[2] = r.n_big;
+            ctl->val_cnt[3] = r.n_inv;
+            ctl->dup_rows = (int)min(r.dups, 0x7fffffffull);
+            ctl->obj_minexp = (int)r.min_exp;
+            ctl->obj_abs = r.abs_sum;
+        }
+        __syncthreads();
+    }
+    const bool no_dups = s_tot.dups == 0;
+    if (no_dups) {  // uniform
+        const int q = (int)s_tot.min_exp;
+        const bool order_free = q >= (1 << 20) || (q > -1000 && 2.0 * s_tot.abs_sum < __builtin_ldexp(1.0, q + 52));
         if (order_free) {
             __shared__ double s_part[16];
             double part = 0.0;
@@ -193,7 +281,7 @@ __global__ __launch_bounds__(1024) void k_obj_sum(Ctl *ctl, E ed, const int *row
     if (threadIdx.x >= kWave) return;  // one wavefront
     const int lane = threadIdx.x;
     double obj = 0.0;
-    if (ctl->dup_rows == 0) {
+    if (no_dups) {
         // 64 contributions per coalesced load, then added one by one in person order (v_readlane): the
         // additions stay sequential, only the loads are parallel
         double nxt = (lane < n_rows) ? contrib[lane] : 0.0;

@@ -936,7 +936,6 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
         // one lane per person -- the one that holds the last match, lane 0 of the group when there is none -- finishes
         // the person (kernels_check.hpp); the price of the wanted column comes from memory, requested for all persons
         // of the lane group before the first is used
-        if (loader) return;
         int pj_[kTileRows];
         double wp[kTileRows];
 #pragma unroll
@@ -953,7 +952,11 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
             const bool me = person[j] >= 0 && (Q >= 0 ? sg[j] == Q : gl == 0);
             if (me) final_person(acc, ta.fo, person[j], pj_[j], Q >= 0, n, (double)__int_as_float(scost[j]), V, wp[j], eps);
         }
-        flush_final(a.ctl, ta.fo, acc);
+        flag_ece_failure(a.ctl, acc.bad);
+        if (ta.fo.fin) {  // uniform over the launch
+            __syncthreads();  // every look-up is done: the price buffers are free
+            flush_final_wg(ta.fo, acc, s_price);
+        }
         return;
     }
     // merge the kGL lanes of each group, once per person (same three all-reduces as top2_wave_reduce)

@@ -193,6 +193,8 @@ struct misslap_solver {
     Ctl *ctl = nullptr;
     double *contrib = nullptr;
     int *nmatch = nullptr;
+    FinSlot *fin_slots = nullptr;  // per-workgroup results of the final pass (kernels_check.hpp)
+    int fin_slots_n = 0;
     unsigned long long *launch_edges = nullptr;
     int launch_edges_cap = 0;
     // tile-major second copy of the edges for k_bid_tiled (kernels_tiled.hpp)
@@ -727,8 +729,9 @@ int check_lanes(const misslap_solver *h) {
 #define MISSLAP_CHECK_KERNEL(GL) k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 3, 0, GL, 1, 1>
 
 // rows [0, n_rows) on the row-major CSR (the sample of run_ece; every row where there is no tile-major copy)
-int launch_rows_gather(misslap_solver *h, float eps, const FinalOut &fo, int n_rows) {
+int launch_rows_gather(misslap_solver *h, float eps, const FinalOut &fo, int n_rows, int *n_blocks = nullptr) {
     const int grid = blocks_for(n_rows, 4);
+    if (n_blocks) *n_blocks = grid;
     if (h->f32) {
         EdgesF32 ed{h->edges32};
         hipLaunchKernelGGL(k_ece<EdgesF32>, dim3(grid), dim3(256), 0, h->stream, h->ctl, ed, h->row_ptr, h->price,
@@ -742,9 +745,9 @@ int launch_rows_gather(misslap_solver *h, float eps, const FinalOut &fo, int n_r
     return MISSLAP_OK;
 }
 // every row, on the engine the handle has
-int launch_rows_all(misslap_solver *h, float eps, const FinalOut &fo) {
+int launch_rows_all(misslap_solver *h, float eps, const FinalOut &fo, int *n_blocks = nullptr) {
     const int gl = check_lanes(h);
-    if (!gl) return launch_rows_gather(h, eps, fo, h->n_rows);
+    if (!gl) return launch_rows_gather(h, eps, fo, h->n_rows, n_blocks);
     RoundArgs a = round_args(h);
     a.eps = eps;
     a.launch_edges = nullptr;
@@ -754,6 +757,8 @@ int launch_rows_all(misslap_solver *h, float eps, const FinalOut &fo) {
     long long grid = ((long long)h->n_rows + per_wg_max - 1) / per_wg_max;
     const long long spread = std::min<long long>(h->n_cus, ((long long)h->n_rows + groups - 1) / groups);
     if (grid < spread) grid = spread;
+    if (fo.fin && grid > h->fin_slots_n) return fail(MISSLAP_ERR_STATE, "final pass: grid %lld exceeds its result slots (%d)", grid, h->fin_slots_n);
+    if (n_blocks) *n_blocks = (int)grid;
     const size_t lds = tiled_lds_bytes(kTileColsHalf);
     switch (gl) {
 #define X(GL) \
@@ -776,7 +781,7 @@ int run_ece(misslap_solver *h, float eps, int *ok) {
     }
     h->ctl_fresh = false;
     HIP_TRY(hipMemsetAsync(&h->ctl->ece_fail, 0, sizeof(int), h->stream));
-    const FinalOut fo{0, h->maximize, h->o2p, h->contrib, h->nmatch, h->n_rows, h->n_cols};
+    const FinalOut fo{0, h->maximize, h->o2p, h->contrib, h->nmatch, h->n_rows, h->n_cols, nullptr};
     const int sample = std::min(h->n_rows, kEceSampleRows);
     if ((rc = launch_rows_gather(h, eps, fo, sample))) return rc;
     if (sample < h->n_rows && (rc = launch_rows_all(h, eps, fo))) return rc;
@@ -1057,6 +1062,8 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
         blk.want(&h->ctl, 1);
         blk.want(&h->contrib, N);
         blk.want(&h->nmatch, N);
+        h->fin_slots_n = (int)std::max<size_t>(kMaxGridBlocks, N / 256 + 256);  // >= any grid of the final pass
+        blk.want(&h->fin_slots, (size_t)h->fin_slots_n);
         h->wg_stats_slots = (int)std::min<size_t>(N / 64 + 4096, 1u << 22);
         blk.want(&h->wg_stats, 2 * (size_t)h->wg_stats_slots);
         if (h->tiled_ok && kTiledShapes[h->tiled_shape][7] > 1) {
@@ -1739,16 +1746,19 @@ MISSLAP_API int misslap_finish(misslap_solver *h, int32_t *person_to_object_out,
     // ONE pass over the rows for meta['eCE'] / soln_found (:297, :300), the objective (:302, :489-523) and the validity
     // flags of the assignment (benchmarking.py:56-64): all three look for the stored entry (i, sol[i])
     hipLaunchKernelGGL(k_final_reset, dim3(1), dim3(1), 0, h->stream, h->ctl);
-    const FinalOut fo{1, h->maximize, h->o2p, h->contrib, h->nmatch, h->n_rows, h->n_cols};
-    if ((rc = launch_rows_all(h, h->target_eps, fo))) return rc;
+    const FinalOut fo{1, h->maximize, h->o2p, h->contrib, h->nmatch, h->n_rows, h->n_cols, h->fin_slots};
+    int n_slots = 0;
+    // (a workgroup without rows returns before it writes its slot)
+    HIP_TRY(hipMemsetAsync(h->fin_slots, 0, sizeof(FinSlot) * (size_t)h->fin_slots_n, h->stream));
+    if ((rc = launch_rows_all(h, h->target_eps, fo, &n_slots))) return rc;
     if (h->f32) {
         EdgesF32 ed{h->edges32};
         hipLaunchKernelGGL(k_obj_sum<EdgesF32>, dim3(1), dim3(1024), 0, h->stream, h->ctl, ed, h->row_ptr, h->p2o,
-                           h->n_rows, h->maximize, h->contrib, h->nmatch);
+                           h->n_rows, h->maximize, h->contrib, h->nmatch, h->fin_slots, n_slots);
     } else {
         EdgesF64 ed{h->col, h->val64};
         hipLaunchKernelGGL(k_obj_sum<EdgesF64>, dim3(1), dim3(1024), 0, h->stream, h->ctl, ed, h->row_ptr, h->p2o,
-                           h->n_rows, h->maximize, h->contrib, h->nmatch);
+                           h->n_rows, h->maximize, h->contrib, h->nmatch, h->fin_slots, n_slots);
     }
     HIP_TRY(hipGetLastError());
     if (person_to_object_out)

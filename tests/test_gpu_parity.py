@@ -1047,7 +1047,7 @@ def _drive_to_phase_end(g):
     ("forced_f64", dict(kind="sparse", n=6000, m=6000, density=0.003), "max", dict(force_f64=True)),
     # fewer rows than the sample: the sample IS the pass
     ("small", dict(kind="sparse", n=300, m=300, density=0.05), "max", dict()),
-    ("rect", dict(kind="sparse", n=5000, m=7500, density=0.004), "max", dict(tail_threshold=0)),
+    ("tiled_rect", dict(kind="sparse", n=5000, m=7500, density=0.004), "max", dict(tail_threshold=0)),
 ])
 def test_ece_pass_equals_the_reference_loop_at_every_phase_end(label, spec, prob, kw, gpu_lib):
     """misslap_check_ece (sample pass + full pass, on the full-scan engine where the handle has the tile-major copy)
@@ -1075,7 +1075,8 @@ def test_ece_pass_equals_the_reference_loop_at_every_phase_end(label, spec, prob
     ref = orc.auction_solve(loc=loc, val=val.copy(), problem=prob, cardinality_check=False, max_iter=10**7)
     assert np.array_equal(sol, ref["sol"]) and g.meta["eCE"] == ref["meta"]["eCE"] == 1
     assert g.meta["soln_found"] == ref["meta"]["soln_found"] and g.gpu["obj_f64"] == ref["extra"]["obj_f64"]
-    assert g.gpu["complete_assignment"][1:] == (True, True) and g.gpu["valid_assignment"]
+    n = int(loc[:, 0].max()) + 1  # benchmarking.py:56-64 with size = number of rows
+    assert g.gpu["complete_assignment"] == (np.unique(sol).size == n, True, bool((sol < n).all())) and g.gpu["valid_assignment"]
 
 
 @pytest.mark.parametrize("thr", [None, 0, 16])
