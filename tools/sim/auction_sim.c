@@ -20,6 +20,11 @@
  * Bidder trace: with SIM_TRACE=<file> and SIM_TRACE_THR=<K> in the environment the persons bidding in rounds with
  * at most K bidders are written as int32, rounds separated by -1 (tools/tail_reuse.py reads it).
  *
+ * On-chip working set of the small rounds: with SIM_LDS=<K> every bid of a round with at most K bidders looks its
+ * person's line up in direct-mapped caches of 128 .. 1024 lines (index = person mod size) and each candidate's price
+ * record in direct-mapped caches of 1024 .. 16384 records (index = object mod size); the hit rates are printed per
+ * mode ("lds_sim").  The caches are write-through in the design they stand for, so a hit is a tag match.
+ *
  * usage: auction_sim <input.bin> C policy build_thr use_thr
  *   input.bin: int64 nnz, int32 maximize, int32 loc[nnz][2], double val[nnz]
  *   build_thr: caches are (re)built on a miss in rounds with K <= build_thr
@@ -91,6 +96,14 @@ int main(int argc, char **argv) {
     int64_t khist[33] = {0};  /* rounds with exactly K bidders, K <= 32 */
     int64_t its = 0;
     int K = N, nred = 0;
+    /* direct-mapped on-chip caches of the small rounds (see the header) */
+    const int lds_thr = getenv("SIM_LDS") ? atoi(getenv("SIM_LDS")) : 0;
+    enum { NL = 4, NR = 5 };
+    const int lsz[NL] = {128, 256, 512, 1024}, rsz[NR] = {1024, 2048, 4096, 8192, 16384};
+    int *ltag[NL], *rtag[NR];
+    for (int a = 0; a < NL; ++a) ltag[a] = malloc(sizeof(int) * lsz[a]), memset(ltag[a], 0xff, sizeof(int) * lsz[a]);
+    for (int a = 0; a < NR; ++a) rtag[a] = malloc(sizeof(int) * rsz[a]), memset(rtag[a], 0xff, sizeof(int) * rsz[a]);
+    int64_t lds_bids[7] = {0}, lds_lhit[7][NL] = {{0}}, lds_recs[7] = {0}, lds_rhit[7][NR] = {{0}}, lds_allrec[7][NR] = {{0}};
     FILE *trace = getenv("SIM_TRACE") ? fopen(getenv("SIM_TRACE"), "wb") : NULL;
     const int trace_thr = getenv("SIM_TRACE_THR") ? atoi(getenv("SIM_TRACE_THR")) : 256;
     for (;;) {
@@ -130,6 +143,25 @@ int main(int argc, char **argv) {
                     bids[mode]++;
                     hits[mode] += hit;
                     round_hits += hit;
+                }
+                if (lds_thr && K <= lds_thr && c_valid[i]) {
+                    lds_bids[mode]++;
+                    for (int a = 0; a < NL; ++a) {
+                        lds_lhit[mode][a] += ltag[a][i % lsz[a]] == i;
+                        ltag[a][i % lsz[a]] = i;
+                    }
+                    lds_recs[mode] += c_n[i];
+                    for (int a = 0; a < NR; ++a) {
+                        int all = 1;
+                        for (int k = 0; k < c_n[i]; ++k) {
+                            const int cj = c_col[(size_t)i * C + k];
+                            const int h1 = rtag[a][cj % rsz[a]] == cj;
+                            lds_rhit[mode][a] += h1;
+                            all &= h1;
+                            rtag[a][cj % rsz[a]] = cj;
+                        }
+                        lds_allrec[mode][a] += all;
+                    }
                 }
                 const int bg = hit && build && alive < refresh;
                 bg_builds += bg;
@@ -260,6 +292,19 @@ int main(int argc, char **argv) {
                "\"all_hit_rounds\": %.4f}",
                m ? ",\n  " : "", names[m], (long long)phase_rounds[m], (long long)rounds[m], (long long)bids[m],
                bids[m] ? (double)hits[m] / bids[m] : 0.0, rounds[m] ? (double)allhit[m] / rounds[m] : 0.0);
+    if (lds_thr) {
+        printf("],\n \"lds_sim\": [");
+        for (int m = 0; m < 7; ++m) {
+            if (!lds_bids[m]) continue;
+            printf("%s{\"mode\": \"%s\", \"bids\": %lld, \"line_hit\": {", m ? ",\n  " : "", names[m], (long long)lds_bids[m]);
+            for (int a = 0; a < NL; ++a) printf("%s\"%d\": %.4f", a ? ", " : "", lsz[a], (double)lds_lhit[m][a] / lds_bids[m]);
+            printf("}, \"record_hit\": {");
+            for (int a = 0; a < NR; ++a) printf("%s\"%d\": %.4f", a ? ", " : "", rsz[a], lds_recs[m] ? (double)lds_rhit[m][a] / lds_recs[m] : 0.0);
+            printf("}, \"all_records_of_a_bid_hit\": {");
+            for (int a = 0; a < NR; ++a) printf("%s\"%d\": %.4f", a ? ", " : "", rsz[a], (double)lds_allrec[m][a] / lds_bids[m]);
+            printf("}}");
+        }
+    }
     printf("],\n \"rounds_by_K\": [");
     for (int k = 1; k <= 32; ++k) printf("%s%lld", k > 1 ? ", " : "", (long long)khist[k]);
     printf("]}\n");

@@ -37,6 +37,9 @@ if g:
     ok = res["its"] == g["meta"]["its"] and hashlib.sha256(sol.tobytes()).hexdigest() == g["sol_sha256"]
     res["matches_fixture"] = bool(ok)
 modes = res.pop("modes")
+for m in res.pop("lds_sim", []):
+    print("  lds %-12s bids=%9d line_hit=%s record_hit=%s all_records_of_a_bid_hit=%s" % (
+        m["mode"], m["bids"], m["line_hit"], m["record_hit"], m["all_records_of_a_bid_hit"]))
 by_k = res.pop("rounds_by_K", None)
 print(json.dumps(res))
 for m in modes:
