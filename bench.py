@@ -108,24 +108,56 @@ def launch_ranks(n, argv):
     raise SystemExit(0 if all(rc == 0 for rc in rcs) else next(rc for rc in rcs if rc != 0) or 1)
 
 
-def measured_copy_peak(torch):
-    """Device copy rate of THIS GPU in THIS process (read + write bytes of a 1 GiB fp32 copy per second): the
-    'achievable' HBM rate next to the 8 TB/s of the data sheet (report both)."""
-    n = 1 << 28
-    a = torch.empty(n, dtype=torch.float32, device="cuda").normal_()
-    b = torch.empty_like(a)
-    for _ in range(3):
-        b.copy_(a)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 20
-    e0.record()
-    for _ in range(reps):
-        b.copy_(a)
-    e1.record()
-    e1.synchronize()
-    ms = e0.elapsed_time(e1) / reps
-    del a, b
-    return 2 * n * 4 / (ms * 1e-3) / 1e9
+def measured_hbm_peaks(device):
+    """What the HBM of THIS GPU delivers to the library's own streaming kernels in THIS process (misslap_measure_hbm:
+    16 bytes per lane, 8 workgroups per CU, 1 GiB): a read-only pass and a copy -- the 'achievable' rates next to the
+    8 TB/s of the data sheet (report both).  The roofline kernel only reads, so its fraction of the
+    measured peak is quoted against the READ rate."""
+    import ctypes as C
+    from sslap_amd import _lib
+    rd, cp = C.c_double(), C.c_double()
+    _lib.check(_lib.load().misslap_measure_hbm(int(device), 1 << 30, 20, C.byref(rd), C.byref(cp)))
+    return rd.value, cp.value
+
+
+def run_concurrent(B, steps, make_solver, edges_per_solve, want_sha, digest):
+    """B independent solves at a time on B handles / B HIP streams driven by B host threads (ctypes releases the GIL
+    for the whole solve): what one GPU delivers when the application has many LAPs -- the reference's own harness
+    solves them in a loop (benchmarking.py:84-142).  During 87 % of a C3 solve a single problem occupies ONE of the
+    256 CUs (the tail kernels), so independent problems overlap almost freely."""
+    import threading
+    start = threading.Barrier(B + 1)
+    shas, errs = [], []
+    lock = threading.Lock()
+
+    def worker():
+        try:
+            start.wait()
+            for _ in range(steps):
+                s = make_solver()
+                sol = s.solve()
+                d = digest(sol)
+                with lock:
+                    shas.append(d)
+                del s
+        except Exception as e:  # noqa: BLE001
+            with lock:
+                errs.append(repr(e))
+    th = [threading.Thread(target=worker) for _ in range(B)]
+    for t in th:
+        t.start()
+    start.wait()
+    t0 = time.perf_counter()
+    for t in th:
+        t.join()
+    wall = time.perf_counter() - t0
+    if errs:
+        raise SystemExit(f"concurrent solves failed: {errs[:2]}")
+    n = B * steps
+    return {"B": B, "solves": n, "wall_ms": round(1e3 * wall, 3), "ms_per_solve": round(1e3 * wall / n, 3),
+            "aggregate_medges_s": round(edges_per_solve * n / wall / 1e6, 2),
+            "all_sha256_equal_reference_run": all(d == want_sha for d in shas) and len(shas) == n,
+            "hw_queues_env": os.environ.get("GPU_MAX_HW_QUEUES")}
 
 
 def source_digest():
@@ -166,6 +198,9 @@ def main():
     ap.add_argument("--cpu-rounds", type=int, default=100_000)
     ap.add_argument("--cpu-sample-only", action="store_true", help="cpu_baseline: the bounded sample only")
     ap.add_argument("--tail-threshold", type=int, default=None)
+    ap.add_argument("--concurrent", type=int, default=0,
+                    help="N = 1 only: after the timed single-solve steps, B independent solves at a time from B host "
+                         "threads (B handles, B streams); reported beside the single-solve `value`, never instead of it")
     ap.add_argument("--mode", choices=("sharded", "replicas"), default="sharded",
                     help="N > 1: 'sharded' = ONE problem, persons of the big rounds sharded over the ranks, RCCL "
                          "exchange (strong scaling; the default); 'replicas' = N independent problems, one per GPU, "
@@ -174,6 +209,11 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(args.gpus, sys.argv[1:])  # does not return
+    if args.concurrent > 1:
+        # hardware queues for the concurrent streams (the runtime's default is 4 per process: streams beyond that
+        # share a queue and their kernels serialise -- C3, 16 at a time: 2.8x the single-solve throughput with 4 queues,
+        # 4.8x with 16, 6.4x with 32); must be in the environment before the HIP runtime starts
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(max(2 * args.concurrent, 4), 32)))
 
     import numpy as np
     import torch
@@ -216,7 +256,8 @@ def main():
     d_loc = torch.from_numpy(loc).cuda()
     d_val = torch.from_numpy(val).cuda()
     del loc, val
-    gpu_opts = dict(device=local_rank, profile=True)
+    # (device-resident inputs ordered behind the stream that produced them: no device-wide wait per create)
+    gpu_opts = dict(device=local_rank, profile=True, input_stream=torch.cuda.current_stream().cuda_stream)
     if args.tail_threshold is not None:
         gpu_opts["tail_threshold"] = args.tail_threshold
 
@@ -272,12 +313,22 @@ def main():
         edges_all = sum(g["edges_scanned"] for _, g in runs)
         fs_all_edges, fs_max_ms = None, None
 
+    # who took part: every rank's device, assignment hash and what its communicator says about itself
+    from sslap_amd import _lib
+    import ctypes as C
+    name = C.create_string_buffer(128)
+    uuid = C.create_string_buffer(40)
+    cus, hbm = C.c_int32(), C.c_int64()
+    _lib.load().misslap_device_info(local_rank, name, 128, C.byref(cus), C.byref(hbm))
+    _lib.load().misslap_device_uuid(local_rank, uuid, 40)
+    me = {"rank": rank, "device": name.value.decode(), "device_uuid": uuid.value.decode(), "local_rank": local_rank,
+          "sol_sha256": synth.sol_digest(sol), "comm": comm.info() if comm is not None else None,
+          "sharded_rounds_per_solve": runs[-1][1].get("sharded_rounds", 0)}
+    ranks = [me]
+    if world > 1:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, me)
     if rank == 0:
-        from sslap_amd import _lib
-        import ctypes as C
-        name = C.create_string_buffer(128)
-        cus, hbm = C.c_int32(), C.c_int64()
-        _lib.load().misslap_device_info(local_rank, name, 128, C.byref(cus), C.byref(hbm))
         meta, gpu = runs[-1]
         bpe = gpu["bytes_per_edge"]
         bid_ms = sum(g["bid_ms"] for _, g in runs)
@@ -347,7 +398,23 @@ def main():
                         "h2d_bytes": int(loc_h.nbytes + val_h.nbytes),
                         "note": "create from host numpy arrays (H2D of the COO input + CSR build) + solve; never part of `value`"}
             del sh, loc_h, val_h
-        copy_peak = measured_copy_peak(torch)
+        read_peak, copy_peak = measured_hbm_peaks(local_rank)
+        conc = None
+        if args.concurrent > 1 and world == 1:
+            opts_c = dict(gpu_opts, profile=False)
+            # hipFree waits for EVERY stream of the device: a handle destroyed while fifteen other solves run stalls
+            # behind their kernels.  The library parks freed blocks instead when its cache limits allow it (default:
+            # small blocks only) -- with room for B handles no solve of the concurrent phase calls hipMalloc / hipFree
+            cache_gb = 0 if os.environ.get("MISSLAP_BENCH_SMALL_CACHE") else 4 * args.concurrent
+            if cache_gb:
+                _lib.check(_lib.load().misslap_set_cache_limits(cache_gb << 30, 8 << 30, 4096))
+            conc = run_concurrent(args.concurrent, max(1, args.steps),
+                                  lambda: AuctionSolver.from_device_pointers(d_loc.data_ptr(), d_val.data_ptr(), nnz,
+                                                                             problem="max", max_iter=10**8, **opts_c),
+                                  gpu["edges_scanned"], synth.sol_digest(sol), synth.sol_digest)
+            conc["block_cache_GiB"] = cache_gb
+            conc["single_solve_ms_per_step"] = round(1e3 * dt / args.steps, 3)
+            conc["throughput_vs_single"] = round(conc["aggregate_medges_s"] / (edges_all / dt / 1e6), 2)
         out = {
             "metric": "Medges/s (bid-phase CSR nnz/s) + solve ms, N=200k d=0.1% sparse LAP",
             "value": round(edges_all / dt / 1e6, 2),
@@ -375,6 +442,8 @@ def main():
             # reference-equivalent count (sum of the bidders' row lengths, the oracle's number); rows that a
             # person's candidate line answered exactly are counted but not read:
             "edges_read_per_solve": gpu["edges_scanned"] - gpu["cand_edges"],
+            # ... so this, not `value`, is what the memory system saw (never to be read as `value`'s bandwidth)
+            "edges_read_medges_s": round((edges_all - sum(g["cand_edges"] for _, g in runs)) / dt / 1e6, 2) if world == 1 else None,
             "candidate_line_hit_rate": round(gpu["cand_hits"] / max(gpu["bids_made"], 1), 4),
             "sol_sha256": synth.sol_digest(sol), "obj_f64": gpu["obj_f64"],
             "complete_assignment": list(gpu["complete_assignment"]), "valid_assignment": gpu["valid_assignment"],
@@ -406,9 +475,11 @@ def main():
                 "launches": rk_launches, "avg_launch_us": round(1e3 * rk_ms / max(rk_launches, 1), 3),
                 "algorithmic_bytes_per_edge": bpe,
                 "algorithmic_bytes_per_launch": round(rk_edges * bpe / max(rk_launches, 1)),
-                # the same achieved rate against what a device copy reaches on this GPU in this process
-                "peak_measured_copy": round(copy_peak, 1), "frac_of_measured": round(achieved / copy_peak, 5),
-                "fullscan_frac_of_measured": round(fs_achieved / copy_peak, 5),
+                # the same achieved rate against what the library's own streaming kernels reach on this GPU in this
+                # process: a read-only pass (the roofline kernel only reads: the fractions are against THIS) and a copy
+                "peak_measured_read": round(read_peak, 1), "peak_measured_copy": round(copy_peak, 1),
+                "frac_of_measured": round(achieved / read_peak, 5),
+                "fullscan_frac_of_measured": round(fs_achieved / read_peak, 5),
                 "timing": "HIP events handed to the launch (hipExtLaunchKernel): begin / end of the kernel itself",
                 "traffic": traffic,
                 "traffic_source": "rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction calibrated on known-size "
@@ -416,6 +487,17 @@ def main():
                 **traffic_meta,
             },
             "device": name.value.decode(), "compute_units": int(cus.value),
+            # N > 1: proof that N ranks took part and agree -- what the transport itself reports (ncclCommCount), every
+            # rank's device and assignment hash, the exchanges a solve issued
+            "ranks": ranks,
+            "rccl_nranks": (ranks[0]["comm"]["transport_ranks"] if ranks[0]["comm"] and ranks[0]["comm"]["kind"] == "rccl" else None),
+            "comm_kind": ranks[0]["comm"]["kind"] if ranks[0]["comm"] else None,
+            "comm_ranks_seen_by_every_rank": [r["comm"]["transport_ranks"] if r["comm"] else None for r in ranks],
+            "distinct_gpus": len({r["device_uuid"] for r in ranks}),
+            "sharded_rounds_per_solve": ranks[0]["sharded_rounds_per_solve"],
+            "exchanges_per_solve": 2 * ranks[0]["sharded_rounds_per_solve"],
+            "sol_sha256_equal_on_all_ranks": len({r["sol_sha256"] for r in ranks}) == 1,
+            "concurrent": conc,
         }
         if world == 1 and not args.no_cpu:
             whole = not args.cpu_sample_only and args.config != "C5"  # (C5: ~20 min of oracle time)
@@ -423,6 +505,8 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
+        if not out["sol_sha256_equal_on_all_ranks"]:
+            raise SystemExit("the ranks disagree on the assignment")
     if world > 1:
         dist.destroy_process_group()
 

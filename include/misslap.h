@@ -121,8 +121,8 @@ typedef struct misslap_meta {
     uint64_t tiled_edges;
     int32_t tiled_active;        /* full-scan engine for big rounds: 0 none (k_bid only), 1 k_bid_tiled */
     int32_t tiled_min_K;         /* rounds with K >= this use it */
-    int64_t merge_launches;      /* (unused: the 2-D scan engine of round 1 was removed) */
-    double merge_ms;
+    int64_t merge_launches;      /* DEPRECATED, always 0 (the 2-D scan engine of round 1 was removed); the two fields */
+    double merge_ms;             /* only keep the offsets of what follows */
     uint64_t shard_edges;        /* multi-GPU: edges scanned in sharded rounds (this rank's share); the rest of
                                     edges_scanned is replicated work, identical on every rank */
     uint64_t cand_hits;          /* bids answered from the person's candidate line (exactly the same bid, no row scan) */
@@ -141,6 +141,8 @@ typedef struct misslap_meta {
     int32_t lines_active;        /* 1 = the handle kept candidate lines (0: switched off by option, by row length, or
                                     because eps could fall below the rounding error of a price update, see create) */
     int32_t reserved_i;
+    int64_t sharded_rounds;      /* multi-GPU: rounds whose bidders were sharded over the ranks -- each of them issued the
+                                    two all-reduces of the exchange step on this rank (0 on a single GPU) */
 } misslap_meta;
 
 /* Snapshot of the round state (tests / multi-GPU driver). */
@@ -250,6 +252,11 @@ int misslap_rccl_unique_id(void *id_out /* MISSLAP_RCCL_ID_BYTES */);
 int misslap_comm_init_rccl(misslap_comm **out, const void *unique_id, int32_t rank, int32_t world, int32_t device);
 int misslap_comm_init_custom(misslap_comm **out, const misslap_comm_ops *ops);
 int misslap_comm_destroy(misslap_comm *comm);
+/* What a communicator is, as the transport itself reports it: *kind = 1 RCCL / 0 custom; *rank, *world as given at
+ * creation; *transport_ranks = ncclCommCount of the RCCL communicator (the number of ranks RCCL itself sees -- a
+ * multi-GPU run proves with it that N ranks took part), for a custom one the world size of its ops.  Any pointer
+ * may be NULL. */
+int misslap_comm_info(const misslap_comm *comm, int32_t *kind, int32_t *rank, int32_t *world, int32_t *transport_ranks);
 /* AuctionSolver.solve() (auction_.pyx:268-306) over all ranks of `comm` (NULL: no exchange, a single rank).  Only
  * rounds with K >= status.shard_min_K are sharded and exchanged; all others are replicated. */
 int misslap_solve_sharded(misslap_solver *h, misslap_comm *comm, int32_t *person_to_object_out, misslap_meta *meta);
@@ -294,6 +301,13 @@ int misslap_get_state(misslap_solver *h, double *prices, int32_t *unassigned, in
 /* Device properties of the GPU the handle runs on (name buffer >= 128 bytes). */
 int misslap_device_info(int32_t device, char *name, int32_t name_len, int32_t *compute_units,
                         int64_t *hbm_bytes);
+/* The device's UUID as 32 hex digits + NUL (buffer >= 33 bytes): tells two ranks that share a GPU from two that do not. */
+int misslap_device_uuid(int32_t device, char *uuid_hex, int32_t len);
+/* What the HBM of THIS device delivers to a streaming kernel of the library, measured now: a read-only pass (every
+ * workgroup walks one contiguous chunk, four 16-byte non-temporal loads in flight per lane) and a copy of the same
+ * shape over `bytes` bytes, `reps` timed launches each; GB/s of bytes read, and of bytes read + written.  The "achievable" peak next to the data sheet's 8 TB/s that
+ * the roofline figures of bench.py are quoted against. */
+int misslap_measure_hbm(int32_t device, int64_t bytes, int32_t reps, double *read_GBs, double *copy_GBs);
 
 /* Feasibility guard of the front-end: maximum bipartite matching (Hopcroft-Karp) on the host, the reference's
  * c_hopcroft_solve / sslap.hopcroft_solve (feasibility_.pyx:95-283; called at auction_.pyx:562-566, :608-612).
@@ -317,6 +331,12 @@ int misslap_matching_of(misslap_solver *h, int32_t *size, int32_t *phases);
  * Call it when the embedding application needs the memory back; never while another thread creates / destroys handles
  * on a stream that may still use a parked block (the entry point synchronises every device it frees on). */
 int misslap_trim_caches(int64_t *freed_bytes);
+/* Limits of the device-block cache: total bytes parked, largest block parked, number of blocks (defaults 256 MB /
+ * 32 MB / 16: what a stream of small problems needs; MISSLAP_BLOCK_CACHE_MB in the environment sets the first two at
+ * start-up).  An application that solves many LARGE problems at a time raises them -- hipFree waits for every stream
+ * of the device, so a handle destroyed while other solves run stalls behind their kernels, and a cached block costs
+ * neither hipMalloc nor hipFree (bench.py --concurrent: C3, 16 at a time). */
+int misslap_set_cache_limits(int64_t max_total_bytes, int64_t max_block_bytes, int32_t max_blocks);
 
 const char *misslap_last_error(void);
 int misslap_abi_version(void);

@@ -46,7 +46,7 @@ class Meta(C.Structure):
         ("shard_edges", C.c_uint64), ("cand_hits", C.c_uint64), ("cand_edges", C.c_uint64),
         ("tail_stats", C.c_double * 12),
         ("complete_assignment", C.c_int32), ("valid_assignment", C.c_int32), ("lines_active", C.c_int32),
-        ("reserved_i", C.c_int32),
+        ("reserved_i", C.c_int32), ("sharded_rounds", C.c_int64),
     ]
 
 
@@ -116,11 +116,15 @@ SYMBOLS = {
     "misslap_comm_init_rccl": (C.c_int, [C.POINTER(_VP), _VP, C.c_int32, C.c_int32, C.c_int32]),
     "misslap_comm_init_custom": (C.c_int, [C.POINTER(_VP), C.POINTER(CommOps)]),
     "misslap_comm_destroy": (C.c_int, [_VP]),
+    "misslap_comm_info": (C.c_int, [_VP, _I32P, _I32P, _I32P, _I32P]),
+    "misslap_device_uuid": (C.c_int, [C.c_int32, C.c_char_p, C.c_int32]),
+    "misslap_measure_hbm": (C.c_int, [C.c_int32, C.c_int64, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "misslap_solve_sharded": (C.c_int, [_VP, _VP, _VP, C.POINTER(Meta)]),
     "misslap_drive_sharded": (C.c_int, [C.POINTER(RoundOps), _VP]),
     "misslap_hopcroft_karp": (C.c_int, [_VP, C.c_int64, C.c_int32, C.c_int32, _I32P, _VP, _VP]),
     "misslap_matching_gpu": (C.c_int, [_VP, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _I32P, _VP, _VP, _I32P]),
     "misslap_trim_caches": (C.c_int, [C.POINTER(C.c_int64)]),
+    "misslap_set_cache_limits": (C.c_int, [C.c_int64, C.c_int64, C.c_int32]),
     "misslap_last_error": (C.c_char_p, []),
     "misslap_abi_version": (C.c_int, []),
 }

@@ -29,6 +29,7 @@ struct misslap_comm {
     // RCCL
     void *nccl_comm = nullptr;
     int device = 0;
+    long long sharded_rounds = 0;  // rounds of the current solve that went through the exchange step
 };
 
 namespace misslap {
@@ -42,6 +43,7 @@ struct RcclApi {
     int (*CommInitRank)(void **, int, UniqueId, int) = nullptr;
     int (*CommDestroy)(void *) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*CommCount)(void *, int *) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
     void *handle = nullptr;
     std::string error;
@@ -69,6 +71,7 @@ inline RcclApi &rccl_api() {
         api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
         api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
         api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+        api.CommCount = reinterpret_cast<decltype(api.CommCount)>(sym("ncclCommCount"));
     });
     return api;
 }
@@ -106,6 +109,7 @@ int drive_sharded(const misslap_round_ops *o, misslap_comm *c, Fail &&fail) {
                 // a big round: bidders sharded over the ranks, per-object arg-max exchanged.  K is exact here, so
                 // the device-side decision "K >= shard_min_K" is the same on every rank.  No host read until the
                 // round is complete.
+                if (c) c->sharded_rounds += 1;
                 if ((rc = o->round_bid(o->ctx))) return rc;
                 if ((rc = exchange(true))) return rc;
                 if ((rc = o->round_tiebreak(o->ctx))) return rc;

@@ -239,6 +239,7 @@ struct misslap_solver {
     bool profile_all = false;  // profile >= 2: events around every k_bid launch, not only the full scans
     int rounds_per_sync = kDefaultRoundsPerSync;
     int rank = 0, world = 1;
+    long long sharded_rounds = 0;  // rounds of the last solve that were sharded and exchanged (misslap_solve_sharded)
     int shard_min_K = 0;  // multi-GPU: only rounds with K >= this are sharded and exchanged
     bool profile = false;
     int K_ub = 0;  // host-side upper bound of K (K never grows inside a phase)
@@ -361,7 +362,20 @@ struct BlockCache {
     std::mutex m;
     std::vector<Ent> idle;
     size_t held = 0;
-    static constexpr size_t kMaxEntries = 16, kMaxEach = (size_t)32 << 20, kMaxHeld = (size_t)256 << 20;
+    // limits (misslap_set_cache_limits; MISSLAP_BLOCK_CACHE_MB in the environment sets the first two at start-up).  The
+    // defaults keep what a stream of SMALL problems needs; an application that solves many large problems at a time
+    // raises them: hipFree waits for every stream of the device, i.e. for the other solves' running kernels
+    size_t kMaxHeld = (size_t)256 << 20, kMaxEach = (size_t)32 << 20, kMaxEntries = 16;
+    BlockCache() {
+        if (const char *e = std::getenv("MISSLAP_BLOCK_CACHE_MB")) {
+            const long long mb = std::atoll(e);
+            if (mb >= 0) {
+                kMaxHeld = (size_t)mb << 20;
+                kMaxEach = kMaxHeld;
+                kMaxEntries = 4096;
+            }
+        }
+    }
     void *take(int device, size_t bytes, size_t *got) {
         std::lock_guard<std::mutex> g(m);
         size_t best = idle.size();
@@ -530,6 +544,7 @@ int launch_bid_tiled(misslap_solver *h) {
         ta.order_person = order_person;
         ta.order_pos = order_pos;
     }
+    if (grid > h->wg_stats_slots) return fail(MISSLAP_ERR_STATE, "scan grid %lld exceeds the statistics slots (%d)", grid, h->wg_stats_slots);
     ProfRec *pr = nullptr;
     if (h->profile) {
         if (h->launch_idx >= h->launch_edges_cap)
@@ -539,7 +554,6 @@ int launch_bid_tiled(misslap_solver *h) {
         pr->fullscan = h->phase_fresh;  // K == N; with several ranks: this rank's share of the full scan
         pr->launch_idx = a.launch_idx = h->launch_idx++;
     }
-    if (grid > h->wg_stats_slots) return fail(MISSLAP_ERR_STATE, "scan grid %lld exceeds the statistics slots (%d)", grid, h->wg_stats_slots);
     h->wg_stats_pending = std::max(h->wg_stats_pending, (int)grid);
     const size_t lds = tiled_lds_bytes(shp[4]);
     const dim3 g((unsigned)grid);
@@ -1449,6 +1463,16 @@ MISSLAP_API int misslap_matching_of(misslap_solver *h, int32_t *size, int32_t *p
 
 MISSLAP_API const char *misslap_last_error(void) { return g_err.c_str(); }
 
+MISSLAP_API int misslap_set_cache_limits(int64_t max_total_bytes, int64_t max_block_bytes, int32_t max_blocks) {
+    if (max_total_bytes < 0 || max_block_bytes < 0 || max_blocks < 0) return fail(MISSLAP_ERR_INVALID, "negative limit");
+    BlockCache &bc = block_cache();
+    std::lock_guard<std::mutex> g(bc.m);
+    bc.kMaxHeld = (size_t)max_total_bytes;
+    bc.kMaxEach = (size_t)max_block_bytes;
+    bc.kMaxEntries = (size_t)max_blocks;
+    return MISSLAP_OK;
+}
+
 MISSLAP_API int misslap_trim_caches(int64_t *freed_bytes) {
     int64_t freed = 0;
     int keep_dev = 0;
@@ -1503,6 +1527,99 @@ MISSLAP_API int misslap_device_info(int32_t device, char *name, int32_t name_len
     if (compute_units) *compute_units = p.multiProcessorCount;
     if (hbm_bytes) *hbm_bytes = (int64_t)p.totalGlobalMem;
     return MISSLAP_OK;
+}
+
+MISSLAP_API int misslap_device_uuid(int32_t device, char *uuid_hex, int32_t len) {
+    if (!uuid_hex || len < 33) return fail(MISSLAP_ERR_INVALID, "uuid buffer of at least 33 bytes expected");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(MISSLAP_ERR_NO_DEVICE, "no HIP device available");
+    hipUUID id;
+    HIP_TRY(hipDeviceGetUuid(&id, device));
+    for (int k = 0; k < 16; ++k) snprintf(uuid_hex + 2 * k, 3, "%02x", (unsigned)(unsigned char)id.bytes[k]);
+    return MISSLAP_OK;
+}
+
+// Streaming rates of this device (see the header).  The shape is the fastest of tools/micro/stream_bench.hip
+// (profiles/r04_micro_stream.txt): every workgroup walks ONE contiguous chunk of the buffer, four 16-byte non-temporal
+// loads in flight per lane -- 6.9-7.0 TB/s read-only against 5.3 TB/s for a grid-stride loop over the whole buffer
+// with plain loads (6.1 for contiguous chunks with plain loads); a copy reaches 6.0-6.3 TB/s (read + written bytes).
+namespace {
+typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_stream_read(const v4u_t *src, size_t n16, unsigned *sink) {
+    const size_t per = (n16 + gridDim.x - 1) / gridDim.x;
+    size_t k = (size_t)blockIdx.x * per + threadIdx.x;
+    const size_t end = min(n16, (size_t)(blockIdx.x + 1) * per);
+    unsigned acc = 0;
+    for (; k + 3 * 256 < end; k += 4 * 256) {
+        v4u_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load(src + k + u * 256);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+    }
+    for (; k < end; k += 256) {
+        const v4u_t a = src[k];
+        acc ^= a.x ^ a.y ^ a.z ^ a.w;
+    }
+    if (acc == 0x9e3779b9u) *sink = acc;  // keeps the loads alive; the buffer is zero-filled, so nothing is stored
+}
+__global__ __launch_bounds__(256) void k_stream_copy(const v4u_t *src, v4u_t *dst, size_t n16) {
+    const size_t per = (n16 + gridDim.x - 1) / gridDim.x;
+    size_t k = (size_t)blockIdx.x * per + threadIdx.x;
+    const size_t end = min(n16, (size_t)(blockIdx.x + 1) * per);
+    for (; k + 3 * 256 < end; k += 4 * 256) {
+        v4u_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load(src + k + u * 256);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) __builtin_nontemporal_store(v[u], dst + k + u * 256);
+    }
+    for (; k < end; k += 256) dst[k] = src[k];
+}
+}  // namespace
+MISSLAP_API int misslap_measure_hbm(int32_t device, int64_t bytes, int32_t reps, double *read_GBs, double *copy_GBs) {
+    if (bytes < (1 << 20) || reps < 1 || (!read_GBs && !copy_GBs)) return fail(MISSLAP_ERR_INVALID, "bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(MISSLAP_ERR_NO_DEVICE, "no HIP device available");
+    if (device < 0 || device >= ndev) return fail(MISSLAP_ERR_INVALID, "device %d out of range", device);
+    HIP_TRY(hipSetDevice(device));
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+    const size_t n16 = (size_t)bytes / 16;
+    v4u_t *src = nullptr, *dst = nullptr;
+    unsigned *sink = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto done = [&](int code) {
+        if (src) (void)hipFree(src);
+        if (dst) (void)hipFree(dst);
+        if (sink) (void)hipFree(sink);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        return code;
+    };
+    if (hipMalloc((void **)&src, n16 * 16) != hipSuccess || hipMalloc((void **)&sink, 256) != hipSuccess ||
+        (copy_GBs && hipMalloc((void **)&dst, n16 * 16) != hipSuccess) || hipEventCreate(&e0) != hipSuccess ||
+        hipEventCreate(&e1) != hipSuccess || hipMemset(src, 0, n16 * 16) != hipSuccess)
+        return done(fail(MISSLAP_ERR_HIP, "misslap_measure_hbm: allocation failed: %s", hipGetErrorString(hipGetLastError())));
+    const dim3 block(256);
+    auto timed = [&](bool copy, double *out, double bytes_moved) {
+        // read: 16 workgroups per CU; copy: one workgroup per 16 KB (the two best grids of the microbenchmark)
+        const dim3 grid(copy ? (unsigned)std::max<size_t>(1, n16 / 1024) : (unsigned)cus * 16);
+        for (int r = -2; r < reps; ++r) {  // two warm-up launches
+            if (r == 0 && hipEventRecord(e0, nullptr) != hipSuccess) return false;
+            if (copy) hipLaunchKernelGGL(k_stream_copy, grid, block, 0, nullptr, src, dst, n16);
+            else hipLaunchKernelGGL(k_stream_read, grid, block, 0, nullptr, src, n16, sink);
+        }
+        float ms = 0.f;
+        if (hipEventRecord(e1, nullptr) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+            hipEventElapsedTime(&ms, e0, e1) != hipSuccess || ms <= 0.f)
+            return false;
+        *out = bytes_moved * reps / (ms * 1e-3) / 1e9;
+        return true;
+    };
+    if (read_GBs && !timed(false, read_GBs, (double)n16 * 16)) return done(fail(MISSLAP_ERR_HIP, "misslap_measure_hbm: timing failed"));
+    if (copy_GBs && !timed(true, copy_GBs, 2.0 * (double)n16 * 16)) return done(fail(MISSLAP_ERR_HIP, "misslap_measure_hbm: timing failed"));
+    return done(MISSLAP_OK);
 }
 
 MISSLAP_API int misslap_create(misslap_solver **out, int64_t nnz, const int32_t *loc, const double *val,
@@ -1821,6 +1938,7 @@ MISSLAP_API int misslap_finish(misslap_solver *h, int32_t *person_to_object_out,
 #endif
     meta->cand_hits = c.cand_hits;
     meta->cand_edges = c.cand_edges;
+    meta->sharded_rounds = h->sharded_rounds;
     if (h->profile && h->prof_used) {
         std::vector<unsigned long long> le((size_t)h->launch_idx);
         if (h->launch_idx)
@@ -1846,9 +1964,6 @@ MISSLAP_API int misslap_finish(misslap_solver *h, int32_t *person_to_object_out,
                     meta->fullscan_ms += ms;
                     meta->fullscan_edges += e;
                 }
-            } else if (r.kind == 3) {
-                meta->merge_launches += 1;
-                meta->merge_ms += ms;
             } else {
                 meta->tail_launches += 1;
                 meta->tail_ms += ms;
@@ -1961,6 +2076,25 @@ MISSLAP_API int misslap_comm_init_custom(misslap_comm **out, const misslap_comm_
     return MISSLAP_OK;
 }
 
+MISSLAP_API int misslap_comm_info(const misslap_comm *c, int32_t *kind, int32_t *rank, int32_t *world, int32_t *transport_ranks) {
+    if (!c) return fail(MISSLAP_ERR_INVALID, "null communicator");
+    if (kind) *kind = c->custom ? 0 : 1;
+    if (rank) *rank = c->rank;
+    if (world) *world = c->world;
+    if (transport_ranks) {
+        *transport_ranks = c->ops.world;
+        if (!c->custom) {
+            RcclApi &api = rccl_api();
+            int n = 0;
+            if (!api.CommCount) return fail(MISSLAP_ERR_HIP, "librccl: ncclCommCount is missing");
+            const int rc = api.CommCount(c->nccl_comm, &n);
+            if (rc) return fail(MISSLAP_ERR_HIP, "ncclCommCount failed: %s", api.GetErrorString(rc));
+            *transport_ranks = n;
+        }
+    }
+    return MISSLAP_OK;
+}
+
 MISSLAP_API int misslap_comm_destroy(misslap_comm *c) {
     if (!c) return MISSLAP_OK;
     if (!c->custom && c->nccl_comm) (void)rccl_api().CommDestroy(c->nccl_comm);
@@ -1985,10 +2119,15 @@ MISSLAP_API int misslap_solve_sharded(misslap_solver *h, misslap_comm *comm, int
     if (comm && !comm->custom && comm->device != h->device)  // an all-reduce enqueued on another device's stream fails late or hangs
         return fail(MISSLAP_ERR_INVALID, "the RCCL communicator lives on device %d, the handle on device %d", comm->device,
                     h->device);
+    // (before any work: a caller that forgot the size must not pay for a solve to learn it)
+    if (meta && h->abi >= 2 && (meta->struct_size < (int32_t)offsetof(misslap_meta, edges_scanned) || meta->struct_size > 65536))
+        return fail(MISSLAP_ERR_INVALID, "misslap_meta.struct_size = %d: set it to sizeof(misslap_meta) before the call", meta->struct_size);
     HIP_TRY(hipSetDevice(h->device));
     const double t0 = now_ms();
     const misslap_round_ops o = handle_round_ops(h);
+    if (comm) comm->sharded_rounds = 0;
     int rc = drive_sharded(&o, comm, fail);
+    h->sharded_rounds = comm ? comm->sharded_rounds : 0;
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->solve_ms += now_ms() - t0;

@@ -48,6 +48,13 @@ class Comm:
                 pass
             self._c = None
 
+    def info(self):
+        """dict(kind='rccl' | 'custom', rank, world, transport_ranks): transport_ranks is what the transport itself
+        reports -- ncclCommCount for RCCL."""
+        k, r, w, n = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        _lib.check(_lib.load().misslap_comm_info(self._c, C.byref(k), C.byref(r), C.byref(w), C.byref(n)))
+        return dict(kind="rccl" if k.value else "custom", rank=r.value, world=w.value, transport_ranks=n.value)
+
     @staticmethod
     def unique_id():
         """Rank 0: a fresh RCCL id (128 bytes) to hand to every rank."""

@@ -1102,3 +1102,64 @@ def test_falling_prices_without_lines_equal_the_reference(thr, gpu_lib):
     sg = g.state()
     assert np.array_equal(sg["p"].view(np.uint64), so["p"].view(np.uint64))
     assert np.array_equal(sg["p2o"], so["p2o"]) and np.array_equal(sol, so["p2o"]) and np.array_equal(sg["U"], so["U"])
+
+
+def _dist_cfg_worker(rank, world, port, cfgs, out):
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tests"), os.path.join(root, "tests", "golden")):
+        sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    from sslap_amd import from_sparse, synth
+    from sslap_amd.dist import Comm, solve_sharded
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm = Comm.gloo_staged()
+    res = {}
+    for cfg in cfgs:
+        loc, val = synth.gen_config(cfg)
+        s = from_sparse(loc, val, problem="max", cardinality_check=False, shard=(rank, world), max_iter=10**8)
+        sol = solve_sharded(s, comm)  # library defaults: shard_min_K = the full-scan threshold
+        res[cfg] = (synth.sol_digest(sol), s.meta["its"], s.meta["nreductions"], s.gpu["obj_f64"], s.gpu["edges_scanned"],
+                    s.gpu["shard_edges"], s.gpu["sharded_rounds"], s.shard_min_K, comm.info())
+        del s
+    out.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_solve_at_baseline_sizes_two_ranks_one_gpu(golden_large, gpu_lib):
+    """The sharded path at BASELINE sizes with the library's default shard threshold: C2 and C4 (the config with the
+    most sharded rounds per solve, 26 of 176) solved by two ranks that share cuda:0 and exchange through the custom
+    communicator (gloo, staged through the host).  Every rank must return the reference's assignment (sha256 of the
+    fixture captured from the real reference), and the sharded rounds' shares must add up to the single-GPU count."""
+    import socket
+    import torch.multiprocessing as mp
+    cfgs = ("C2", "C4")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dist_cfg_worker, args=(r, 2, port, cfgs, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for cfg in cfgs:
+        g = golden_large["cases"][cfg]
+        for rank in (0, 1):
+            sha, its, nred, obj, edges, sh, rounds, smk, info = got[rank][cfg]
+            assert sha == g["sol_sha256"], (cfg, rank)
+            assert (its, nred, obj) == (g["meta"]["its"], g["meta"]["nreductions"], g["obj_f64"]), (cfg, rank)
+            assert info == dict(kind="custom", rank=rank, world=2, transport_ranks=2)
+            assert rounds > 0 and sh > 0 and smk >= 8192
+        (e0, s0, r0), (e1, s1, r1) = got[0][cfg][4:7], got[1][cfg][4:7]
+        assert r0 == r1 and e0 - s0 == e1 - s1  # the same rounds were sharded; the replicated part is identical
+        assert s0 + s1 + (e0 - s0) == g["edges_scanned"]  # unique work = the single-GPU (= the reference's) edge count
+    assert got[0]["C4"][6] >= 20  # 26 sharded rounds per C4 solve
