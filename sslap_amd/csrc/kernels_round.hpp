@@ -42,10 +42,15 @@ struct RoundArgs {
     double *cand64;               // ... their fp64 costs (12 B/edge layout only, nullptr otherwise)
     int cand_build_max_K;         // k_bid uses and (re)builds lines only in rounds with K <= this
     int cand_refresh_min;         // ... and treats a hit that leaves fewer live candidates than this as a miss
-    unsigned long long *wg_stats; // k_bid_tiled's statistics, {edges, bids} per workgroup (plain stores: 256 workgroups
-    int n_wg_stats;               // ending together on the same two counters cost the scan 1.7 us); k_apply adds up the
-                                  // n_wg_stats slots the round's scan launch may have written and clears them
+    // Statistics of the bid kernels, one 64-byte slot per WORKGROUP (kStat* below), added to with plain loads / stores
+    // by thread 0 of the workgroup -- launches of a stream are ordered, so nobody else touches the slot -- and summed
+    // once, when the solve is finished (k_collect_stats).  Atomics on the control block are not an option: they are
+    // performed one after the other, ~5.5 ns each, and a launch is not over before the last one has retired -- 2048
+    // workgroups x 4-5 counters made a bid launch of a mid round 39 us instead of 12 (C3; 13 ms per solve).
+    unsigned long long *wg_stats;
 };
+constexpr int kStatEdges = 0, kStatBids = 1, kStatHits = 2, kStatHitEdges = 3, kStatShardEdges = 4, kStatLaunchEdges = 5,
+              kStatWords = 8;
 
 __device__ __forceinline__ bool round_live(const Ctl *c, int thr) {
     return c->K > thr && c->K > 0 && c->nits < c->max_iter;
@@ -179,13 +184,14 @@ __global__ __launch_bounds__(kBidBlock) void k_bid(RoundArgs a, E ed) {
             th += s_nh[w];
         }
         if (tb) {
-            atomicAdd(&a.ctl->edges, te);
-            if (a.world > 1 && a.ctl->K >= a.shard_min_K) atomicAdd(&a.ctl->shard_edges, te);
-            atomicAdd(&a.ctl->bids, (unsigned long long)tb);
-            if (a.launch_edges) atomicAdd(&a.launch_edges[a.launch_idx], te);
+            unsigned long long *st = a.wg_stats + (size_t)kStatWords * blockIdx.x;
+            st[kStatEdges] += te;
+            st[kStatBids] += (unsigned long long)tb;
+            if (a.world > 1 && a.ctl->K >= a.shard_min_K) st[kStatShardEdges] += te;
+            if (a.launch_edges) st[kStatLaunchEdges] += te;  // a profiled launch: claimed by k_take_launch_edges
             if (th) {
-                atomicAdd(&a.ctl->cand_hits, (unsigned long long)th);
-                atomicAdd(&a.ctl->cand_edges, the);
+                st[kStatHits] += (unsigned long long)th;
+                st[kStatHitEdges] += the;
             }
         }
     }
@@ -402,28 +408,49 @@ __global__ __launch_bounds__(256) void k_tiebreak(RoundArgs a, const int *order_
 
 // ASSIGN (auction_.pyx:388-427).  All writes of one round are disjoint: winners are distinct unassigned persons,
 // evicted owners are distinct assigned persons, and a winner's slot in U is its own.
-// the scan's statistics (see RoundArgs::wg_stats), by the first wavefront of the apply launch
-__device__ __forceinline__ void collect_wg_stats(const RoundArgs &a, Ctl *ctl) {
-    if (a.n_wg_stats > 0 && blockIdx.x == 0 && threadIdx.x < kWave) {
-        unsigned long long e = 0, b = 0;
-        for (int k = threadIdx.x; k < a.n_wg_stats; k += kWave) {
-            const unsigned long long ek = a.wg_stats[2 * k], bk = a.wg_stats[2 * k + 1];
-            if (ek | bk) {
-                e += ek;
-                b += bk;
-                a.wg_stats[2 * k] = 0ull;
-                a.wg_stats[2 * k + 1] = 0ull;
-            }
-        }
-        for (int off = 32; off >= 1; off >>= 1) {
-            e += ((unsigned long long)__shfl_xor((unsigned)(e >> 32), off) << 32) | (unsigned long long)__shfl_xor((unsigned)(e & 0xffffffffull), off);
-            b += ((unsigned long long)__shfl_xor((unsigned)(b >> 32), off) << 32) | (unsigned long long)__shfl_xor((unsigned)(b & 0xffffffffull), off);
-        }
-        if (threadIdx.x == 0 && (e | b)) {
-            atomicAdd(&ctl->edges, e);
-            atomicAdd(&ctl->bids, b);
+// The workgroups' statistics slots (RoundArgs::wg_stats) -> the control block; one 1024-thread workgroup, once per solve.
+__device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v, unsigned long long *s_w) {
+    for (int off = 32; off >= 1; off >>= 1)
+        v += ((unsigned long long)__shfl_xor((unsigned)(v >> 32), off) << 32) | (unsigned long long)__shfl_xor((unsigned)(v & 0xffffffffull), off);
+    __syncthreads();  // s_w of the previous call is no longer read
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+    __syncthreads();
+    unsigned long long t = 0;
+    for (int w = 0; w < (int)blockDim.x / kWave; ++w) t += s_w[w];
+    return t;
+}
+__global__ __launch_bounds__(1024) void k_collect_stats(Ctl *ctl, unsigned long long *wg_stats, int n_slots) {
+    __shared__ unsigned long long s_w[16];
+    unsigned long long v[5] = {0, 0, 0, 0, 0};
+    for (int k = threadIdx.x; k < n_slots; k += 1024) {
+        unsigned long long *st = wg_stats + (size_t)kStatWords * k;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            v[q] += st[q];
+            st[q] = 0ull;
         }
     }
+    unsigned long long t[5];
+    for (int q = 0; q < 5; ++q) t[q] = block_sum_u64(v[q], s_w);
+    if (threadIdx.x == 0) {
+        ctl->edges += t[kStatEdges];
+        ctl->bids += t[kStatBids];
+        ctl->cand_hits += t[kStatHits];
+        ctl->cand_edges += t[kStatHitEdges];
+        ctl->shard_edges += t[kStatShardEdges];
+    }
+}
+// ... and, behind a PROFILED bid launch, the edges that launch scanned (options.profile)
+__global__ __launch_bounds__(1024) void k_take_launch_edges(unsigned long long *wg_stats, int n_slots, unsigned long long *out) {
+    __shared__ unsigned long long s_w[16];
+    unsigned long long v = 0;
+    for (int k = threadIdx.x; k < n_slots; k += 1024) {
+        unsigned long long *st = wg_stats + (size_t)kStatWords * k;
+        v += st[kStatLaunchEdges];
+        st[kStatLaunchEdges] = 0ull;
+    }
+    const unsigned long long t = block_sum_u64(v, s_w);
+    if (threadIdx.x == 0) *out += t;
 }
 // list position n has won object j: price, eviction, assignment; returns 1 if the slot becomes a hole
 __device__ __forceinline__ int apply_winner_of(const RoundArgs &a, Ctl *ctl, int j, int n) {
@@ -449,15 +476,20 @@ __device__ __forceinline__ int apply_winner_of(const RoundArgs &a, Ctl *ctl, int
     a.U[n] = -1;                             // :412 hole
     return 1;
 }
-__device__ __forceinline__ void count_holes(Ctl *ctl, int holes) {  // one atomic per wavefront
+__device__ __forceinline__ void count_holes(Ctl *ctl, int holes) {  // one atomic per workgroup (256 threads)
+    __shared__ int s_h[4];
     for (int off = 32; off >= 1; off >>= 1) holes += __shfl_xor(holes, off);
-    if ((threadIdx.x & 63) == 0 && holes) atomicAdd(&ctl->nholes, holes);
+    if ((threadIdx.x & 63) == 0) s_h[threadIdx.x >> 6] = holes;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int t = s_h[0] + s_h[1] + s_h[2] + s_h[3];
+        if (t) atomicAdd(&ctl->nholes, t);
+    }
 }
 // One thread per object: instead of the reference's O(M) sequential walk (:394).
 __global__ __launch_bounds__(256) void k_apply(RoundArgs a) {
     Ctl *ctl = a.ctl;
     if (!round_live(ctl, a.thr)) return;
-    collect_wg_stats(a, ctl);
     int holes = 0;
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < a.n_cols; j += gridDim.x * blockDim.x) {
         const int n = a.best_pos[j];
@@ -472,7 +504,6 @@ __global__ __launch_bounds__(256) void k_apply(RoundArgs a) {
 __global__ __launch_bounds__(256) void k_apply_bidders(RoundArgs a) {
     Ctl *ctl = a.ctl;
     if (!round_live(ctl, a.thr)) return;
-    collect_wg_stats(a, ctl);
     const int K = ctl->K;
     int holes = 0;
     for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < K; n += gridDim.x * blockDim.x) {

@@ -1096,11 +1096,12 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
             te += s_e[w];
             tb += s_n[w];
         }
-        if (tb) {  // (no other workgroup touches my slot; k_apply collects, see RoundArgs::wg_stats)
-            a.wg_stats[2 * blockIdx.x] += te;
-            a.wg_stats[2 * blockIdx.x + 1] += (unsigned long long)tb;
-            if (a.world > 1 && a.ctl->K >= a.shard_min_K) atomicAdd(&a.ctl->shard_edges, te);
-            if (a.launch_edges) atomicAdd(&a.launch_edges[a.launch_idx], te);
+        if (tb) {  // (no other workgroup touches my slot, see RoundArgs::wg_stats)
+            unsigned long long *st = a.wg_stats + (size_t)kStatWords * blockIdx.x;
+            st[kStatEdges] += te;
+            st[kStatBids] += (unsigned long long)tb;
+            if (a.world > 1 && a.ctl->K >= a.shard_min_K) st[kStatShardEdges] += te;
+            if (a.launch_edges) st[kStatLaunchEdges] += te;
         }
     }
     MISSLAP_ESTAMP(4);

@@ -206,9 +206,8 @@ struct misslap_solver {
     int ovf_cap = 0;
     double2 *part_vw = nullptr;  // column-split launch shapes: per-(share of the tiles, bidder slot) partial top-2
     int *part_g = nullptr;
-    unsigned long long *wg_stats = nullptr;  // RoundArgs::wg_stats ({edges, bids} per workgroup of a scan launch)
+    unsigned long long *wg_stats = nullptr;  // RoundArgs::wg_stats (statistics of the bid kernels, a slot per workgroup)
     int wg_stats_slots = 0;                  // ... allocated
-    int wg_stats_pending = 0;                // ... that the last scan launch may have written (collected by the next k_apply)
     int *split_cnt = nullptr;    // ... and the arrival counter of every slice 
     int n_tiled = 0;  // entries of `tiled` including the padding entries
     int T = 0;
@@ -444,7 +443,6 @@ RoundArgs round_args(misslap_solver *h) {
     a.eps = h->eps;
     a.launch_idx = 0;
     a.wg_stats = h->wg_stats;
-    a.n_wg_stats = 0;
     a.gather_max_K = h->tiled_ok ? h->tiled_min_K : 0;
     a.cand = h->cand;
     a.cand64 = h->cand64;
@@ -554,7 +552,6 @@ int launch_bid_tiled(misslap_solver *h) {
         pr->fullscan = h->phase_fresh;  // K == N; with several ranks: this rank's share of the full scan
         pr->launch_idx = a.launch_idx = h->launch_idx++;
     }
-    h->wg_stats_pending = std::max(h->wg_stats_pending, (int)grid);
     const size_t lds = tiled_lds_bytes(shp[4]);
     const dim3 g((unsigned)grid);
     switch (h->tiled_shape) {
@@ -564,6 +561,7 @@ int launch_bid_tiled(misslap_solver *h) {
 #undef X
         default: return fail(MISSLAP_ERR_STATE, "bad tiled shape");
     }
+    if (pr) hipLaunchKernelGGL(k_take_launch_edges, dim3(1), dim3(1024), 0, h->stream, h->wg_stats, (int)grid, h->launch_edges + pr->launch_idx);
     HIP_TRY(hipGetLastError());
     return MISSLAP_OK;
 }
@@ -618,6 +616,7 @@ int launch_bid(misslap_solver *h) {
     if (h->f32) MISSLAP_LAUNCH_BID(EdgesF32, e32);  // (rounds that k_round_small finishes: bids with the owners)
     else MISSLAP_LAUNCH_BID(EdgesF64, e64);
 #undef MISSLAP_LAUNCH_BID
+    if (pr) hipLaunchKernelGGL(k_take_launch_edges, dim3(1), dim3(1024), 0, h->stream, h->wg_stats, grid, h->launch_edges + pr->launch_idx);
     HIP_TRY(hipGetLastError());
     h->phase_fresh = false;
     return MISSLAP_OK;
@@ -646,8 +645,6 @@ int launch_apply(misslap_solver *h) {
     }
     h->K_exact = false;
     h->round_ordered = false;
-    a.n_wg_stats = h->wg_stats_pending;
-    h->wg_stats_pending = 0;
     // by the bidders where they are few against the objects (every rank holds every bid only in unsharded rounds)
     if ((h->world == 1 || h->K_ub < h->shard_min_K) && (long long)h->K_ub * h->apply_bidders_ratio <= h->n_cols)
         hipLaunchKernelGGL(k_apply_bidders, dim3(blocks_for(h->K_ub, 256)), dim3(256), 0, h->stream, a);
@@ -1078,8 +1075,8 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
         blk.want(&h->nmatch, N);
         h->fin_slots_n = (int)std::max<size_t>(kMaxGridBlocks, N / 256 + 256);  // >= any grid of the final pass
         blk.want(&h->fin_slots, (size_t)h->fin_slots_n);
-        h->wg_stats_slots = (int)std::min<size_t>(N / 64 + 4096, 1u << 22);
-        blk.want(&h->wg_stats, 2 * (size_t)h->wg_stats_slots);
+        h->wg_stats_slots = (int)std::min<size_t>(N / 64 + 4096, 1u << 22);  // >= kMaxGridBlocks and any scan grid
+        blk.want(&h->wg_stats, (size_t)kStatWords * (size_t)h->wg_stats_slots);
         if (h->tiled_ok && kTiledShapes[h->tiled_shape][7] > 1) {
             blk.want(&h->part_vw, (size_t)kTiledShapes[h->tiled_shape][7] * N);
             blk.want(&h->part_g, (size_t)kTiledShapes[h->tiled_shape][7] * N);
@@ -1094,7 +1091,7 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
     }
     HIP_TRY(hipMemsetAsync(h->price, 0, sizeof(double) * Mpad, h->stream));
     HIP_TRY(hipMemsetAsync(h->bid_rec, 0, sizeof(int4) * kRoundSmallMax, h->stream));
-    HIP_TRY(hipMemsetAsync(h->wg_stats, 0, sizeof(unsigned long long) * 2 * (size_t)h->wg_stats_slots, h->stream));
+    HIP_TRY(hipMemsetAsync(h->wg_stats, 0, sizeof(unsigned long long) * kStatWords * (size_t)h->wg_stats_slots, h->stream));
     if (h->split_cnt) HIP_TRY(hipMemsetAsync(h->split_cnt, 0, sizeof(int) * ((size_t)N / 256 + 1024), h->stream));
     if (h->profile)
         HIP_TRY(hipMemsetAsync(h->launch_edges, 0, sizeof(unsigned long long) * h->launch_edges_cap, h->stream));
@@ -1881,6 +1878,10 @@ MISSLAP_API int misslap_finish(misslap_solver *h, int32_t *person_to_object_out,
     if (person_to_object_out)
         HIP_TRY(hipMemcpyAsync(person_to_object_out, h->p2o, sizeof(int) * (size_t)h->n_rows, hipMemcpyDeviceToHost,
                                h->stream));
+    // the bid kernels' statistics (a slot per workgroup, RoundArgs::wg_stats) -> the control block
+    hipLaunchKernelGGL(k_collect_stats, dim3(1), dim3(1024), 0, h->stream, h->ctl, h->wg_stats, h->wg_stats_slots);
+    HIP_TRY(hipGetLastError());
+    h->ctl_fresh = false;
     if ((rc = read_ctl(h))) return rc;
     const int ece = complete && !h->h_ctl->ece_fail ? 1 : 0;
     if (!meta_out) return MISSLAP_OK;

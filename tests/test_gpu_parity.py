@@ -875,7 +875,7 @@ def test_abi1_caller_is_still_served(gpu_lib):
 
     class MetaV1(C.Structure):
         _fields_ = [f for f in _lib.Meta._fields_[2:] if f[0] not in ("complete_assignment", "valid_assignment",
-                                                                     "lines_active", "reserved_i")]
+                                                                     "lines_active", "reserved_i", "sharded_rounds")]
     assert C.sizeof(OptionsV1) == 88 and C.sizeof(MetaV1) == 376
     loc, val = synth.gen_sparse(1200, 1200, 0.02, seed=3)
     ref = orc.auction_solve(loc=loc, val=val.copy(), problem="max", cardinality_check=False)
