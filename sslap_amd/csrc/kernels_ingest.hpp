@@ -40,9 +40,11 @@ __global__ __launch_bounds__(256) void k_ingest_rows(const int *loc, long long n
         const int m2 = __shfl_xor(mc, off);
         mc = m2 > mc ? m2 : mc;
     }
+    // (an atomic only where it can still change the result: 8192 wavefronts each adding one to the same word are 45 us
+    // during which the launch cannot end -- same-address atomics retire one after the other)
     if ((threadIdx.x & 63) == 0) {
         if (err) atomicOr(&st->err, err);
-        atomicMax(&st->max_col, mc);
+        if (mc > __hip_atomic_load(&st->max_col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&st->max_col, mc);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) row_ptr[n_rows] = (int)nnz;  // :47
 }
@@ -68,8 +70,8 @@ __global__ __launch_bounds__(256) void k_ingest_vals(const double *val, long lon
         err |= __shfl_xor(err, off);
     }
     if ((threadIdx.x & 63) == 0) {
-        atomicMax(&st->max_abs_bits, mx);
-        if (notf) atomicOr(&st->not_f32, 1);
+        if (mx > __hip_atomic_load(&st->max_abs_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&st->max_abs_bits, mx);
+        if (notf && !__hip_atomic_load(&st->not_f32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&st->not_f32, 1);
         if (err) atomicOr(&st->err, err);
     }
 }
@@ -148,7 +150,8 @@ __global__ __launch_bounds__(256) void k_max_row_len(const int *row_ptr, int n_r
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_rows; i += gridDim.x * blockDim.x)
         m = max(m, row_ptr[i + 1] - row_ptr[i]);
     for (int off = 32; off >= 1; off >>= 1) m = max(m, __shfl_xor(m, off));
-    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(&st->max_row_len, m);
+    if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(&st->max_row_len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(&st->max_row_len, m);
 }
 
 // ---- dense ingest (_from_matrix, auction_.pyx:546-557): keep v >= 0 in row-major order -----------------

@@ -394,9 +394,22 @@ __global__ __launch_bounds__(kLongThreads) void k_refresh_long(RoundArgs a, E ed
 
 // order_pos: the bidders of this rank's shard were taken in person order (k_bid_tiled, partial rounds): shard slot
 // -> list position; nullptr = the shard is a range of list positions
-__global__ __launch_bounds__(256) void k_tiebreak(RoundArgs a, const int *order_pos) {
+// take_n / take_out (profiling only): the round's bid launch was a profiled one -- the first wavefront adds up what its
+// take_n workgroups scanned (RoundArgs::wg_stats), like k_take_launch_edges, without a launch of its own
+__global__ __launch_bounds__(256) void k_tiebreak(RoundArgs a, const int *order_pos, int take_n, unsigned long long *take_out) {
     const Ctl *ctl = a.ctl;
     if (!round_live(ctl, a.thr)) return;
+    if (take_n > 0 && blockIdx.x == 0 && threadIdx.x < kWave) {
+        unsigned long long v = 0;
+        for (int k = threadIdx.x; k < take_n; k += kWave) {
+            unsigned long long *st = a.wg_stats + (size_t)kStatWords * k;
+            v += st[kStatLaunchEdges];
+            st[kStatLaunchEdges] = 0ull;
+        }
+        for (int off = 32; off >= 1; off >>= 1)
+            v += ((unsigned long long)__shfl_xor((unsigned)(v >> 32), off) << 32) | (unsigned long long)__shfl_xor((unsigned)(v & 0xffffffffull), off);
+        if (threadIdx.x == 0) *take_out += v;
+    }
     int lo, hi;
     shard_range(ctl->K, a.rank, a.world, a.shard_min_K, lo, hi);
     for (int r = lo + blockIdx.x * blockDim.x + threadIdx.x; r < hi; r += gridDim.x * blockDim.x) {
@@ -627,53 +640,62 @@ __global__ __launch_bounds__(256) void k_compact_fill(RoundArgs a) {
 // launches (count, scatter, fill, round_end) -- most grid rounds have K of a few hundred to a few thousand
 // and are bound by launch boundaries, not by work.  The host uses it while K_ub <= kCompactSmallMax.
 constexpr int kCompactSmallMax = 32768;
-// the body shared by k_compact_small and k_round_small: one 1024-thread workgroup, `nholes` uniform
+// one 1024-thread workgroup, `nholes` uniform.  4096 list positions per pass: the four loads of a thread are in flight
+// together, the per-wavefront counts go through LDS once (double-buffered by pass parity: ONE barrier per pass), and
+// the running list lengths are the same in every thread's registers (a pass used to be 1024 positions behind one
+// exposed memory latency and three barriers: 10 us for the 10 000 - 30 000 positions of a mid round).
 __device__ __forceinline__ void compact_small_body(const RoundArgs &a, Ctl *ctl, int K, int nholes) {
     const int Kn = K - nholes;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    __shared__ int s_wl[16], s_wm[16];
-    __shared__ int s_cl, s_cm;
+    constexpr int kQ = 4;
+    __shared__ int s_w[2][2][kQ][16];  // [pass parity][left holes / movers][quarter][wavefront]
     if (nholes > 0) {
-        if (t == 0) {
-            s_cl = 0;
-            s_cm = 0;
-        }
-        __syncthreads();
-        for (int base = 0; base < K; base += 1024) {
-            const int n = base + t;
-            int u = -1;
-            if (n < K) u = a.U[n];
-            const bool isl = (n < Kn) && (u == -1);
-            const bool ism = (n >= Kn) && (n < K) && (u != -1);
-            const unsigned long long bl = __ballot(isl), bm = __ballot(ism);
-            if (lane == 0) {
-                s_wl[wave] = __popcll(bl);
-                s_wm[wave] = __popcll(bm);
+        int run_l = 0, run_m = 0, par = 0;  // (uniform)
+        for (int base = 0; base < K; base += kQ * 1024, par ^= 1) {
+            int u[kQ];
+            unsigned long long bl[kQ], bm[kQ];
+            bool isl[kQ], ism[kQ];
+#pragma unroll
+            for (int q = 0; q < kQ; ++q) {
+                const int n = base + q * 1024 + t;
+                u[q] = a.U[min(n, K - 1)];  // unconditional (a load inside a branch is waited for at once), masked below
             }
-            __syncthreads();
-            int wl = 0, wm = 0, tl = 0, tm = 0;
-            for (int w2 = 0; w2 < 16; ++w2) {
-                if (w2 < wave) {
-                    wl += s_wl[w2];
-                    wm += s_wm[w2];
+#pragma unroll
+            for (int q = 0; q < kQ; ++q) {
+                const int n = base + q * 1024 + t;
+                isl[q] = (n < Kn) & (u[q] == -1);
+                ism[q] = (n >= Kn) & (n < K) & (u[q] != -1);
+                bl[q] = __ballot(isl[q]);
+                bm[q] = __ballot(ism[q]);
+                if (lane == 0) {
+                    s_w[par][0][q][wave] = __popcll(bl[q]);
+                    s_w[par][1][q][wave] = __popcll(bm[q]);
                 }
-                tl += s_wl[w2];
-                tm += s_wm[w2];
-            }
-            const int cl = s_cl, cm = s_cm;
-            if (isl) a.hole_list[cl + wl + __popcll(bl & lanemask_lt())] = n;
-            if (ism) {
-                a.mover_list[cm + wm + __popcll(bm & lanemask_lt())] = u;
-                a.U[n] = -1;  // data[right_track] = -1   (:159)
             }
             __syncthreads();
-            if (t == 0) {
-                s_cl = cl + tl;
-                s_cm = cm + tm;
+#pragma unroll
+            for (int q = 0; q < kQ; ++q) {
+                const int n = base + q * 1024 + t;
+                int wl = 0, wm = 0, tl = 0, tm = 0;
+#pragma unroll
+                for (int w2 = 0; w2 < 16; ++w2) {
+                    const int x = s_w[par][0][q][w2], y = s_w[par][1][q][w2];
+                    wl += w2 < wave ? x : 0;
+                    wm += w2 < wave ? y : 0;
+                    tl += x;
+                    tm += y;
+                }
+                if (isl[q]) a.hole_list[run_l + wl + __popcll(bl[q] & lanemask_lt())] = n;
+                if (ism[q]) {
+                    a.mover_list[run_m + wm + __popcll(bm[q] & lanemask_lt())] = u[q];
+                    a.U[n] = -1;  // data[right_track] = -1   (:159)
+                }
+                run_l += tl;
+                run_m += tm;
             }
-            __syncthreads();
         }
-        const int nl = s_cl;  // left holes == movers
+        __syncthreads();  // the lists are complete (written by other threads of this workgroup)
+        const int nl = run_l;  // left holes == movers
         for (int k = t; k < nl; k += 1024) a.U[a.hole_list[k]] = a.mover_list[k];  // data[left_track] = i   (:158)
     }
     if (t == 0) {

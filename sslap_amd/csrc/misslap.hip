@@ -208,6 +208,8 @@ struct misslap_solver {
     int *part_g = nullptr;
     unsigned long long *wg_stats = nullptr;  // RoundArgs::wg_stats (statistics of the bid kernels, a slot per workgroup)
     int wg_stats_slots = 0;                  // ... allocated
+    int take_edges_n = 0;                    // a profiled bid launch whose edge count the round's k_tiebreak still has to
+    unsigned long long *take_edges_out = nullptr;  // add up: its grid and where the count goes
     int *split_cnt = nullptr;    // ... and the arrival counter of every slice 
     int n_tiled = 0;  // entries of `tiled` including the padding entries
     int T = 0;
@@ -228,6 +230,12 @@ struct misslap_solver {
     int cand_build_max_K = 0x7fffffff;
     int tail_round_budget = kLongRowTailBudget;
     int max_row_len = 0;
+    long long avg_row_len = 0;
+    // Lines in USE: the handle has them and its rows can keep one -- rows of at most kCandRowMax edges, or longer ones
+    // once the long-row builder runs (k_refresh_long).  Otherwise (C4: 300 edges per row) every line is empty for the
+    // whole solve, and loading + evaluating it in front of every bid, and the maintenance pass over all of them, are
+    // pure overhead: the kernels then run as for a handle without lines.
+    bool lines_live() const { return cand != nullptr && (avg_row_len <= kCandRowMax || long_rows); }
     bool long_rows_later = false;  // rows of a few hundred edges: k_refresh_long only if the tail turns out long
     bool long_rows = false;  // some row is longer than kCandRowMax: k_refresh_long has work
     bool line_maintenance = true;  // k_refresh_lines ahead of the tail kernels (options.reserved[4] = 2: off)
@@ -362,9 +370,11 @@ struct BlockCache {
     std::vector<Ent> idle;
     size_t held = 0;
     // limits (misslap_set_cache_limits; MISSLAP_BLOCK_CACHE_MB in the environment sets the first two at start-up).  The
-    // defaults keep what a stream of SMALL problems needs; an application that solves many large problems at a time
-    // raises them: hipFree waits for every stream of the device, i.e. for the other solves' running kernels
-    size_t kMaxHeld = (size_t)256 << 20, kMaxEach = (size_t)32 << 20, kMaxEntries = 16;
+    // defaults -- 4 GB of a 288 GB device, blocks of up to 1 GB -- hold the blocks of one or two problems of the
+    // BASELINE sizes (C3: 0.9 GB per handle): hipMalloc + hipFree of those cost a millisecond per create / destroy pair
+    // (C4: setup 4.0 -> 3.0 ms), and hipFree waits for every stream of the device, i.e. for other solves' kernels.  An
+    // application that solves many large problems at a time raises them further
+    size_t kMaxHeld = (size_t)4 << 30, kMaxEach = (size_t)1 << 30, kMaxEntries = 64;
     BlockCache() {
         if (const char *e = std::getenv("MISSLAP_BLOCK_CACHE_MB")) {
             const long long mb = std::atoll(e);
@@ -444,8 +454,8 @@ RoundArgs round_args(misslap_solver *h) {
     a.launch_idx = 0;
     a.wg_stats = h->wg_stats;
     a.gather_max_K = h->tiled_ok ? h->tiled_min_K : 0;
-    a.cand = h->cand;
-    a.cand64 = h->cand64;
+    a.cand = h->lines_live() ? h->cand : nullptr;
+    a.cand64 = h->lines_live() ? h->cand64 : nullptr;
     a.cand_build_max_K = h->cand_build_max_K;
     a.cand_refresh_min = h->cand_refresh_min;
     return a;
@@ -561,7 +571,10 @@ int launch_bid_tiled(misslap_solver *h) {
 #undef X
         default: return fail(MISSLAP_ERR_STATE, "bad tiled shape");
     }
-    if (pr) hipLaunchKernelGGL(k_take_launch_edges, dim3(1), dim3(1024), 0, h->stream, h->wg_stats, (int)grid, h->launch_edges + pr->launch_idx);
+    if (pr) {  // (the round's k_tiebreak adds the workgroups' counts up: no launch of its own inside a timed solve)
+        h->take_edges_n = (int)grid;
+        h->take_edges_out = h->launch_edges + pr->launch_idx;
+    }
     HIP_TRY(hipGetLastError());
     return MISSLAP_OK;
 }
@@ -605,7 +618,7 @@ int launch_bid(misslap_solver *h) {
     const EdgesF64 e64{h->col, h->val64};
     const dim3 g(grid), b(kBidBlock);
     // variant: 2 = lines used and rebuilt; 1 = lines used, lean scan, nothing built (the full-scan regime); 0 = no lines
-    const int variant = !h->cand ? 0 : h->K_ub > h->cand_build_max_K ? 1 : 2;
+    const int variant = !h->lines_live() ? 0 : h->K_ub > h->cand_build_max_K ? 1 : 2;
 #define MISSLAP_LAUNCH_BID(E, ED)                                                                                   \
     do {                                                                                                            \
         if (h->round_small) MISSLAP_LAUNCH_TIMED(pr, (k_bid<E, RecSource, 2>), g, b, 0, h->stream, a, ED);          \
@@ -616,7 +629,12 @@ int launch_bid(misslap_solver *h) {
     if (h->f32) MISSLAP_LAUNCH_BID(EdgesF32, e32);  // (rounds that k_round_small finishes: bids with the owners)
     else MISSLAP_LAUNCH_BID(EdgesF64, e64);
 #undef MISSLAP_LAUNCH_BID
-    if (pr) hipLaunchKernelGGL(k_take_launch_edges, dim3(1), dim3(1024), 0, h->stream, h->wg_stats, grid, h->launch_edges + pr->launch_idx);
+    if (pr && !h->round_small) {
+        h->take_edges_n = std::max(h->take_edges_n, grid);  // (a full-scan engine launch of the same round may be pending too)
+        h->take_edges_out = h->launch_edges + pr->launch_idx;
+    } else if (pr) {  // (no k_tiebreak in a round that k_round_small finishes; such launches are profiled at level 2 / 3 only)
+        hipLaunchKernelGGL(k_take_launch_edges, dim3(1), dim3(1024), 0, h->stream, h->wg_stats, grid, h->launch_edges + pr->launch_idx);
+    }
     HIP_TRY(hipGetLastError());
     h->phase_fresh = false;
     return MISSLAP_OK;
@@ -628,7 +646,9 @@ int launch_tiebreak(misslap_solver *h) {
     RoundArgs a = round_args(h);
     const long long share = h->K_ub;
     hipLaunchKernelGGL(k_tiebreak, dim3(blocks_for(share, 256)), dim3(256), 0, h->stream, a,
-                       h->round_ordered ? h->mover_list : nullptr);
+                       h->round_ordered ? h->mover_list : nullptr, h->take_edges_n, h->take_edges_out);
+    h->take_edges_n = 0;
+    h->take_edges_out = nullptr;
     HIP_TRY(hipGetLastError());
     return MISSLAP_OK;
 }
@@ -678,9 +698,10 @@ int launch_tail(misslap_solver *h) {
     a.p2o = h->p2o;
     a.o2p = h->o2p;
     a.U = h->U;
-    a.cand = h->cand;
-    a.cand64 = h->cand64;
-    a.round_budget = h->long_rows && h->cand && h->line_maintenance ? h->tail_round_budget : 0;
+    const bool lines = h->lines_live();
+    a.cand = lines ? h->cand : nullptr;
+    a.cand64 = lines ? h->cand64 : nullptr;
+    a.round_budget = h->long_rows && lines && h->line_maintenance ? h->tail_round_budget : 0;
     a.thr = h->thr;
     a.eps = h->eps;
     ProfRec *pr = nullptr;
@@ -697,10 +718,10 @@ int launch_tail(misslap_solver *h) {
     // instance that holds every mode
 #define MISSLAP_LAUNCH_TAIL(E, ED)                                                                                       \
     do {                                                                                                                 \
-        if (h->cand && h->line_maintenance)                                                                              \
+        if (lines && h->line_maintenance)                                                                                \
             hipLaunchKernelGGL(k_refresh_lines<E>, dim3(blocks_for((h->n_rows + 1) / 2, kBidBlock / kWave)),             \
                                dim3(kBidBlock), 0, h->stream, round_args(h), ED, kCandMaintenanceMin);                   \
-        if (h->cand && h->line_maintenance && h->long_rows) {                                                            \
+        if (lines && h->line_maintenance && h->long_rows) {                                                              \
             if (h->max_row_len <= 256 * kLongPer)                                                                        \
                 hipLaunchKernelGGL((k_refresh_long<E, 256>), dim3(blocks_for(h->n_rows, 1)), dim3(256), 0, h->stream,    \
                                    round_args(h), ED, kCandMaintenanceMin);                                              \
@@ -710,9 +731,9 @@ int launch_tail(misslap_solver *h) {
         }                                                                                                                \
         if (h->K_ub > kTeamMax)                                                                                          \
             hipLaunchKernelGGL((k_tail<E, 2 * kTailMax>), dim3(1), dim3(2 * kTailMax), 0, h->stream, a, ED);             \
-        if (h->K_ub > 2 && h->cand)                                                                                      \
+        if (h->K_ub > 2 && lines)                                                                                        \
             hipLaunchKernelGGL((k_tail<E, 2 * kTailMax, true>), dim3(1), dim3(2 * kTailMax), 0, h->stream, a, ED);       \
-        if (h->cand) hipLaunchKernelGGL((k_tail<E, 2 * kWave>), dim3(1), dim3(2 * kWave), 0, h->stream, a, ED);          \
+        if (lines) hipLaunchKernelGGL((k_tail<E, 2 * kWave>), dim3(1), dim3(2 * kWave), 0, h->stream, a, ED);            \
         else hipLaunchKernelGGL((k_tail<E, kTailMax>), dim3(1), dim3(kTailMax), 0, h->stream, a, ED);                    \
     } while (0)
     if (h->f32) MISSLAP_LAUNCH_TAIL(EdgesF32, e32);
@@ -887,6 +908,7 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
     // hundred edges per row the pass costs more than the scans it saves (C4, 300 edges per row, 176 rounds: 13.4 ->
     // 18.3 ms), so it runs from kLongRowsFrom edges per row on average.
     const long long avg_row = nnz / h->n_rows;
+    h->avg_row_len = avg_row;
     h->max_row_len = st.max_row_len;
     h->long_rows = st.max_row_len > kCandRowMax && avg_row >= kLongRowsFrom && avg_row <= kCandLongMax;
     // ... below that (C4's 300 edges per row, a dense 600^2) only once the solve has shown that its tail is long:
