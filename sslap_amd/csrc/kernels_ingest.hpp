@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void k_init_state(Ctl *ctl, double *price, Pri
         ctl->shard_edges = 0;
         ctl->obj_abs = 0.0;
         ctl->obj_minexp = 1 << 20;
-        ctl->pad1 = 0;
+        ctl->n_need = 0;
         ctl->obj = 0.0;
         for (int k = 0; k < 16; ++k) ctl->dbg[k] = 0;
     }

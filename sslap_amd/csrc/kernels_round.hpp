@@ -48,6 +48,8 @@ struct RoundArgs {
     // performed one after the other, ~5.5 ns each, and a launch is not over before the last one has retired -- 2048
     // workgroups x 4-5 counters made a bid launch of a mid round 39 us instead of 12 (C3; 13 ms per solve).
     unsigned long long *wg_stats;
+    int *need_list;               // [n_rows] persons with LONG rows whose line k_refresh_lines found spent (Ctl::n_need of
+                                  // them): the work list of k_refresh_long
 };
 constexpr int kStatEdges = 0, kStatBids = 1, kStatHits = 2, kStatHitEdges = 3, kStatShardEdges = 4, kStatLaunchEdges = 5,
               kStatWords = 8;
@@ -204,8 +206,10 @@ __global__ __launch_bounds__(kBidBlock) void k_bid(RoundArgs a, E ed) {
 // every person's line is evaluated once at the current prices (two persons per wavefront), and a line that would not
 // answer, or has fewer than `min_alive` live candidates left, is rebuilt from a full scan -- here, where a scan is
 // one of thousands in flight.  Nothing is bid: lines only decide which edges a later bid looks at.
+// long_max > 0: the long-row builder runs behind this pass and takes rows of up to so many edges; their lines are
+// rebuilt below min_alive_long live candidates.
 template <class E>
-__global__ __launch_bounds__(kBidBlock) void k_refresh_lines(RoundArgs a, E ed, int min_alive) {
+__global__ __launch_bounds__(kBidBlock) void k_refresh_lines(RoundArgs a, E ed, int min_alive, int long_max, int min_alive_long) {
     if (!E::kCand || a.cand == nullptr) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wpb = kBidBlock / kWave;
@@ -225,10 +229,15 @@ __global__ __launch_bounds__(kBidBlock) void k_refresh_lines(RoundArgs a, E ed, 
 #pragma unroll
         for (int X = 0; X < 2; ++X) {
             if (X == 1 && !act1) continue;  // wave-uniform
-            if (b[X].hit && alive[X] >= min_alive) continue;
+            if (b[X].hit && alive[X] >= max(min_alive, min_alive_long)) continue;
             const int i = X ? i1 : i0;
             const int s = a.row_ptr[i], e = a.row_ptr[i + 1];
-            if (e - s > kCandRowMax) continue;  // (wave-uniform) rows too long for a line are never cached
+            if (e - s > kCandRowMax) {  // (wave-uniform) too long for a rebuild here: k_refresh_long's, if it can hold the row
+                if (long_max > 0 && e - s <= long_max && !(b[X].hit && alive[X] >= min_alive_long) && lane == 0)
+                    a.need_list[atomicAdd(&a.ctl->n_need, 1)] = i;
+                continue;
+            }
+            if (b[X].hit && alive[X] >= min_alive) continue;
             CandBid full;
             CandBuildArgs ba;
             const typename E::Raw none[4] = {};
@@ -250,32 +259,23 @@ constexpr int kLongPer = 32;                   // values per thread
 constexpr int kCandLongMax = 512 * kLongPer;  // 16384: the longest row that keeps a line (512-thread instance; 1024
                                               // threads leave 128 registers per thread, which spills the row's values)
 template <class E, int kLongThreads>          // 256 threads: rows <= 8192 edges; 512 threads: rows <= 16384
-__global__ __launch_bounds__(kLongThreads) void k_refresh_long(RoundArgs a, E ed, int min_alive) {
+__global__ __launch_bounds__(kLongThreads) void k_refresh_long(RoundArgs a, E ed) {
     if (!E::kCand || a.cand == nullptr) return;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    __shared__ int s_need, s_cnt[2], s_n, s_g[kCandMax + 2], s_col[kCandMax + 2];
+    __shared__ int s_cnt[2], s_n, s_g[kCandMax + 2], s_col[kCandMax + 2];
     __shared__ double s_cost[kCandMax + 2], s_red[2][kLongThreads / kWave];
-    const double eps = (double)a.eps;
     const double ninf = -__builtin_huge_val();
     const PriceSource src{a.price};
-    for (int i = blockIdx.x; i < a.n_rows; i += gridDim.x) {
+    // (the persons come from k_refresh_lines, which has evaluated every line at today's prices two per wavefront: a
+    // workgroup per person re-doing that evaluation for ALL persons was 179 us per pass at dense 8000 x 8000, where a
+    // pass finds a few hundred spent lines)
+    const int n_need = a.ctl->n_need;
+    for (int idx = blockIdx.x; idx < n_need; idx += gridDim.x) {
+        const int i = a.need_list[idx];
         const int s = a.row_ptr[i], e = a.row_ptr[i + 1], len = e - s;
-        if (len <= kCandRowMax || len > kLongThreads * kLongPer) continue;  // uniform over the workgroup
-        // does the line still answer, with enough life left?  (wavefront 0, like k_refresh_lines)
-        if (wave == 0) {
-            typename E::Slot sl = LineIO<typename E::Slot>::load(a.cand, a.cand64,
-                                                                 (size_t)i * kCandLanes + (lane & (kCandLanes - 1)));
-            CandBid b[2];
-            int alive[2], err = 0;
-            cand_eval2(sl, true, false, src, eps, b, err, NoEarly(), NoStamp(), alive);
-            if (lane == 0) s_need = !(b[0].hit && alive[0] >= min_alive);
-        }
+        if (len <= kCandRowMax || len > kLongThreads * kLongPer) continue;  // uniform over the workgroup (never: the list's rule)
         if (t == 0) s_n = 0;
         __syncthreads();
-        if (!s_need) {
-            __syncthreads();
-            continue;
-        }
         // the row's values, in registers
         double v[kLongPer];
         double m1 = ninf, m2 = ninf;  // my best two (multiplicity counted)

@@ -75,8 +75,9 @@ __device__ __forceinline__ int apply_winner(const TailArgs &a, int person, int p
 }
 
 // After the tail kernel: price[j], o2p[j] from the records; p2o rebuilt as the inverse of o2p.
-__global__ __launch_bounds__(256) void k_sync_clear_p2o(int *p2o, int n_rows) {
+__global__ __launch_bounds__(256) void k_sync_clear_p2o(Ctl *ctl, int *p2o, int n_rows) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_rows; i += gridDim.x * blockDim.x) p2o[i] = -1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->n_need = 0;  // the maintenance pass's work list has been consumed
 }
 __global__ __launch_bounds__(256) void k_sync_from_rec(Ctl *ctl, const PriceRec *rec, double *price, int *o2p, int *p2o,
                                                        int n_cols, int lines) {

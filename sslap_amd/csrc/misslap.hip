@@ -83,7 +83,13 @@ constexpr long long kLongRowsAfterTailRounds = 1500;
 // row in place: a missed line stays missed until the next pass, and every miss is a scan of the whole row).  Dense
 // 8000^2: no limit 341 ms, 4096: 324, 1024: 220, 256: 121, 128: 120, 64: 144, 32: 200; with a quarter of the budget for
 // the block instance (most bidders per round, i.e. most lines spent) 512: 123, 256: 101, 128: 108.
-constexpr int kLongRowTailBudget = 256;  // average row length from which the long-row line builder runs
+constexpr int kLongRowTailBudget = 192;
+// ... and what a pass rebuilds: after a few hundred rounds of a dense problem nearly EVERY line has lost some of its
+// thirty candidates (everybody's candidates are the same popular objects), so a pass at the strict threshold of the
+// short rows (24 live candidates) re-reads the whole matrix -- 512 MB per pass at dense 8000^2, 141 us.  Long rows are
+// rebuilt below 12 live candidates.  Dense 8000^2, threshold x rounds between passes: 24 x 256: 115 ms, 12 x 256: 102,
+// 12 x 192: 88.6, 12 x 128: 89.9, 10 x 192: 88.5, 14 x 192: 91.2, 16 x 128: 93.6, 12 x 384: 114, 4 x 256: 125.
+constexpr int kLongRowMinAlive = 12;
 // Where a line is rebuilt matters more than whether it hits: lines are built in the grid rounds but earn their keep in
 // the tail kernels, tens of thousands of rounds later, and a line that still hits but is nearly spent would miss THERE,
 // where a row scan is the whole round and not one of hundreds in flight.  Two mechanisms, both on the number of
@@ -190,6 +196,7 @@ struct misslap_solver {
     unsigned long long *best_key = nullptr;
     int *best_pos = nullptr;
     int *cnt = nullptr, *hole_list = nullptr, *mover_list = nullptr;
+    int *need_list = nullptr;  // RoundArgs::need_list
     Ctl *ctl = nullptr;
     double *contrib = nullptr;
     int *nmatch = nullptr;
@@ -453,6 +460,7 @@ RoundArgs round_args(misslap_solver *h) {
     a.eps = h->eps;
     a.launch_idx = 0;
     a.wg_stats = h->wg_stats;
+    a.need_list = h->need_list;
     a.gather_max_K = h->tiled_ok ? h->tiled_min_K : 0;
     a.cand = h->lines_live() ? h->cand : nullptr;
     a.cand64 = h->lines_live() ? h->cand64 : nullptr;
@@ -701,7 +709,11 @@ int launch_tail(misslap_solver *h) {
     const bool lines = h->lines_live();
     a.cand = lines ? h->cand : nullptr;
     a.cand64 = lines ? h->cand64 : nullptr;
-    a.round_budget = h->long_rows && lines && h->line_maintenance ? h->tail_round_budget : 0;
+    static const int budget_env = [] {
+        const char *e = std::getenv("MISSLAP_LONG_TAIL_BUDGET");
+        return e ? std::atoi(e) : 0;
+    }();
+    a.round_budget = h->long_rows && lines && h->line_maintenance ? (budget_env > 0 ? budget_env : h->tail_round_budget) : 0;
     a.thr = h->thr;
     a.eps = h->eps;
     ProfRec *pr = nullptr;
@@ -712,6 +724,12 @@ int launch_tail(misslap_solver *h) {
     }
     const EdgesF32 e32{h->edges32};
     const EdgesF64 e64{h->col, h->val64};
+    // rows the long-row builder takes (it runs right behind the pass over all lines, on the list that pass leaves)
+    const int long_max = !(lines && h->line_maintenance && h->long_rows) ? 0 : (h->max_row_len <= 256 * kLongPer ? 256 : 512) * kLongPer;
+    static const int min_alive_long = [] {
+        const char *e = std::getenv("MISSLAP_LONG_MIN_ALIVE");
+        return e ? std::atoi(e) : kLongRowMinAlive;
+    }();
     // every line checked at today's prices (kernels_round.hpp); then the rounds with more than kTeamMax bidders, with
     // sixteen wavefronts (kernels_tail.hpp); then -- lines only -- the rounds with 3..kTeamMax bidders, one list slot
     // per wavefront; then the rest: with lines the two-wavefront duo / chain instance, without them the 512-thread
@@ -720,14 +738,14 @@ int launch_tail(misslap_solver *h) {
     do {                                                                                                                 \
         if (lines && h->line_maintenance)                                                                                \
             hipLaunchKernelGGL(k_refresh_lines<E>, dim3(blocks_for((h->n_rows + 1) / 2, kBidBlock / kWave)),             \
-                               dim3(kBidBlock), 0, h->stream, round_args(h), ED, kCandMaintenanceMin);                   \
+                               dim3(kBidBlock), 0, h->stream, round_args(h), ED, kCandMaintenanceMin, long_max, min_alive_long); \
         if (lines && h->line_maintenance && h->long_rows) {                                                              \
             if (h->max_row_len <= 256 * kLongPer)                                                                        \
                 hipLaunchKernelGGL((k_refresh_long<E, 256>), dim3(blocks_for(h->n_rows, 1)), dim3(256), 0, h->stream,    \
-                                   round_args(h), ED, kCandMaintenanceMin);                                              \
+                                   round_args(h), ED);                                                                   \
             else                                                                                                         \
                 hipLaunchKernelGGL((k_refresh_long<E, 512>), dim3(blocks_for(h->n_rows, 1)), dim3(512), 0, h->stream,    \
-                                   round_args(h), ED, kCandMaintenanceMin);                                              \
+                                   round_args(h), ED);                                                                   \
         }                                                                                                                \
         if (h->K_ub > kTeamMax)                                                                                          \
             hipLaunchKernelGGL((k_tail<E, 2 * kTailMax>), dim3(1), dim3(2 * kTailMax), 0, h->stream, a, ED);             \
@@ -741,7 +759,7 @@ int launch_tail(misslap_solver *h) {
 #undef MISSLAP_LAUNCH_TAIL
     if (pr) HIP_TRY(hipEventRecord(pr->stop, h->stream));
     // the tail keeps only the price records current: rebuild price / o2p / p2o from them
-    hipLaunchKernelGGL(k_sync_clear_p2o, dim3(blocks_for(h->n_rows, 256)), dim3(256), 0, h->stream, h->p2o, h->n_rows);
+    hipLaunchKernelGGL(k_sync_clear_p2o, dim3(blocks_for(h->n_rows, 256)), dim3(256), 0, h->stream, h->ctl, h->p2o, h->n_rows);
     hipLaunchKernelGGL(k_sync_from_rec, dim3(blocks_for(h->n_cols, 256)), dim3(256), 0, h->stream, h->ctl, h->rec, h->price,
                        h->o2p, h->p2o, h->n_cols, h->cand != nullptr ? 1 : 0);
     HIP_TRY(hipGetLastError());
@@ -1092,6 +1110,7 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
         blk.want(&h->cnt, 2 * ((N + kChunk - 1) / kChunk) + 2);
         blk.want(&h->hole_list, N);
         blk.want(&h->mover_list, N);
+        blk.want(&h->need_list, N);
         blk.want(&h->ctl, 1);
         blk.want(&h->contrib, N);
         blk.want(&h->nmatch, N);
