@@ -36,6 +36,10 @@ constexpr int kTileColsBig = 157 * 128;   // 20096 -> 160768 B, one workgroup pe
 constexpr int kTileColsHalf = 79 * 128;   // 10112 ->  80896 B, two workgroups per CU: one computes while the
                                           //                     other waits for its tile fill
 constexpr int kTileRB = 128;      // persons per layout block
+// LDS behind the price buffers: statistics scratch of the epilogue (16 x 12 + 16 bytes), then 64 bytes per loader
+// wavefront for the L2 touches (see the loader wavefronts of k_bid_tiled)
+constexpr int kTileStatBytes = 16 * 12 + 16;
+constexpr int kTileTouchBytes = 64 * 4;
 // Launch shapes (template parameters of k_bid_tiled): THREADS per workgroup (one workgroup per CU: the
 // price tile takes 128 of the 160 KB of LDS), ROWS persons per 8-lane group (register-resident running
 // top-2 per lane), BATCH persons whose segment loads are in flight together.
@@ -557,34 +561,28 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
         constexpr int kTileLines = kTileCols * 8 / 128;
         const int nx = max(1, (int)gridDim.x / 8), xr = ((int)blockIdx.x / 8) % nx;
         const int lines_per_wg = (kTileLines + nx - 1) / nx, lines_per_wave = (lines_per_wg + kLoaders - 1) / (kLoaders > 0 ? kLoaders : 1);
-        int touch_prev = 0;
         // (always ONE load per call, all lanes active, addresses clamped into the table: the vmcnt(1) below relies on
-        // exactly one load behind the pieces of a fill)
+        // exactly one load behind the pieces of a fill.  The touch is an LDS-DMA of one byte per lane into 64 bytes of
+        // scratch behind the statistics words: a load WITHOUT a register destination -- an asynchronous inline-asm load
+        // into a VGPR would land whenever it lands, in a register the compiler may have re-used by then)
+        char *touch_dst = reinterpret_cast<char *>(s_price + (kDouble ? kBufDoubles + kTileCols : kTileCols + 2)) + kTileStatBytes + 64 * me;
         auto touch = [&](int tile) {
-            int r = 0;
             const int line = min(xr * lines_per_wg + me * lines_per_wave + min(lane, lines_per_wave - 1), kTileLines - 1);
             const char *src = reinterpret_cast<const char *>(a.price + (size_t)min(tile, T - 1) * kTileCols) + (size_t)line * 128;
-            asm volatile("global_load_dword %0, %1, off" : "=v"(r) : "v"(src) : "memory");
-            return r;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)touch_dst, 1, 0, 0);
         };
         if (t_lo < t_hi) dma_fill(t_lo, me, kLoaders);
-        if (MISSLAP_TILED_TOUCH > 0) touch_prev = touch(t_lo + 1);
+        if (MISSLAP_TILED_TOUCH > 0) touch(t_lo + 1);
         for (int tile = t_lo; tile < t_hi; ++tile) {
             // my pieces of tile `tile` have landed (a touch issued behind them may still be in flight)
             if (MISSLAP_TILED_TOUCH > 0) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (ABL != 4) __syncthreads();                    // ... and tile - 1 is no longer read
             if (tile + 1 < t_hi) dma_fill(tile + 1, me, kLoaders);
-            if (MISSLAP_TILED_TOUCH > 0) {
-                // the previous touch is older than the pieces just waited for: it has landed, its register is free
-                asm volatile("" ::"v"(touch_prev));
-                touch_prev = touch(tile + 1 + MISSLAP_TILED_TOUCH);
-            }
+            if (MISSLAP_TILED_TOUCH > 0) touch(tile + 1 + MISSLAP_TILED_TOUCH);
         }
-        if (MISSLAP_TILED_TOUCH > 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            asm volatile("" ::"v"(touch_prev));
-        }
+        if (MISSLAP_TILED_TOUCH > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     // Software pipeline over steps = (tile, batch of kTileBatch persons): while step s is consumed, the edges
     // of step s+1 and the segment pointers of step s+2 are in flight; they do not depend on LDS.

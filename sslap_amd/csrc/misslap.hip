@@ -126,7 +126,7 @@ const int kTiledShapes[kNumTiledShapes][8] = {
     X(8, 1024, 4, 2, 2, kTileColsHalf, 3, 8, 1) X(9, 1024, 4, 2, 2, kTileColsHalf, 3, 16, 1)
 inline size_t tiled_lds_bytes(int tile_cols) {  // see the LDS map in k_bid_tiled; + statistics scratch
     const size_t doubles = tile_cols == kTileColsBig ? (size_t)tile_cols + 2 : 2 * (size_t)tile_cols + 128;
-    return doubles * sizeof(double) + 16 * 12 + 16;  // + statistics scratch + the arrival word of a column-split shape
+    return doubles * sizeof(double) + kTileStatBytes + kTileTouchBytes;  // + statistics scratch (incl. the arrival word of a column-split shape) + the loaders' touch scratch
 }
 
 // Profiled launches (options.profile): the two events are handed to the launch itself (hipExtLaunchKernel), so they
