@@ -352,14 +352,16 @@ def main():
         # this same command, summarised by tools/pmc_summary.py with the gfx950 corrections).  The file names the
         # kernel sources (sha256) and the commit it was measured on: any other code gets null, not a stale number.
         traffic, traffic_meta = None, {}
-        tpath = os.path.join(ROOT, "profiles", f"r03_pmc_traffic_{args.config}.json")
-        if not os.path.exists(tpath):
-            tpath = os.path.join(ROOT, "profiles", f"r02_pmc_traffic_{args.config}.json")
+        import glob
+        tpaths = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_pmc_traffic_{args.config}.json")))
+        tpath = tpaths[-1] if tpaths else ""  # the newest round's measurement
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             traffic_meta = dict(traffic_commit=tj.get("commit"), traffic_source_sha256=tj.get("source_sha256"),
                                 traffic_file=os.path.relpath(tpath, ROOT))
-            tk = [(k, v) for k, v in tj["kernels"].items() if rk_name in k and "merge" not in k]
+            # (the bid instance of the full-scan engine: its last template argument is MODE = 0; MODE 1 is the eCE pass)
+            tk = [(k, v) for k, v in sorted(tj["kernels"].items())
+                  if (rk_name + "<") in k and not (rk_name == "k_bid_tiled" and not k.rstrip().endswith(", 0>"))]
             if tk and tj.get("source_sha256") == source_digest():
                 traffic = round(tk[0][1]["read_avg"] + tk[0][1]["write_avg"])
                 traffic_meta["traffic_kernel"] = tk[0][0]
