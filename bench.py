@@ -487,6 +487,10 @@ def main():
                 "traffic_source": "rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction calibrated on known-size "
                                   "kernels + WRITE_SIZE), bytes per launch" if traffic else None,
                 **traffic_meta,
+                # (gather engine only -- configs without the tile-major copy: its launches answer part of their bids from
+                # candidate lines, whose rows are counted like the reference counts them but never read; a dense matrix
+                # can so exceed the peak on paper.  The full-scan engine k_bid_tiled reads every edge it counts.)
+                "counts_rows_answered_from_lines": (not tiled) and gpu.get("lines_active", 0) == 1,
             },
             "device": name.value.decode(), "compute_units": int(cus.value),
             # N > 1: proof that N ranks took part and agree -- what the transport itself reports (ncclCommCount), every
