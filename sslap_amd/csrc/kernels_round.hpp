@@ -396,9 +396,12 @@ __global__ __launch_bounds__(kLongThreads) void k_refresh_long(RoundArgs a, E ed
 // -> list position; nullptr = the shard is a range of list positions
 // take_n / take_out (profiling only): the round's bid launch was a profiled one -- the first wavefront adds up what its
 // take_n workgroups scanned (RoundArgs::wg_stats), like k_take_launch_edges, without a launch of its own
-__global__ __launch_bounds__(256) void k_tiebreak(RoundArgs a, const int *order_pos, int take_n, unsigned long long *take_out) {
+// order_min_K: the person-ordered scan (and the kernels that prepare order_pos) ran only if K >= order_min_K -- a round
+// enqueued on a stale upper bound of K may have been bid by k_bid instead, in list order
+__global__ __launch_bounds__(256) void k_tiebreak(RoundArgs a, const int *order_pos, int order_min_K, int take_n, unsigned long long *take_out) {
     const Ctl *ctl = a.ctl;
     if (!round_live(ctl, a.thr)) return;
+    if (ctl->K < order_min_K) order_pos = nullptr;
     if (take_n > 0 && blockIdx.x == 0 && threadIdx.x < kWave) {
         unsigned long long v = 0;
         for (int k = threadIdx.x; k < take_n; k += kWave) {

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(1024) void k_scan_sums(const int *in, long long n, 
         sums[blockIdx.x] = t;
     }
 }
-__global__ __launch_bounds__(1024) void k_scan_of_sums(int *sums, int nblocks) {  // in place, exclusive
+__device__ __forceinline__ void scan_of_sums_body(int *sums, int nblocks) {  // in place, exclusive; one 1024-thread workgroup
     __shared__ int s_w[16];
     __shared__ int s_carry;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -150,6 +150,7 @@ __global__ __launch_bounds__(1024) void k_scan_of_sums(int *sums, int nblocks) {
         __syncthreads();
     }
 }
+__global__ __launch_bounds__(1024) void k_scan_of_sums(int *sums, int nblocks) { scan_of_sums_body(sums, nblocks); }
 __global__ __launch_bounds__(1024) void k_scan_apply(const int *in, long long n, const int *sums, int *out) {
     __shared__ int s_w[16];
     __shared__ int s_carry;
@@ -254,11 +255,15 @@ __global__ __launch_bounds__(256) void k_tile_scatter(const int2 *edges, const i
 // (p2o[i] == -1), and the bid is stored at the person's true list position (the tie rule of :379 is about list
 // positions).  Four small launches ahead of the bid kernel: inverse of U, chunk counts, scan of the counts (the ingest's
 // k_scan_of_sums), ranks + scatter.
-__global__ __launch_bounds__(256) void k_order_inverse(const Ctl *ctl, const int *U, int *pos_of) {
+// (thr / min_K: the scan these kernels prepare runs only in a live round with K >= min_K -- otherwise nothing to do)
+__device__ __forceinline__ bool order_needed(const Ctl *ctl, int thr, int min_K) { return round_live(ctl, thr) && ctl->K >= min_K; }
+__global__ __launch_bounds__(256) void k_order_inverse(const Ctl *ctl, const int *U, int *pos_of, int thr, int min_K) {
+    if (!order_needed(ctl, thr, min_K)) return;
     const int K = ctl->K;
     for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < K; n += gridDim.x * blockDim.x) pos_of[U[n]] = n;
 }
-__global__ __launch_bounds__(1024) void k_order_sums(const int *p2o, int n_rows, int *sums) {
+__global__ __launch_bounds__(1024) void k_order_sums(const Ctl *ctl, const int *p2o, int n_rows, int *sums, int thr, int min_K) {
+    if (!order_needed(ctl, thr, min_K)) return;
     __shared__ int s_w[16];
     const int base = blockIdx.x * kScanChunk;
     int v = 0;
@@ -275,8 +280,10 @@ __global__ __launch_bounds__(1024) void k_order_sums(const int *p2o, int n_rows,
         sums[blockIdx.x] = t;
     }
 }
-__global__ __launch_bounds__(1024) void k_order_scatter(const int *p2o, int n_rows, const int *sums, const int *pos_of,
-                                                        int *order_person, int *order_pos) {
+__global__ __launch_bounds__(1024) void k_order_scan(const Ctl *ctl, int *sums, int nblocks, int thr, int min_K);
+__global__ __launch_bounds__(1024) void k_order_scatter(const Ctl *ctl, const int *p2o, int n_rows, const int *sums, const int *pos_of,
+                                                        int *order_person, int *order_pos, int thr, int min_K) {
+    if (!order_needed(ctl, thr, min_K)) return;
     __shared__ int s_w[16];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     int carry = sums[blockIdx.x];  // (exclusive: unassigned persons in the chunks before this one)
@@ -299,6 +306,11 @@ __global__ __launch_bounds__(1024) void k_order_scatter(const int *p2o, int n_ro
         }
         carry += tot;
     }
+}
+
+__global__ __launch_bounds__(1024) void k_order_scan(const Ctl *ctl, int *sums, int nblocks, int thr, int min_K) {
+    if (!order_needed(ctl, thr, min_K)) return;
+    scan_of_sums_body(sums, nblocks);
 }
 
 // ---- the kernel -------------------------------------------------------------------------------------------

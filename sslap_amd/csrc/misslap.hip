@@ -548,15 +548,18 @@ int launch_bid_tiled(misslap_solver *h) {
     // A partial round whose K the host knows: bidders in person order (kernels_tiled.hpp, k_order_*).  Scratch that
     // is idle during a bid phase: the compaction lists (the tie-break reads order_pos before they are rewritten),
     // the chunk counters, the objective's match counters.
-    h->round_ordered = h->order_partial && !h->phase_fresh && h->K_exact && h->K_ub < h->n_rows;
+    // (K < N in every round of a phase but the first: every winner of the first round takes an unowned object.  The
+    // ordering kernels and the scan take K from the device, so the host need not know it exactly.)
+    h->round_ordered = h->order_partial && !h->phase_fresh;
     if (h->round_ordered) {
         int *pos_of = h->nmatch, *order_person = h->hole_list, *order_pos = h->mover_list, *sums = h->cnt;
         const int nchunks = (h->n_rows + kScanChunk - 1) / kScanChunk;
-        hipLaunchKernelGGL(k_order_inverse, dim3(blocks_for(h->K_ub, 256)), dim3(256), 0, h->stream, h->ctl, h->U, pos_of);
-        hipLaunchKernelGGL(k_order_sums, dim3(nchunks), dim3(1024), 0, h->stream, h->p2o, h->n_rows, sums);
-        hipLaunchKernelGGL(k_scan_of_sums, dim3(1), dim3(1024), 0, h->stream, sums, nchunks);
-        hipLaunchKernelGGL(k_order_scatter, dim3(nchunks), dim3(1024), 0, h->stream, h->p2o, h->n_rows, sums, pos_of,
-                           order_person, order_pos);
+        // (each returns at once when the scan itself will: a round enqueued on a stale upper bound of K)
+        hipLaunchKernelGGL(k_order_inverse, dim3(blocks_for(h->K_ub, 256)), dim3(256), 0, h->stream, h->ctl, h->U, pos_of, h->thr, h->tiled_min_K);
+        hipLaunchKernelGGL(k_order_sums, dim3(nchunks), dim3(1024), 0, h->stream, h->ctl, h->p2o, h->n_rows, sums, h->thr, h->tiled_min_K);
+        hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(1024), 0, h->stream, h->ctl, sums, nchunks, h->thr, h->tiled_min_K);
+        hipLaunchKernelGGL(k_order_scatter, dim3(nchunks), dim3(1024), 0, h->stream, h->ctl, h->p2o, h->n_rows, sums, pos_of,
+                           order_person, order_pos, h->thr, h->tiled_min_K);
         ta.order_person = order_person;
         ta.order_pos = order_pos;
     }
@@ -654,7 +657,7 @@ int launch_tiebreak(misslap_solver *h) {
     RoundArgs a = round_args(h);
     const long long share = h->K_ub;
     hipLaunchKernelGGL(k_tiebreak, dim3(blocks_for(share, 256)), dim3(256), 0, h->stream, a,
-                       h->round_ordered ? h->mover_list : nullptr, h->take_edges_n, h->take_edges_out);
+                       h->round_ordered ? h->mover_list : nullptr, h->tiled_min_K, h->take_edges_n, h->take_edges_out);
     h->take_edges_n = 0;
     h->take_edges_out = nullptr;
     HIP_TRY(hipGetLastError());
@@ -2034,6 +2037,9 @@ misslap_round_ops handle_round_ops(misslap_solver *h) {
     o.rounds_per_sync = h->rounds_per_sync;
     o.large_round_K = kRoundSmallMax;
     o.rounds_per_sync_large = kRoundsPerSyncLargeK;
+    // (MISSLAP_BIG_ROUNDS_BATCHED=1, host_comm.hpp: the rounds of the full-scan regime through the batched path, one per
+    // batch, so that the host's upper bound of K is at most two rounds old when the regime ends)
+    if (h->world == 1 && !big_rounds_exact_env()) o.rounds_per_sync_large = 1;
     o.max_iter = h->max_iter;
     o.ctx = h;
     o.status = [](void *x, int64_t *K, int64_t *its) {
