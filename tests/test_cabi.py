@@ -97,6 +97,20 @@ def test_options_struct_size_versions_are_recognised():
     assert rc in (0, _lib.ERR_NO_DEVICE), msg
 
 
+def test_cache_limits_and_comm_info_need_no_gpu():
+    """misslap_set_cache_limits validates its arguments; misslap_comm_info reports a custom communicator as its ops
+    describe it (for RCCL it is ncclCommCount: tests/test_gpu_parity.py::test_rccl_world1_smoke)."""
+    lib = _lib.load()
+    assert lib.misslap_set_cache_limits(-1, 0, 0) == _lib.ERR_INVALID
+    assert lib.misslap_set_cache_limits(4 << 30, 1 << 30, 64) == 0  # the library's defaults
+    from sslap_amd.dist import Comm
+    c = Comm.custom(1, 2, lambda p, n, s: None, lambda p, n, s: None)
+    assert c.info() == dict(kind="custom", rank=1, world=2, transport_ranks=2)
+    assert lib.misslap_comm_info(None, None, None, None, None) == _lib.ERR_INVALID
+    rd = C.c_double()
+    assert lib.misslap_measure_hbm(0, 1 << 20, 0, C.byref(rd), None) == _lib.ERR_INVALID  # reps < 1
+
+
 def test_trim_caches_needs_no_gpu():
     freed = C.c_int64(-1)
     assert _lib.load().misslap_trim_caches(C.byref(freed)) == 0 and freed.value >= 0

@@ -960,6 +960,7 @@ def test_rccl_world1_smoke(gpu_lib):
     k_bid, k_tiebreak and k_apply for EVERY grid round (shard_min_k = -1) -- and the solve still equals the oracle."""
     from sslap_amd.dist import Comm, solve_sharded
     comm = Comm.rccl(0, 1, 0, lambda uid: uid)
+    assert comm.info() == dict(kind="rccl", rank=0, world=1, transport_ranks=1)  # transport_ranks = ncclCommCount
     for n, dens, seed, ints, thr in ((1500, 0.02, 1, 0, 0), (30000, 0.002, 4, 0, None), (2000, 0.02, 5, 3, 8)):
         loc, val = synth.gen_sparse(n, n, dens, seed=seed, integer_values=ints)
         ref = orc.auction_solve(loc=loc, val=val.copy(), problem="max", cardinality_check=False, max_iter=10**8)
@@ -968,6 +969,7 @@ def test_rccl_world1_smoke(gpu_lib):
         sol = solve_sharded(s, comm)
         assert np.array_equal(sol, ref["sol"]) and s.meta["its"] == ref["meta"]["its"]
         assert s.gpu["obj_f64"] == ref["extra"]["obj_f64"] and s.gpu["edges_scanned"] == ref["extra"]["edges_scanned"]
+        assert s.gpu["sharded_rounds"] == s.gpu["grid_rounds"] > 0  # shard_min_k = -1: every grid round is exchanged
     # a communicator that does not match the handle's shard is refused
     s = from_sparse(loc, val.copy(), problem="max", cardinality_check=False, shard=(0, 2))
     with pytest.raises(ValueError, match="communicator is rank 0 of 1"):
@@ -1163,3 +1165,18 @@ def test_sharded_solve_at_baseline_sizes_two_ranks_one_gpu(golden_large, gpu_lib
         assert r0 == r1 and e0 - s0 == e1 - s1  # the same rounds were sharded; the replicated part is identical
         assert s0 + s1 + (e0 - s0) == g["edges_scanned"]  # unique work = the single-GPU (= the reference's) edge count
     assert got[0]["C4"][6] >= 20  # 26 sharded rounds per C4 solve
+
+
+def test_measured_hbm_rates_and_device_uuid(gpu_lib):
+    """misslap_measure_hbm (the 'measured peak' of bench.py's roofline): the library's own read-only and copy streaming
+    kernels reach a plausible share of the 8 TB/s data sheet rate; misslap_device_uuid gives 32 hex digits."""
+    import ctypes as C
+    from sslap_amd import _lib
+    rd, cp = C.c_double(), C.c_double()
+    _lib.check(gpu_lib.misslap_measure_hbm(0, 1 << 29, 5, C.byref(rd), C.byref(cp)))
+    assert 3000.0 < rd.value < 8000.0 and 3000.0 < cp.value < 8000.0
+    buf = C.create_string_buffer(40)
+    _lib.check(gpu_lib.misslap_device_uuid(0, buf, 40))
+    assert len(buf.value) == 32 and int(buf.value, 16) >= 0
+    with pytest.raises(ValueError):
+        _lib.check(gpu_lib.misslap_device_uuid(0, buf, 8))

@@ -46,6 +46,14 @@ for seed in range(first, first + count):
           and np.array_equal(sg["p"].view(np.uint64), so["p"].view(np.uint64))
           and np.array_equal(sg["U"][:sg["K"]], so["U"][:so["K"]])
           and g.gpu["edges_scanned"] == o.extra["edges_scanned"] and g.gpu["obj_f64"] == o.extra["obj_f64"])
+    # the validity flags of the reference's harness (benchmarking.py:56-64), reduced on the device by the final pass
+    sel = np.full(n, -1.0)
+    rows, cols = loc[:, 0], loc[:, 1]
+    cwrap = np.where(gsol < 0, (int(loc[:, 1].max()) + 1) + gsol, gsol)
+    hit = cols == cwrap[rows]
+    sel[rows[hit]] = val[hit]  # (the last stored entry wins, like a dense matrix built from loc / val)
+    want_flags = ((np.unique(gsol).size == n, bool((gsol >= 0).all()), bool((gsol < n).all())), bool((sel >= 0).all()))
+    ok = ok and (g.gpu["complete_assignment"], g.gpu["valid_assignment"]) == want_flags
     if not ok:
         bad += 1
         print("MISMATCH", seed, n, m, density, ints, prob, kw, gpu, flush=True)
