@@ -277,7 +277,11 @@ def main():
     barrier()
     t0 = time.perf_counter()
     runs = []
+    s = None
     for _ in range(args.steps):
+        # (a step ends with its handle destroyed -- the reference's solver object dies with the call, too; a handle that
+        # outlived its step would also make the next create open a second HIP stream, 6 ms, inside the timed region)
+        del s
         s, sol = one_step()
         runs.append((dict(s.meta), dict(s.gpu)))
     barrier()

@@ -67,6 +67,25 @@ double now_ms() {
     using clk = std::chrono::steady_clock;
     return std::chrono::duration<double, std::milli>(clk::now().time_since_epoch()).count();
 }
+// MISSLAP_TRACE_CREATE=1: where a handle's setup time goes (stderr, one line per stage; the stream is drained at every
+// stage, so the sum is a little above an untraced create)
+struct CreateTrace {
+    bool on;
+    double t0;
+    hipStream_t st;
+    explicit CreateTrace(hipStream_t s) : st(s) {
+        const char *e = std::getenv("MISSLAP_TRACE_CREATE");
+        on = e && e[0] == '1';
+        t0 = now_ms();
+    }
+    void stage(const char *name) {
+        if (!on) return;
+        (void)hipStreamSynchronize(st);
+        const double t = now_ms();
+        fprintf(stderr, "[misslap create] %-28s %8.3f ms\n", name, t - t0);
+        t0 = t;
+    }
+};
 
 // Rounds with K <= threshold run in the tail kernels.  Break-even against a grid round (two launches: k_bid +
 // k_round_small, ~12 us), measured with tools/sweep_thr.py / tools/tail_stats.py after every change of either side.
@@ -876,6 +895,7 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
     h->n_rows = last_row + 1;  // auction_.pyx:209 (rows are ascending, so the last one is the maximum)
     int rc;
     DevScratch tmp;  // every temporary below: released on every return path
+    CreateTrace trace(h->stream);
     IngestStats *d_st = nullptr;
     if ((rc = tmp.alloc(&d_st, 1))) return rc;
     HIP_TRY(hipMemsetAsync(d_st, 0, sizeof(IngestStats), h->stream));
@@ -898,6 +918,7 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
     IngestStats st;
     HIP_TRY(hipMemcpyAsync(&st, d_st, sizeof(st), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    trace.stage("ingest rows / values");
     if (st.err & kErrColNegative) return fail(MISSLAP_ERR_INVALID, "loc holds a negative row or column index");
     if (st.err & kErrRowsUnsorted)
         return fail(MISSLAP_ERR_INVALID, "loc rows must be sorted in ascending order (auction_.pyx:33-48 contract)");
@@ -959,6 +980,7 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
         hipLaunchKernelGGL(k_build_edges_f64, dim3(grid), dim3(256), 0, h->stream, d_loc, d_val, (long long)nnz,
                            flip, h->col, h->val64);
     }
+    trace.stage("edge layout");
     const size_t N = (size_t)h->n_rows, M = (size_t)h->n_cols;
     // second, tile-major copy of the edges for the full-scan bid engines (8 B/edge layout, big rounds only)
     // launch shape: options.reserved[1] = k + 1 picks shape k (tuning); 0 = by the average (person, tile) segment length
@@ -1022,6 +1044,7 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
             hipLaunchKernelGGL(k_scan_sums, dim3(nch), dim3(1024), 0, h->stream, cnt, (long long)N, sums);
             hipLaunchKernelGGL(k_scan_of_sums, dim3(1), dim3(1024), 0, h->stream, sums, nch);
             hipLaunchKernelGGL(k_scan_apply, dim3(nch), dim3(1024), 0, h->stream, cnt, (long long)N, sums, h->ovf_ptr);
+            trace.stage("tile counts + scans");
             int unsorted = 0, total = 0, n_ovf = 0;
             HIP_TRY(hipMemcpyAsync(&unsorted, flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(hipMemcpyAsync(&total, start + L, sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -1061,6 +1084,7 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
                                    h->tcol, h->ovf_q);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipStreamSynchronize(h->stream));
+                trace.stage("tile-major copy");
                 h->tiled_ok = true;
                 // break-even against k_bid (cost ~ K) measured at C3: the full-scan engines have a fixed cost
                 // (price fills, barriers / the merge pass) of about a fifth of a full k_bid scan
@@ -1093,6 +1117,7 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
             HIP_TRY(hipStreamSynchronize(h->stream));  // the temporaries are released at scope exit
         }
     }
+    trace.stage("tile engine attributes");
     {
         DevBlock blk;
         blk.want(&h->price, Mpad);
@@ -1172,6 +1197,7 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
     h->phase_fresh = true;
     HIP_TRY(hipStreamSynchronize(h->stream));
     tmp.drained = true;
+    trace.stage("state blocks + init");
     return MISSLAP_OK;
 }
 
@@ -1676,13 +1702,17 @@ MISSLAP_API int misslap_create(misslap_solver **out, int64_t nnz, const int32_t 
     if (nnz >= nnz_limit(opt))
         return fail(MISSLAP_ERR_INVALID, "nnz must be < %lld (int32 row pointers)", (long long)nnz_limit(opt));
     misslap_solver *h = nullptr;
+    CreateTrace trace(nullptr);
     rc = new_handle(out, opt, abi, &h);
     if (rc) return rc;
+    trace.st = h->stream;
+    trace.stage("new handle");
     h->nnz = nnz;
     if ((rc = sync_device_inputs(opt, h->stream))) {
         free_all(h);
         return rc;
     }
+    trace.stage("inputs ordered");
     const int *d_loc = nullptr;
     const double *d_val = nullptr;
     int *own_loc = nullptr;
@@ -1709,10 +1739,12 @@ MISSLAP_API int misslap_create(misslap_solver **out, int64_t nnz, const int32_t 
         d_val = own_val;
         last_row = loc[2 * (nnz - 1)];
     }
+    trace.stage("last row read");
     rc = build_from_device_coo(h, d_loc, d_val, last_row, opt);
     if (rc) return cleanup(rc);
     cleanup(0);
     h->setup_ms = now_ms() - t0;
+    trace.stage("(build, see above) + cleanup");
     *out = h;
     return MISSLAP_OK;
 }
