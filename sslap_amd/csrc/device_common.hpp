@@ -62,6 +62,22 @@ struct Ctl {
     unsigned long long val_cnt[4]; // k_validity: distinct owned objects, sol < 0, sol >= n_rows, invalid selected entries
 };
 
+// ---- live status ---------------------------------------------------------------------------------
+// The kernel that closes a round (or a run of tail kernels) writes {K, error bits, nits}, each next to the TICKET the
+// host gave the launch, into four words of PINNED HOST memory.  The host's loop then learns the state of the rounds it
+// has enqueued by polling those words: no copy kernel behind every batch, no stream drain, no driver wake-up (a status
+// read used to be hipMemcpyAsync + hipStreamSynchronize: 15-25 us of idle device per read; C4 has one in front of each
+// of its 26 big rounds).  A word carries its ticket, so any four words with the same ticket are one consistent status
+// whatever order they land in.
+__device__ __forceinline__ void post_live_status(unsigned long long *live, unsigned ticket, int K, int err, long long nits) {
+    if (!live) return;
+    const unsigned long long t = (unsigned long long)ticket << 32;
+    __hip_atomic_store(&live[0], t | (unsigned)K, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&live[1], t | (unsigned)err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&live[2], t | (unsigned)((unsigned long long)nits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&live[3], t | (unsigned)((unsigned long long)nits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ---- edge storage ------------------------------------------------------------------------------
 struct EdgesF32 {  // 8 B / edge
     static constexpr bool kCand = true;  // persons keep candidate lines (see below)

@@ -50,6 +50,8 @@ struct RoundArgs {
     unsigned long long *wg_stats;
     int *need_list;               // [n_rows] persons with LONG rows whose line k_refresh_lines found spent (Ctl::n_need of
                                   // them): the work list of k_refresh_long
+    unsigned long long *live;     // pinned host words the round-closing kernel posts the status to (post_live_status);
+    unsigned ticket;              // nullptr: none.  ticket: the host's number of that launch
 };
 constexpr int kStatEdges = 0, kStatBids = 1, kStatHits = 2, kStatHitEdges = 3, kStatShardEdges = 4, kStatLaunchEdges = 5,
               kStatWords = 8;
@@ -61,9 +63,9 @@ __device__ __forceinline__ bool round_live(const Ctl *c, int thr) {
 // an early exit that does not need it, so the exit is made to need it: `never` is a condition on the loaded value
 // that holds for no valid content.
 struct CtlHead {
-    int K;
+    int K, err;
     long long nits, max_iter;
-    __device__ __forceinline__ explicit CtlHead(const Ctl *c) : K(c->K), nits(c->nits), max_iter(c->max_iter) {
+    __device__ __forceinline__ explicit CtlHead(const Ctl *c) : K(c->K), err(c->err), nits(c->nits), max_iter(c->max_iter) {
         __builtin_amdgcn_sched_barrier(0);  // the requests above are issued before anything below waits
     }
     __device__ __forceinline__ bool live(int thr, bool never) const {
@@ -647,7 +649,7 @@ constexpr int kCompactSmallMax = 32768;
 // together, the per-wavefront counts go through LDS once (double-buffered by pass parity: ONE barrier per pass), and
 // the running list lengths are the same in every thread's registers (a pass used to be 1024 positions behind one
 // exposed memory latency and three barriers: 10 us for the 10 000 - 30 000 positions of a mid round).
-__device__ __forceinline__ void compact_small_body(const RoundArgs &a, Ctl *ctl, int K, int nholes) {
+__device__ __forceinline__ void compact_small_body(const RoundArgs &a, Ctl *ctl, int K, int nholes, int err_seen) {
     const int Kn = K - nholes;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     constexpr int kQ = 4;
@@ -702,18 +704,24 @@ __device__ __forceinline__ void compact_small_body(const RoundArgs &a, Ctl *ctl,
         for (int k = t; k < nl; k += 1024) a.U[a.hole_list[k]] = a.mover_list[k];  // data[left_track] = i   (:158)
     }
     if (t == 0) {
+        const long long nits = ctl->nits + 1;  // :273
         ctl->K = Kn;  // :429
         ctl->nholes = 0;
         ctl->nleft = 0;
-        ctl->nits += 1;  // :273
+        ctl->nits = nits;
         ctl->grid_rounds += 1;
+        post_live_status(a.live, a.ticket, Kn, err_seen, nits);
     }
 }
 
 __global__ __launch_bounds__(1024) void k_compact_small(RoundArgs a) {
     Ctl *ctl = a.ctl;
-    if (!round_live(ctl, a.thr)) return;
-    compact_small_body(a, ctl, ctl->K, ctl->nholes);
+    const CtlHead head(ctl);
+    if (!head.live(a.thr, false)) {  // (the round was not live: its ticket is posted all the same -- the host waits for it)
+        if (threadIdx.x == 0) post_live_status(a.live, a.ticket, head.K, head.err, head.nits);
+        return;
+    }
+    compact_small_body(a, ctl, head.K, ctl->nholes, head.err);
 }
 
 // RESOLVE + ASSIGN + push_all_left + round end of a round with few bidders in ONE launch (a single 1024-thread
@@ -741,7 +749,10 @@ __global__ __launch_bounds__(1024) void k_round_small(RoundArgs a) {
         key[q] = a.bid_key[min(q * 1024 + t, a.n_rows - 1)];
         never |= (br[q].x < 0) | (key[q] == ~0ull);
     }
-    if (!head.live(a.thr, never)) return;
+    if (!head.live(a.thr, never)) {
+        if (t == 0) post_live_status(a.live, a.ticket, head.K, head.err, head.nits);
+        return;
+    }
     const int K = head.K;
     __shared__ int s_cnt[16], s_wl[16], s_wm[16];
     __shared__ int s_hole[kRoundSmallMax], s_mover[kRoundSmallMax];  // push_all_left lists
@@ -861,19 +872,26 @@ __global__ __launch_bounds__(1024) void k_round_small(RoundArgs a) {
         ctl->K = Kn;  // :429
         ctl->nholes = 0;
         ctl->nleft = 0;
-        ctl->nits += 1;  // :273
+        ctl->nits = head.nits + 1;  // :273
         ctl->grid_rounds += 1;
+        post_live_status(a.live, a.ticket, Kn, head.err, head.nits + 1);
     }
 }
 
 __global__ void k_round_end(RoundArgs a) {
     Ctl *ctl = a.ctl;
-    if (!round_live(ctl, a.thr)) return;
-    ctl->K = ctl->K - ctl->nholes;  // :429
+    const CtlHead head(ctl);
+    if (!head.live(a.thr, false)) {
+        post_live_status(a.live, a.ticket, head.K, head.err, head.nits);
+        return;
+    }
+    const int Kn = head.K - ctl->nholes;
+    ctl->K = Kn;  // :429
     ctl->nholes = 0;
     ctl->nleft = 0;
-    ctl->nits += 1;                 // :273
+    ctl->nits = head.nits + 1;      // :273
     ctl->grid_rounds += 1;
+    post_live_status(a.live, a.ticket, Kn, head.err, head.nits + 1);
 }
 
 // eps-phase restart (auction_.pyx:286-290): forget assignments, keep prices.

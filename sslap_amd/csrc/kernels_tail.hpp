@@ -80,7 +80,9 @@ __global__ __launch_bounds__(256) void k_sync_clear_p2o(Ctl *ctl, int *p2o, int 
     if (blockIdx.x == 0 && threadIdx.x == 0) ctl->n_need = 0;  // the maintenance pass's work list has been consumed
 }
 __global__ __launch_bounds__(256) void k_sync_from_rec(Ctl *ctl, const PriceRec *rec, double *price, int *o2p, int *p2o,
-                                                       int n_cols, int lines) {
+                                                       int n_cols, int lines, unsigned long long *live, unsigned ticket) {
+    // (closes a run of tail kernels: K / nits are theirs; an error bit raised below reaches the host with the next status)
+    if (blockIdx.x == 0 && threadIdx.x == 0) post_live_status(live, ticket, ctl->K, ctl->err, ctl->nits);
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n_cols; j += gridDim.x * blockDim.x) {
         const PriceRec r = rec[j];
         // price[] still holds the prices the tail kernels started from: a price may only have risen since (the

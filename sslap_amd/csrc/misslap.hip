@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <utility>
 #include <vector>
@@ -245,6 +246,15 @@ struct misslap_solver {
     std::vector<Blk> blocks;  // device memory of the arrays above (DevBlock), released as a whole
     Ctl *h_ctl = nullptr;  // pinned mirror
     Ctl *h_stat = nullptr;  // pinned [2]: status copies that trail the grid rounds by one batch (status_enqueue)
+    // live status (device_common.hpp, post_live_status): four pinned words behind the mirrors, the ticket of the last
+    // round-closing launch, and whether everything enqueued since the last full read is covered by that ticket
+    volatile unsigned long long *live = nullptr;
+    unsigned long long *live_dev = nullptr;  // the same words as the device addresses them
+    unsigned ticket = 0;
+    bool live_valid = false;
+    bool live_off = false;      // MISSLAP_LIVE_STATUS=0, or a poll has timed out: status reads by copy + stream drain
+    unsigned slot_ticket[2] = {0, 0};
+    bool slot_live[2] = {false, false};
     hipEvent_t stat_ev[2] = {nullptr, nullptr};
     // scalar solver state (auction_.pyx:180-187)
     float eps = 0, target_eps = 0, theta = 0, start_eps = 0;
@@ -480,6 +490,8 @@ RoundArgs round_args(misslap_solver *h) {
     a.launch_idx = 0;
     a.wg_stats = h->wg_stats;
     a.need_list = h->need_list;
+    a.live = nullptr;
+    a.ticket = 0;
     a.gather_max_K = h->tiled_ok ? h->tiled_min_K : 0;
     a.cand = h->lines_live() ? h->cand : nullptr;
     a.cand64 = h->lines_live() ? h->cand64 : nullptr;
@@ -527,17 +539,82 @@ int read_ctl(misslap_solver *h) {
     return MISSLAP_OK;
 }
 
+// Wait for the status a round-closing launch posts (post_live_status): exact = the ticket `want` itself, otherwise any
+// ticket at or behind it.  Returns false on a timeout (the caller falls back to a copy + drain and stops using the words).
+bool live_poll(misslap_solver *h, unsigned want, bool exact, int *K, int *err, long long *nits) {
+    volatile unsigned long long *w = h->live;
+    const double t_end = now_ms() + 20000.0;
+    for (unsigned spins = 0;; ++spins) {
+        const unsigned long long a = w[0], b = w[1], c = w[2], d = w[3];
+        const unsigned t = (unsigned)(a >> 32);
+        if ((unsigned)(b >> 32) == t && (unsigned)(c >> 32) == t && (unsigned)(d >> 32) == t && w[0] == a &&
+            (exact ? t == want : (int)(t - want) >= 0)) {
+            *K = (int)(unsigned)(a & 0xffffffffull);
+            *err = (int)(unsigned)(b & 0xffffffffull);
+            *nits = (long long)((c & 0xffffffffull) | ((d & 0xffffffffull) << 32));
+            return true;
+        }
+        if (spins < 4000) {
+            __builtin_ia32_pause();
+        } else {
+            std::this_thread::yield();  // (a tail kernel runs for milliseconds: do not burn a core another solve needs)
+            if ((spins & 1023) == 0 && now_ms() > t_end) return false;
+        }
+    }
+}
+// K / nits / error bits of everything enqueued so far, into the mirror's fields: from the live words where the last
+// thing enqueued that changes them was a ticketed launch, by a full read otherwise.
+int read_status(misslap_solver *h) {
+    if (h->ctl_fresh || !h->live_valid || h->live_off) return read_ctl(h);
+    int K = 0, err = 0;
+    long long nits = 0;
+    if (!live_poll(h, h->ticket, true, &K, &err, &nits)) {
+        h->live_off = true;
+        return read_ctl(h);
+    }
+    h->h_ctl->K = K;
+    h->h_ctl->nits = nits;
+    h->h_ctl->err = err;
+    h->K_ub = K;
+    h->K_exact = true;
+    if (err) return fail(MISSLAP_ERR_STATE, "device-side invariant violated (error bits 0x%x)", err);
+    return MISSLAP_OK;
+}
+
 // Status of the round loop WITHOUT draining the stream: a copy of the control block is enqueued behind a batch of
 // rounds and read while the next batch runs.  K never grows inside an eps-phase, so a status that is one batch old
 // is still an upper bound for the launch grids, and every round kernel is a no-op once the round is not live: a
 // batch enqueued on a stale "go on" costs its launches and nothing else.
 int status_enqueue(misslap_solver *h, int slot) {
+    h->slot_live[slot] = h->live_valid && !h->live_off;
+    if (h->slot_live[slot]) {  // nothing to enqueue: the rounds post their status themselves
+        h->slot_ticket[slot] = h->ticket;
+        return MISSLAP_OK;
+    }
     h->ctl_fresh = false;
     HIP_TRY(hipMemcpyAsync(&h->h_stat[slot], h->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipEventRecord(h->stat_ev[slot], h->stream));
     return MISSLAP_OK;
 }
 int status_wait(misslap_solver *h, int slot) {
+    if (h->slot_live[slot]) {
+        int K = 0, err = 0;
+        long long nits = 0;
+        if (live_poll(h, h->slot_ticket[slot], false, &K, &err, &nits)) {
+            h->h_stat[slot].K = K;
+            h->h_stat[slot].nits = nits;
+            h->h_stat[slot].err = err;
+            h->K_ub = K;
+            h->K_exact = false;
+            if (err) return fail(MISSLAP_ERR_STATE, "device-side invariant violated (error bits 0x%x)", err);
+            return MISSLAP_OK;
+        }
+        h->live_off = true;  // timed out: drain the stream and read the control block
+        int rc = read_ctl(h);
+        h->h_stat[slot] = *h->h_ctl;
+        h->K_exact = false;
+        return rc;
+    }
     HIP_TRY(hipEventSynchronize(h->stat_ev[slot]));
     const Ctl &c = h->h_stat[slot];
     h->K_ub = c.K;
@@ -686,6 +763,9 @@ int launch_tiebreak(misslap_solver *h) {
 int launch_apply(misslap_solver *h) {
     h->ctl_fresh = false;
     RoundArgs a = round_args(h);
+    a.live = h->live_off ? nullptr : h->live_dev;
+    a.ticket = ++h->ticket;
+    h->live_valid = a.live != nullptr;
     if (h->round_small) {
         h->round_small = false;
         h->K_exact = false;
@@ -782,8 +862,9 @@ int launch_tail(misslap_solver *h) {
     if (pr) HIP_TRY(hipEventRecord(pr->stop, h->stream));
     // the tail keeps only the price records current: rebuild price / o2p / p2o from them
     hipLaunchKernelGGL(k_sync_clear_p2o, dim3(blocks_for(h->n_rows, 256)), dim3(256), 0, h->stream, h->ctl, h->p2o, h->n_rows);
+    h->live_valid = !h->live_off && h->live_dev != nullptr;
     hipLaunchKernelGGL(k_sync_from_rec, dim3(blocks_for(h->n_cols, 256)), dim3(256), 0, h->stream, h->ctl, h->rec, h->price,
-                       h->o2p, h->p2o, h->n_cols, h->cand != nullptr ? 1 : 0);
+                       h->o2p, h->p2o, h->n_cols, h->cand != nullptr ? 1 : 0, h->live_valid ? h->live_dev : nullptr, ++h->ticket);
     HIP_TRY(hipGetLastError());
     h->phase_fresh = false;
     return MISSLAP_OK;
@@ -845,7 +926,7 @@ int launch_rows_all(misslap_solver *h, float eps, const FinalOut &fo, int *n_blo
 // eCE_satisfied(eps), auction_.pyx:443-485.  The sample pass first (kernels_check.hpp: a failing test fails within the
 // first few rows), then every row -- a launch that returns at once when the sample has set the flag.
 int run_ece(misslap_solver *h, float eps, int *ok) {
-    int rc = read_ctl(h);
+    int rc = read_status(h);
     if (rc) return rc;
     if (h->h_ctl->K > 0) {  // auction_.pyx:446-447
         *ok = 0;
@@ -1164,8 +1245,21 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
     if (h->split_cnt) HIP_TRY(hipMemsetAsync(h->split_cnt, 0, sizeof(int) * ((size_t)N / 256 + 1024), h->stream));
     if (h->profile)
         HIP_TRY(hipMemsetAsync(h->launch_edges, 0, sizeof(unsigned long long) * h->launch_edges_cap, h->stream));
-    if (!h->h_ctl) HIP_TRY(hipHostMalloc((void **)&h->h_ctl, 3 * sizeof(Ctl)));  // the mirror and the two trailing status copies
+    // the mirror, the two trailing status copies and the live status words (kept together: one pooled allocation)
+    if (!h->h_ctl) HIP_TRY(hipHostMalloc((void **)&h->h_ctl, 3 * sizeof(Ctl) + 128));
     h->h_stat = h->h_ctl + 1;
+    {
+        char *base = reinterpret_cast<char *>(h->h_ctl + 3);
+        base += (64 - (reinterpret_cast<uintptr_t>(base) & 63)) & 63;
+        h->live = reinterpret_cast<volatile unsigned long long *>(base);
+        for (int k = 0; k < 4; ++k) h->live[k] = 0ull;  // ticket 0 = nothing posted (tickets start at 1)
+        void *dev = nullptr;
+        if (hipHostGetDevicePointer(&dev, base, 0) == hipSuccess) h->live_dev = static_cast<unsigned long long *>(dev);
+        const char *e = std::getenv("MISSLAP_LIVE_STATUS");
+        h->live_off = h->live_dev == nullptr || (e && e[0] == '0');
+        h->ticket = 0;
+        h->live_valid = false;
+    }
     for (hipEvent_t &e : h->stat_ev)
         if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     h->shard_min_K = h->tiled_ok ? h->tiled_min_K : (int)std::max<size_t>((N * 3) / 10, 8192);
@@ -1896,7 +1990,7 @@ MISSLAP_API int misslap_check_ece(misslap_solver *h, float eps, int32_t *satisfi
 MISSLAP_API int misslap_phase_end(misslap_solver *h, int32_t *finished) {
     if (!h) return fail(MISSLAP_ERR_INVALID, "null handle");
     HIP_TRY(hipSetDevice(h->device));
-    int rc = read_ctl(h);
+    int rc = read_status(h);  // (K, nits and the error bits are all this needs)
     if (rc) return rc;
     const Ctl &c = *h->h_ctl;
     if (c.nits >= h->max_iter) {  // terminate(), first clause (:308-309)
@@ -1913,6 +2007,7 @@ MISSLAP_API int misslap_phase_end(misslap_solver *h, int32_t *finished) {
             hipLaunchKernelGGL(k_reset_phase, dim3(blocks_for(h->n_rows > h->n_cols ? h->n_rows : h->n_cols, 256)),
                                dim3(256), 0, h->stream, h->ctl, h->p2o, h->o2p, h->rec, h->U, h->n_rows, h->n_cols);
             HIP_TRY(hipGetLastError());
+            h->live_valid = false;  // (K was changed by a launch without a ticket; the mirror below is current)
             h->nreductions += 1;  // :292
             h->K_ub = h->n_rows;
             h->K_exact = true;  // k_reset_phase sets K = n_rows ...
@@ -2076,7 +2171,7 @@ misslap_round_ops handle_round_ops(misslap_solver *h) {
     o.ctx = h;
     o.status = [](void *x, int64_t *K, int64_t *its) {
         misslap_solver *s = static_cast<misslap_solver *>(x);
-        const int rc = read_ctl(s);
+        const int rc = read_status(s);
         *K = s->h_ctl->K;
         *its = s->h_ctl->nits;
         return rc;
