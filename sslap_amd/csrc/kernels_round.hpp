@@ -878,6 +878,13 @@ __global__ __launch_bounds__(1024) void k_round_small(RoundArgs a) {
     }
 }
 
+// The status of everything enqueued so far, posted by a launch of its own: behind a batch of small rounds, whose
+// closing kernel (k_round_small, a few microseconds each, thousands per solve) does not pay for four stores to host
+// memory every round.
+__global__ void k_post_status(const Ctl *ctl, unsigned long long *live, unsigned ticket) {
+    post_live_status(live, ticket, ctl->K, ctl->err, ctl->nits);
+}
+
 __global__ void k_round_end(RoundArgs a) {
     Ctl *ctl = a.ctl;
     const CtlHead head(ctl);

@@ -253,6 +253,7 @@ struct misslap_solver {
     unsigned ticket = 0;
     bool live_valid = false;
     bool live_off = false;      // MISSLAP_LIVE_STATUS=0, or a poll has timed out: status reads by copy + stream drain
+    bool live_every_round = false;  // MISSLAP_LIVE_STATUS=2 (A/B): k_round_small posts as well
     unsigned slot_ticket[2] = {0, 0};
     bool slot_live[2] = {false, false};
     hipEvent_t stat_ev[2] = {nullptr, nullptr};
@@ -564,8 +565,16 @@ bool live_poll(misslap_solver *h, unsigned want, bool exact, int *K, int *err, l
 }
 // K / nits / error bits of everything enqueued so far, into the mirror's fields: from the live words where the last
 // thing enqueued that changes them was a ticketed launch, by a full read otherwise.
+// the live words cover everything enqueued: if the last launch that changed K / nits carried no ticket, one that only
+// posts the status is enqueued behind it
+void ensure_posted(misslap_solver *h) {
+    if (h->live_valid || h->live_off) return;
+    hipLaunchKernelGGL(k_post_status, dim3(1), dim3(1), 0, h->stream, h->ctl, h->live_dev, ++h->ticket);
+    h->live_valid = true;
+}
 int read_status(misslap_solver *h) {
-    if (h->ctl_fresh || !h->live_valid || h->live_off) return read_ctl(h);
+    if (h->ctl_fresh || h->live_off) return read_ctl(h);
+    ensure_posted(h);
     int K = 0, err = 0;
     long long nits = 0;
     if (!live_poll(h, h->ticket, true, &K, &err, &nits)) {
@@ -586,8 +595,9 @@ int read_status(misslap_solver *h) {
 // is still an upper bound for the launch grids, and every round kernel is a no-op once the round is not live: a
 // batch enqueued on a stale "go on" costs its launches and nothing else.
 int status_enqueue(misslap_solver *h, int slot) {
-    h->slot_live[slot] = h->live_valid && !h->live_off;
-    if (h->slot_live[slot]) {  // nothing to enqueue: the rounds post their status themselves
+    h->slot_live[slot] = !h->live_off;
+    if (h->slot_live[slot]) {  // no copy: the closing kernel of the batch's last round has posted, or k_post_status does
+        ensure_posted(h);
         h->slot_ticket[slot] = h->ticket;
         return MISSLAP_OK;
     }
@@ -763,7 +773,9 @@ int launch_tiebreak(misslap_solver *h) {
 int launch_apply(misslap_solver *h) {
     h->ctl_fresh = false;
     RoundArgs a = round_args(h);
-    a.live = h->live_off ? nullptr : h->live_dev;
+    // (a round that k_round_small closes posts nothing: four stores to host memory are 1.5 us on a 3-5 us kernel that
+    // runs thousands of times per solve -- a batch of such rounds is followed by k_post_status instead, ensure_posted)
+    a.live = (h->live_off || (h->round_small && !h->live_every_round)) ? nullptr : h->live_dev;
     a.ticket = ++h->ticket;
     h->live_valid = a.live != nullptr;
     if (h->round_small) {
@@ -1257,6 +1269,7 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
         if (hipHostGetDevicePointer(&dev, base, 0) == hipSuccess) h->live_dev = static_cast<unsigned long long *>(dev);
         const char *e = std::getenv("MISSLAP_LIVE_STATUS");
         h->live_off = h->live_dev == nullptr || (e && e[0] == '0');
+        h->live_every_round = e && e[0] == '2';
         h->ticket = 0;
         h->live_valid = false;
     }
