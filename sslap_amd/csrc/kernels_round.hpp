@@ -109,26 +109,31 @@ struct SrcOf<RecSource> {
 // answer, misses by the lean scan, nothing built (the rounds above: a line built there is spent long before the tail
 // kernel could use it, and the rounds in between rebuild it anyway); 0 = no lines (12 B/edge layout, cand = off).
 // The host picks the variant from its upper bound of K; a stale bound only means a round or two more without builds.
-template <class E, class Src, int kLines>
-__global__ __launch_bounds__(kBidBlock) void k_bid(RoundArgs a, E ed) {
-    static_assert(kLines == 2 || !SrcOf<Src>::kOwners, "the lean scan does not carry the owners k_round_small needs");
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int wpb = kBidBlock / kWave;
-    const int first = blockIdx.x * wpb + wave;
-    const Ctl *ctl = a.ctl;
-    const CtlHead head(ctl);
-    const int i_first = a.U[min(first, a.n_rows - 1)];
-    if (!head.live(a.thr, i_first < -1)) return;  // (list entries are persons or -1)
-    if (a.gather_max_K > 0 && head.K >= a.gather_max_K) return;
-    int lo, hi;
-    shard_range(head.K, a.rank, a.world, a.shard_min_K, lo, hi);
-    const double eps = (double)a.eps;  // float promoted to double, auction_.pyx:360
-    const Src src = SrcOf<Src>::make(a);
+// What a wavefront's bids add to the statistics (tally_flush: per workgroup, to its slot of RoundArgs::wg_stats).
+struct BidTally {
     unsigned long long edges = 0, hit_edges = 0;
     int nb = 0, nh = 0, err = 0;
+};
+// hand-over of bids between the workgroups of ONE launch (k_round_fused): device-scope relaxed atomics are performed
+// at the level all XCDs share (the XCDs' L2s are not coherent with each other, and a device-scope fence would write
+// back and invalidate a whole L2 per workgroup); the order is made by hand, see k_round_fused.
+__device__ __forceinline__ void handover_store(unsigned long long *p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long handover_load(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The bids of the list positions first, first + stride, ... below `hi` (one wavefront per position).
+template <class E, class Src, int kLines, bool kHandOver>
+__device__ __forceinline__ void bid_positions(const RoundArgs &a, const E &ed, int lo, int hi, int first, int stride,
+                                              int i_first, BidTally &tl) {
+    const int lane = threadIdx.x & 63;
+    const double eps = (double)a.eps;  // float promoted to double, auction_.pyx:360
+    const Src src = SrcOf<Src>::make(a);
     double hint = 0.0;  // cand_build's search distance, carried from one build of this wavefront to the next
     const bool lines = kLines > 0 && E::kCand && a.cand != nullptr;
-    for (int n = lo + first; n < hi; n += gridDim.x * wpb) {
+    for (int n = lo + first; n < hi; n += stride) {
         const int i = n == first ? i_first : a.U[n];
         const int s = a.row_ptr[i], e = a.row_ptr[i + 1];
         CandBid b[2];
@@ -137,7 +142,7 @@ __global__ __launch_bounds__(kBidBlock) void k_bid(RoundArgs a, E ed) {
             typename E::Slot sl = LineIO<typename E::Slot>::load(a.cand, a.cand64,
                                                                  (size_t)i * kCandLanes + (lane & (kCandLanes - 1)));
             int alive[2];
-            cand_eval2(sl, true, false, src, eps, b, err, NoEarly(), NoStamp(), alive);
+            cand_eval2(sl, true, false, src, eps, b, tl.err, NoEarly(), NoStamp(), alive);
             // A hit on a line with little life left is answered by a full scan all the same -- the bid is the same
             // bid -- so that the line is rebuilt HERE, where a scan is one of many in flight, and not by a miss in
             // the tail kernel, where a scan is the whole round.
@@ -147,41 +152,53 @@ __global__ __launch_bounds__(kBidBlock) void k_bid(RoundArgs a, E ed) {
             if (kLines == 2) {
                 CandBuildArgs ba;
                 const typename E::Raw none[4] = {};
-                wave_bid_full<E, Src, false, false>(ed, src, s, e, none, eps, b[0], ba, err);
+                wave_bid_full<E, Src, false, false>(ed, src, s, e, none, eps, b[0], ba, tl.err);
                 if (lines && ba.want) cand_build(a.cand, a.cand64, i, ba, eps, hint);
             } else {
-                wave_bid_lean(ed, src, s, e, eps, b[0], err);
+                wave_bid_lean(ed, src, s, e, eps, b[0], tl.err);
             }
         } else {
-            nh += 1;
-            hit_edges += (unsigned long long)b[0].len;
+            tl.nh += 1;
+            tl.hit_edges += (unsigned long long)b[0].len;
         }
         if (lane == 0) {
-            a.bid_key[n] = b[0].key;
-            if (SrcOf<Src>::kOwners) {  // k_round_small forms the maxima itself
-                a.bid_rec[n] = make_int4(b[0].obj, b[0].prev, i, s);
+            if (kHandOver) {  // (the resolve part of the same launch, in another workgroup, reads these)
+                handover_store(&a.bid_key[n], b[0].key);
+                unsigned long long *r = reinterpret_cast<unsigned long long *>(&a.bid_rec[n]);
+                handover_store(r, (unsigned long long)(unsigned)b[0].obj | ((unsigned long long)(unsigned)b[0].prev << 32));
+                handover_store(r + 1, (unsigned long long)(unsigned)i | ((unsigned long long)(unsigned)s << 32));
             } else {
-                a.bid_obj[n] = b[0].obj;
-                atomicMax(&a.best_key[b[0].obj], b[0].key);
+                a.bid_key[n] = b[0].key;
+                if (SrcOf<Src>::kOwners) {  // k_round_small forms the maxima itself
+                    a.bid_rec[n] = make_int4(b[0].obj, b[0].prev, i, s);
+                } else {
+                    a.bid_obj[n] = b[0].obj;
+                    atomicMax(&a.best_key[b[0].obj], b[0].key);
+                }
             }
         }
-        edges += (unsigned long long)b[0].len;
-        nb += 1;
+        tl.edges += (unsigned long long)b[0].len;
+        tl.nb += 1;
     }
-    __shared__ unsigned long long s_edges[kBidBlock / kWave], s_hedges[kBidBlock / kWave];
-    __shared__ int s_nb[kBidBlock / kWave], s_nh[kBidBlock / kWave];
+}
+
+template <int kWaves>
+__device__ __forceinline__ void tally_flush(const RoundArgs &a, const BidTally &tl, int K) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __shared__ unsigned long long s_edges[kWaves], s_hedges[kWaves];
+    __shared__ int s_nb[kWaves], s_nh[kWaves];
     if (lane == 0) {
-        s_edges[wave] = edges;
-        s_hedges[wave] = hit_edges;
-        s_nb[wave] = nb;
-        s_nh[wave] = nh;
-        if (err) atomicOr(&a.ctl->err, err);
+        s_edges[wave] = tl.edges;
+        s_hedges[wave] = tl.hit_edges;
+        s_nb[wave] = tl.nb;
+        s_nh[wave] = tl.nh;
+        if (tl.err) atomicOr(&a.ctl->err, tl.err);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned long long te = 0, the = 0;
         int tb = 0, th = 0;
-        for (int w = 0; w < wpb; ++w) {
+        for (int w = 0; w < kWaves; ++w) {
             te += s_edges[w];
             the += s_hedges[w];
             tb += s_nb[w];
@@ -191,7 +208,7 @@ __global__ __launch_bounds__(kBidBlock) void k_bid(RoundArgs a, E ed) {
             unsigned long long *st = a.wg_stats + (size_t)kStatWords * blockIdx.x;
             st[kStatEdges] += te;
             st[kStatBids] += (unsigned long long)tb;
-            if (a.world > 1 && a.ctl->K >= a.shard_min_K) st[kStatShardEdges] += te;
+            if (a.world > 1 && K >= a.shard_min_K) st[kStatShardEdges] += te;
             if (a.launch_edges) st[kStatLaunchEdges] += te;  // a profiled launch: claimed by k_take_launch_edges
             if (th) {
                 st[kStatHits] += (unsigned long long)th;
@@ -199,6 +216,24 @@ __global__ __launch_bounds__(kBidBlock) void k_bid(RoundArgs a, E ed) {
             }
         }
     }
+}
+
+template <class E, class Src, int kLines>
+__global__ __launch_bounds__(kBidBlock) void k_bid(RoundArgs a, E ed) {
+    static_assert(kLines == 2 || !SrcOf<Src>::kOwners, "the lean scan does not carry the owners k_round_small needs");
+    const int wave = threadIdx.x >> 6;
+    const int wpb = kBidBlock / kWave;
+    const int first = blockIdx.x * wpb + wave;
+    const Ctl *ctl = a.ctl;
+    const CtlHead head(ctl);
+    const int i_first = a.U[min(first, a.n_rows - 1)];
+    if (!head.live(a.thr, i_first < -1)) return;  // (list entries are persons or -1)
+    if (a.gather_max_K > 0 && head.K >= a.gather_max_K) return;
+    int lo, hi;
+    shard_range(head.K, a.rank, a.world, a.shard_min_K, lo, hi);
+    BidTally tl;
+    bid_positions<E, Src, kLines, false>(a, ed, lo, hi, first, gridDim.x * wpb, i_first, tl);
+    tally_flush<kBidBlock / kWave>(a, tl, head.K);
 }
 
 // Line maintenance ahead of the tail kernels (once per eps-phase, when K has fallen to the tail threshold).  The grid
@@ -734,25 +769,12 @@ __global__ __launch_bounds__(1024) void k_compact_small(RoundArgs a) {
 constexpr int kRoundSmallMax = 2048;
 constexpr int kRoundSmallSlots = kRoundSmallMax / 1024;  // list positions per thread, kept in registers
 constexpr int kRoundSmallHash = 2 * kRoundSmallMax;      // load factor <= 0.5
-__global__ __launch_bounds__(1024) void k_round_small(RoundArgs a) {
+// (the part behind the bids' arrival: k_round_small gets them from the launch before, k_round_fused from the other
+// workgroups of its own launch)
+__device__ __forceinline__ void round_small_body(const RoundArgs &a, Ctl *ctl, const CtlHead &head,
+                                                 const int4 (&br)[kRoundSmallSlots],
+                                                 const unsigned long long (&key)[kRoundSmallSlots]) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    // Everything a position needs comes from its bidder (k_bid<E, RecSource>) in two loads, requested before the
-    // control block is read (positions at or beyond K hold stale bids, masked below) and kept in registers.
-    Ctl *ctl = a.ctl;
-    const CtlHead head(ctl);
-    int4 br[kRoundSmallSlots];
-    unsigned long long key[kRoundSmallSlots];
-    bool never = false;  // (objects are >= 0, a key is the bit pattern of a finite bid + 1)
-#pragma unroll
-    for (int q = 0; q < kRoundSmallSlots; ++q) {
-        br[q] = a.bid_rec[q * 1024 + t];
-        key[q] = a.bid_key[min(q * 1024 + t, a.n_rows - 1)];
-        never |= (br[q].x < 0) | (key[q] == ~0ull);
-    }
-    if (!head.live(a.thr, never)) {
-        if (t == 0) post_live_status(a.live, a.ticket, head.K, head.err, head.nits);
-        return;
-    }
     const int K = head.K;
     __shared__ int s_cnt[16], s_wl[16], s_wm[16];
     __shared__ int s_hole[kRoundSmallMax], s_mover[kRoundSmallMax];  // push_all_left lists
@@ -876,6 +898,73 @@ __global__ __launch_bounds__(1024) void k_round_small(RoundArgs a) {
         ctl->grid_rounds += 1;
         post_live_status(a.live, a.ticket, Kn, head.err, head.nits + 1);
     }
+}
+
+__global__ __launch_bounds__(1024) void k_round_small(RoundArgs a) {
+    const int t = threadIdx.x;
+    // Everything a position needs comes from its bidder (k_bid<E, RecSource>) in two loads, requested before the
+    // control block is read (positions at or beyond K hold stale bids, masked below) and kept in registers.
+    Ctl *ctl = a.ctl;
+    const CtlHead head(ctl);
+    int4 br[kRoundSmallSlots];
+    unsigned long long key[kRoundSmallSlots];
+    bool never = false;  // (objects are >= 0, a key is the bit pattern of a finite bid + 1)
+#pragma unroll
+    for (int q = 0; q < kRoundSmallSlots; ++q) {
+        br[q] = a.bid_rec[q * 1024 + t];
+        key[q] = a.bid_key[min(q * 1024 + t, a.n_rows - 1)];
+        never |= (br[q].x < 0) | (key[q] == ~0ull);
+    }
+    if (!head.live(a.thr, never)) {
+        if (t == 0) post_live_status(a.live, a.ticket, head.K, head.err, head.nits);
+        return;
+    }
+    round_small_body(a, ctl, head, br, key);
+}
+
+// A whole round with few bidders in ONE launch: the bids of k_bid<E, RecSource, 2> by 1024-thread workgroups (one
+// wavefront per list position), and the rest of the round (round_small_body) by whichever workgroup finishes its bids
+// LAST.  Every workgroup hands its bids over and counts itself in on Ctl::arrive; nobody waits for anybody, so the
+// launch cannot hang whatever else occupies the CUs.  The hand-over does without fences: the bids are device-scope
+// atomic stores, complete (vmcnt) before the barrier behind which thread 0 counts the workgroup in with a device-scope
+// atomic; the last arriver reads them with device-scope atomic loads issued behind the barrier that hands it the
+// count.  Everything else the resolve part touches (U, records, prices, p2o / o2p) nobody wrote in this launch.
+// Saves one launch boundary per round (~5 us of ~10.5; 1 400 - 2 100 such rounds per C3 solve), and one launch in four
+// of a solve is what bounds several solves in flight on one GPU.
+template <class E>
+__global__ __launch_bounds__(1024) void k_round_fused(RoundArgs a, E ed) {
+    const int t = threadIdx.x, wave = t >> 6;
+    constexpr int wpb = 1024 / kWave;
+    const int first = blockIdx.x * wpb + wave;
+    Ctl *ctl = a.ctl;
+    const CtlHead head(ctl);
+    const int i_first = a.U[min(first, a.n_rows - 1)];
+    if (!head.live(a.thr, i_first < -1)) {  // (uniform over the launch: nobody counts in)
+        if (blockIdx.x == 0 && t == 0) post_live_status(a.live, a.ticket, head.K, head.err, head.nits);
+        return;
+    }
+    BidTally tl;
+    bid_positions<E, RecSource, 2, true>(a, ed, 0, head.K, first, gridDim.x * wpb, i_first, tl);
+    tally_flush<wpb>(a, tl, head.K);
+    __shared__ int s_arrived;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) s_arrived = __hip_atomic_fetch_add(&ctl->arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_arrived != (int)gridDim.x - 1) return;  // uniform over the workgroup
+    if (t == 0) __hip_atomic_store(&ctl->arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
+    int4 br[kRoundSmallSlots];
+    unsigned long long key[kRoundSmallSlots];
+#pragma unroll
+    for (int q = 0; q < kRoundSmallSlots; ++q) {
+        const int n = min(q * 1024 + t, a.n_rows - 1);
+        const unsigned long long *r = reinterpret_cast<const unsigned long long *>(&a.bid_rec[q * 1024 + t]);
+        const unsigned long long r0 = handover_load(r), r1 = handover_load(r + 1);
+        br[q] = make_int4((int)(unsigned)(r0 & 0xffffffffull), (int)(unsigned)(r0 >> 32), (int)(unsigned)(r1 & 0xffffffffull),
+                          (int)(unsigned)(r1 >> 32));
+        key[q] = handover_load(&a.bid_key[n]);
+    }
+    round_small_body(a, ctl, head, br, key);
 }
 
 // The status of everything enqueued so far, posted by a launch of its own: behind a batch of small rounds, whose

@@ -264,6 +264,8 @@ struct misslap_solver {
     int64_t max_iter = 0;
     int thr = -1;
     bool round_small = false;  // the current round's bids skip the global atomicMax and k_round_small finishes it
+    bool round_fused = true;   // ... in the same launch (k_round_fused); MISSLAP_ROUND_FUSED=0: two launches
+    bool round_done = false;   // the bid launch of the current round has closed it
     int cand_build_max_K = 0x7fffffff;
     int tail_round_budget = kLongRowTailBudget;
     int max_row_len = 0;
@@ -717,7 +719,9 @@ int launch_bid(misslap_solver *h) {
     h->K_exact = false;
     RoundArgs a = round_args(h);
     const long long share = h->K_ub;  // upper bound: unsharded rounds bid for every list position
-    const int grid = blocks_for(share, kBidBlock / kWave);
+    // a round with few bidders is ONE launch (k_round_fused: bids by 16-wavefront workgroups, the rest by the last of them)
+    const bool fused = h->round_small && h->round_fused;
+    const int grid = blocks_for(share, (fused ? 1024 : kBidBlock) / kWave);
     ProfRec *pr = nullptr;
     // profile 1 times the full scans only (two event records around each of the ~3000 small launches of a solve
     // cost more host time than the launches themselves); profile 2 / 3 time every launch
@@ -733,12 +737,18 @@ int launch_bid(misslap_solver *h) {
     }
     const EdgesF32 e32{h->edges32};
     const EdgesF64 e64{h->col, h->val64};
-    const dim3 g(grid), b(kBidBlock);
+    const dim3 g(grid), b(fused ? 1024 : kBidBlock);
+    if (fused) {  // the launch closes the round: it carries the round's ticket (launch_apply has nothing left to do)
+        a.live = (h->live_off || !h->live_every_round) ? nullptr : h->live_dev;
+        a.ticket = ++h->ticket;
+        h->live_valid = a.live != nullptr;
+    }
     // variant: 2 = lines used and rebuilt; 1 = lines used, lean scan, nothing built (the full-scan regime); 0 = no lines
     const int variant = !h->lines_live() ? 0 : h->K_ub > h->cand_build_max_K ? 1 : 2;
 #define MISSLAP_LAUNCH_BID(E, ED)                                                                                   \
     do {                                                                                                            \
-        if (h->round_small) MISSLAP_LAUNCH_TIMED(pr, (k_bid<E, RecSource, 2>), g, b, 0, h->stream, a, ED);          \
+        if (fused) MISSLAP_LAUNCH_TIMED(pr, (k_round_fused<E>), g, b, 0, h->stream, a, ED);                         \
+        else if (h->round_small) MISSLAP_LAUNCH_TIMED(pr, (k_bid<E, RecSource, 2>), g, b, 0, h->stream, a, ED);     \
         else if (variant == 0) MISSLAP_LAUNCH_TIMED(pr, (k_bid<E, PriceSource, 0>), g, b, 0, h->stream, a, ED);     \
         else if (variant == 1) MISSLAP_LAUNCH_TIMED(pr, (k_bid<E, PriceSource, 1>), g, b, 0, h->stream, a, ED);     \
         else MISSLAP_LAUNCH_TIMED(pr, (k_bid<E, PriceSource, 2>), g, b, 0, h->stream, a, ED);                       \
@@ -754,6 +764,7 @@ int launch_bid(misslap_solver *h) {
     }
     HIP_TRY(hipGetLastError());
     h->phase_fresh = false;
+    h->round_done = fused;
     return MISSLAP_OK;
 }
 
@@ -772,6 +783,11 @@ int launch_tiebreak(misslap_solver *h) {
 
 int launch_apply(misslap_solver *h) {
     h->ctl_fresh = false;
+    if (h->round_small && h->round_done) {  // (k_round_fused has closed the round)
+        h->round_small = h->round_done = false;
+        h->K_exact = false;
+        return MISSLAP_OK;
+    }
     RoundArgs a = round_args(h);
     // (a round that k_round_small closes posts nothing: four stores to host memory are 1.5 us on a 3-5 us kernel that
     // runs thousands of times per solve -- a batch of such rounds is followed by k_post_status instead, ensure_posted)
@@ -1270,6 +1286,8 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
         const char *e = std::getenv("MISSLAP_LIVE_STATUS");
         h->live_off = h->live_dev == nullptr || (e && e[0] == '0');
         h->live_every_round = e && e[0] == '2';
+        const char *f = std::getenv("MISSLAP_ROUND_FUSED");
+        h->round_fused = !(f && f[0] == '0');
         h->ticket = 0;
         h->live_valid = false;
     }

@@ -21,6 +21,7 @@ for p in paths:
     with open(p) as f:
         for r in csv.DictReader(f):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?")))
+all_rows = list(rows)
 lo, hi = min(r[0] for r in rows), max(r[1] for r in rows)
 t0, t1 = lo + f0 * (hi - lo), lo + f1 * (hi - lo)
 rows = [r for r in rows if r[1] > t0 and r[0] < t1]
@@ -50,4 +51,27 @@ out = {"window_ms": round(span / 1e6, 1), "kernels": len(rows), "queues_seen": l
        "in_flight_histogram": {str(k): round(v / span, 4) for k, v in sorted(hist.items())},
        "tail_in_flight_histogram": {str(k): round(v / span, 4) for k, v in sorted(hist_tail.items())},
        "queue_busy_fraction": {q: round(v / span, 3) for q, v in sorted(queues.items())}}
+# per kernel name: mean duration while nothing else runs (before the first moment with 4 kernels in flight) and in the window
+all_rows = sorted(all_rows)
+ev_all = sorted([(s, 1) for s, e, *_ in all_rows] + [(e, -1) for s, e, *_ in all_rows])
+n_all, split = 0, hi
+for t, d in ev_all:
+    n_all += d
+    if n_all >= 4:
+        split = t
+        break
+alone, crowd = defaultdict(list), defaultdict(list)
+for s, e, name, q in all_rows:
+    short = name.split("(")[0].replace("void ", "").replace("misslap::", "")
+    if e <= split:
+        alone[short].append(e - s)
+    elif s >= t0:
+        crowd[short].append(e - s)
+per = {}
+for k in sorted(crowd, key=lambda k: -sum(crowd[k]))[:14]:
+    if alone.get(k):
+        a, c = sum(alone[k]) / len(alone[k]) / 1e3, sum(crowd[k]) / len(crowd[k]) / 1e3
+        per[k] = {"alone_us": round(a, 2), "concurrent_us": round(c, 2), "ratio": round(c / a, 2), "calls": len(crowd[k]),
+                  "share_of_concurrent_kernel_time": round(sum(crowd[k]) / sum(sum(v) for v in crowd.values()), 3)}
+out["per_kernel"] = per
 print(json.dumps(out))
