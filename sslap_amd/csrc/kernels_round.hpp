@@ -41,6 +41,9 @@ struct RoundArgs {
     int2 *cand;                   // candidate lines (device_common.hpp); nullptr = none
     double *cand64;               // ... their fp64 costs (12 B/edge layout only, nullptr otherwise)
     int cand_build_max_K;         // k_bid uses and (re)builds lines only in rounds with K <= this
+    int cand_build_min_K;         // ... and rebuilds a line that missed only in rounds with K > this (below, a round lasts
+                                  // as long as its slowest bidder, and a rebuild doubles a miss: the maintenance pass ahead
+                                  // of the tail kernels rebuilds what the small rounds leave spent)
     int cand_refresh_min;         // ... and treats a hit that leaves fewer live candidates than this as a miss
     // Statistics of the bid kernels, one 64-byte slot per WORKGROUP (kStat* below), added to with plain loads / stores
     // by thread 0 of the workgroup -- launches of a stream are ordered, so nobody else touches the slot -- and summed
@@ -153,7 +156,7 @@ __device__ __forceinline__ void bid_positions(const RoundArgs &a, const E &ed, i
                 CandBuildArgs ba;
                 const typename E::Raw none[4] = {};
                 wave_bid_full<E, Src, false, false>(ed, src, s, e, none, eps, b[0], ba, tl.err);
-                if (lines && ba.want) cand_build(a.cand, a.cand64, i, ba, eps, hint);
+                if (lines && ba.want && hi > a.cand_build_min_K) cand_build(a.cand, a.cand64, i, ba, eps, hint);
             } else {
                 wave_bid_lean(ed, src, s, e, eps, b[0], tl.err);
             }
