@@ -503,7 +503,7 @@ RoundArgs round_args(misslap_solver *h) {
         const char *e = std::getenv("MISSLAP_BUILD_MIN_K");
         return e ? std::atoi(e) : kRoundSmallMax;  // (same box, 2048 vs 0: C3 400.1 vs 401.4 ms, C2 132.0 vs 132.5, C1 9.69 vs 9.85)
     }();
-    a.cand_build_min_K = build_min_env;
+    a.cand_build_min_K = (h->thr > 0 && h->line_maintenance) ? build_min_env : 0;  // (no maintenance pass: nobody else rebuilds)
     a.cand_refresh_min = h->cand_refresh_min;
     return a;
 }
