@@ -388,7 +388,9 @@ def main():
                         "GBs_algorithmic": round(e3 * bpe / (ms3 * 1e-3) / 1e9, 1) if ms3 else None,
                         "edges_read": e3 - (g3["cand_edges"] - gpu_tail_cand_edges(g3)),
                         "note": "one extra untimed solve, every bid launch timed (profile 3); edges = reference-"
-                                "equivalent row lengths of the bidders, edges_read = rows actually streamed"}
+                                "equivalent row lengths of the bidders, edges_read = rows actually streamed; since round 4 a "
+                                "launch of a round with K <= 2048 is the WHOLE round (k_round_fused: bids + resolve + "
+                                "assign + compaction), so ms is not comparable with earlier rounds' bid-only figure"}
         # SURVEY 8(d), second solve figure: one more (untimed) step from HOST arrays -- the reference's `setup` timer
         # brackets the CSR build from host arrays (auction_.pyx:206-207, :265), here that includes the H2D copy of the
         # COO input (16 B per entry, pageable numpy memory)
