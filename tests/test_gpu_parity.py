@@ -416,6 +416,77 @@ def test_tuning_knobs_do_not_change_the_result(knobs, gpu_lib):
         assert g.gpu["edges_scanned"] == o.extra["edges_scanned"], knobs
 
 
+@pytest.mark.parametrize("env", [
+    dict(MISSLAP_ROUND_FUSED="0"),                          # a round with <= 2048 bidders as k_bid + k_round_small
+    dict(MISSLAP_LIVE_STATUS="0"),                          # status reads by copy + stream wait
+    dict(MISSLAP_LIVE_STATUS="2"),                          # every round-closing kernel posts its status
+    dict(MISSLAP_LIVE_STATUS="0", MISSLAP_ROUND_FUSED="0"),
+    dict(MISSLAP_BUILD_MIN_K="0"),                          # small rounds rebuild the lines that missed
+    dict(MISSLAP_BIG_ROUNDS_BATCHED="1"),                   # big rounds enqueued without reading K in between
+])
+def test_environment_switches_do_not_change_the_result(env, gpu_lib, monkeypatch):
+    """The A/B switches of README.md (read when a handle is created) select how a round is LAUNCHED and how the host
+    learns K -- never the bids: sol, round count, prices, list order and the scanned-edge count stay the oracle's."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for seed, (n, m, dens, ints, prob, gk) in enumerate([(3000, 3000, 12.0, 0, "max", {}), (2500, 4000, 30.0, 3, "min", {}),
+                                                        (9000, 9000, 8.0, 0, "max", dict(rounds_per_sync=5)),
+                                                        (700, 700, 40.0, 0, "max", dict(tail_threshold=0))]):
+        loc, val = synth.gen_sparse(n, m, dens / m, seed=940 + seed, integer_values=ints)
+        kw = dict(problem=prob, cardinality_check=False, max_iter=10**8)
+        o = orc.from_sparse(loc, val.copy(), **kw)
+        osol = o.solve()
+        g = from_sparse(loc, val.copy(), **kw, **gk)
+        gsol = g.solve()
+        assert np.array_equal(gsol, osol), (env, n, m)
+        for k in cases.META_KEYS:
+            assert g.meta[k] == o.meta[k], (env, k)
+        sg, so = g.state(), o.state()
+        assert np.array_equal(sg["p"].view(np.uint64), so["p"].view(np.uint64)), env
+        assert np.array_equal(sg["U"][:sg["K"]], so["U"][:so["K"]]), env
+        assert g.gpu["edges_scanned"] == o.extra["edges_scanned"], env
+
+
+def test_concurrent_handles_on_one_gpu_match_the_reference(gpu_lib):
+    """Eight host threads, each creating and solving its own problems on its own handle / HIP stream at the same time
+    (what `bench.py --concurrent` does at C3): no workgroup of one handle's launches waits for another's (k_round_fused
+    hands its bids over without anybody waiting), every handle polls its own live-status words, the block and stream
+    caches are shared -- every solve is the oracle's, bit for bit."""
+    import threading
+    specs = [(1500 + 300 * k, 1500 + 300 * k + (k % 3) * 200, [6.0, 20.0, 60.0][k % 3], [0, 4][k % 2], ["max", "min"][k % 2])
+             for k in range(8)]
+    want = []
+    for k, (n, m, dens, ints, prob) in enumerate(specs):
+        loc, val = synth.gen_sparse(n, m, dens / m, seed=5100 + k, integer_values=ints)
+        o = orc.from_sparse(loc, val.copy(), problem=prob, cardinality_check=False, max_iter=10**8)
+        osol = o.solve()
+        want.append((loc, val, prob, osol, {kk: o.meta[kk] for kk in cases.META_KEYS}, o.state()["p"].view(np.uint64).copy(),
+                     o.extra["edges_scanned"]))
+    errs = []
+    go = threading.Barrier(len(specs))
+
+    def worker(k):
+        try:
+            loc, val, prob, osol, ometa, op, oedges = want[k]
+            go.wait()
+            for rep in range(3):
+                g = from_sparse(loc, val.copy(), problem=prob, cardinality_check=False, max_iter=10**8)
+                gsol = g.solve()
+                ok = (np.array_equal(gsol, osol) and all(g.meta[kk] == ometa[kk] for kk in cases.META_KEYS)
+                      and np.array_equal(g.state()["p"].view(np.uint64), op) and g.gpu["edges_scanned"] == oedges)
+                if not ok:
+                    errs.append((k, rep, "mismatch"))
+                del g
+        except Exception as e:  # noqa: BLE001
+            errs.append((k, repr(e)))
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(len(specs))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+
+
 @pytest.mark.parametrize("thr", [None, 0, 12])
 @pytest.mark.parametrize("lines", [True, False, 2])
 def test_true_fp64_values_with_and_without_lines(lines, thr, gpu_lib):
