@@ -98,7 +98,7 @@ constexpr int kDefaultTailThreshold = 192;
 // 13.7 ms, 40: 13.1
 constexpr int kDefaultTailThresholdNoLines = 40;
 constexpr int kLongRowsFrom = 1024;
-constexpr long long kLongRowsAfterTailRounds = 1500;
+constexpr long long kLongRowsAfterTailRoundsMin = 100;  // ... or n_rows / 64 tail rounds, whichever is more (launch_tail)
 // Tail rounds between two maintenance passes of a long-row handle (the tail kernels cannot rebuild the line of a long
 // row in place: a missed line stays missed until the next pass, and every miss is a scan of the whole row).  Dense
 // 8000^2: no limit 341 ms, 4096: 324, 1024: 220, 256: 121, 128: 120, 64: 144, 32: 200; with a quarter of the budget for
@@ -276,6 +276,9 @@ struct misslap_solver {
     // pure overhead: the kernels then run as for a handle without lines.
     bool lines_live() const { return cand != nullptr && (avg_row_len <= kCandRowMax || long_rows); }
     bool long_rows_later = false;  // rows of a few hundred edges: k_refresh_long only if the tail turns out long
+    long long tail_rounds_host = 0;  // rounds the tail kernels have run so far, from the round counts of the status reads
+    long long tail_nits0 = -1;       // (the control block's own counter reaches the host with a full read only)
+                                     // round count in front of the tail launches whose rounds are not yet counted; -1: none
     bool long_rows = false;  // some row is longer than kCandRowMax: k_refresh_long has work
     bool line_maintenance = true;  // k_refresh_lines ahead of the tail kernels (options.reserved[4] = 2: off)
     int cand_refresh_min = kDefaultCandRefresh;
@@ -531,6 +534,13 @@ ProfRec *prof_next(misslap_solver *h, int kind) {
 // (A status read is a stream drain: ~20 us.  A solve of a small problem is a few hundred rounds of ~1 us inside one
 // tail launch per eps-phase and was spending most of its time in the five reads per phase; with the mirror reused
 // while nothing has been enqueued since the last read, two remain.)
+// (behind every status read) the rounds of the tail launches enqueued before it
+void count_tail_rounds(misslap_solver *h) {
+    if (h->tail_nits0 < 0) return;
+    h->tail_rounds_host += h->h_ctl->nits - h->tail_nits0;
+    h->tail_nits0 = -1;
+}
+
 int read_ctl(misslap_solver *h) {
     if (h->ctl_fresh) {
         if (h->h_ctl->err)
@@ -542,6 +552,7 @@ int read_ctl(misslap_solver *h) {
     h->ctl_fresh = true;
     h->K_ub = h->h_ctl->K;
     h->K_exact = true;
+    count_tail_rounds(h);
     if (h->h_ctl->err)
         return fail(MISSLAP_ERR_STATE, "device-side invariant violated (error bits 0x%x)", h->h_ctl->err);
     return MISSLAP_OK;
@@ -593,6 +604,7 @@ int read_status(misslap_solver *h) {
     h->h_ctl->err = err;
     h->K_ub = K;
     h->K_exact = true;
+    count_tail_rounds(h);
     if (err) return fail(MISSLAP_ERR_STATE, "device-side invariant violated (error bits 0x%x)", err);
     return MISSLAP_OK;
 }
@@ -829,7 +841,17 @@ int launch_apply(misslap_solver *h) {
 int launch_tail(misslap_solver *h) {
     if (h->thr <= 0) return MISSLAP_OK;
     h->ctl_fresh = false;
-    if (h->long_rows_later && h->h_ctl->tail_rounds >= kLongRowsAfterTailRounds) {  // (status read just before)
+    // Rows of a few hundred edges keep no lines until the solve has shown that its tail is long: that many tail rounds
+    // (a tail round without a line is a row scan by one wavefront, 1.5-4 us at 300-1000 edges; the pass that builds the
+    // lines of every row costs milliseconds at C4's 100 000 rows and pays for itself within a phase at a dense
+    // 1000 x 1000).  The tail kernels of such a handle return after as many rounds, so that a first phase with thousands
+    // of tail rounds does not run to its end without lines (dense 1000^2: 13 of 16 ms were its first two tail launches).
+    static const long long after_env = [] {
+        const char *e = std::getenv("MISSLAP_LONG_AFTER_TAIL_ROUNDS");
+        return e ? std::atoll(e) : -1ll;
+    }();
+    const long long long_after = after_env >= 0 ? after_env : std::max<long long>(kLongRowsAfterTailRoundsMin, h->n_rows / 64);
+    if (h->long_rows_later && h->tail_rounds_host >= long_after) {  // (status read just before)
         h->long_rows = true;
         h->long_rows_later = false;
     }
@@ -848,7 +870,9 @@ int launch_tail(misslap_solver *h) {
         const char *e = std::getenv("MISSLAP_LONG_TAIL_BUDGET");
         return e ? std::atoi(e) : 0;
     }();
-    a.round_budget = h->long_rows && lines && h->line_maintenance ? (budget_env > 0 ? budget_env : h->tail_round_budget) : 0;
+    a.round_budget = h->long_rows && lines && h->line_maintenance ? (budget_env > 0 ? budget_env : h->tail_round_budget)
+                     : h->long_rows_later                            ? (int)std::min<long long>(std::max<long long>(long_after, 1), 1 << 30)
+                                                                     : 0;
     a.thr = h->thr;
     a.eps = h->eps;
     ProfRec *pr = nullptr;
@@ -900,6 +924,7 @@ int launch_tail(misslap_solver *h) {
                        h->o2p, h->p2o, h->n_cols, h->cand != nullptr ? 1 : 0, h->live_valid ? h->live_dev : nullptr, ++h->ticket);
     HIP_TRY(hipGetLastError());
     h->phase_fresh = false;
+    if (h->tail_nits0 < 0) h->tail_nits0 = h->h_ctl->nits;  // (the status read in front of this launch)
     return MISSLAP_OK;
 }
 
@@ -1066,9 +1091,13 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
     const long long avg_row = nnz / h->n_rows;
     h->avg_row_len = avg_row;
     h->max_row_len = st.max_row_len;
-    h->long_rows = st.max_row_len > kCandRowMax && avg_row >= kLongRowsFrom && avg_row <= kCandLongMax;
+    static const long long long_from_env = [] {
+        const char *e = std::getenv("MISSLAP_LONG_ROWS_FROM");
+        return e ? std::atoll(e) : (long long)kLongRowsFrom;
+    }();
+    h->long_rows = st.max_row_len > kCandRowMax && avg_row >= long_from_env && avg_row <= kCandLongMax;
     // ... below that (C4's 300 edges per row, a dense 600^2) only once the solve has shown that its tail is long:
-    // launch_tail switches the builder on after kLongRowsAfterTailRounds tail rounds
+    // launch_tail switches the builder on after max(100, n_rows / 64) tail rounds
     h->long_rows_later = !h->long_rows && avg_row > kCandRowMax && avg_row <= kCandLongMax && cand_mode != 1;
     if (h->thr < 0) {  // library default: by whether the persons will have candidate lines (rows of <= 256 edges)
         const bool lines = cand_mode != 1 && (avg_row <= kCandRowMax || h->long_rows);
