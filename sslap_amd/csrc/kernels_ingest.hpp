@@ -12,6 +12,7 @@ struct IngestStats {
     int err;          // kErr* bits
     int not_f32;      // some value is not exactly representable in fp32
     int max_row_len;  // longest row (k_max_row_len): decides whether the long-row line builder has work
+    int long_rows;    // rows of more than kCandRowMax edges (the scans of the bid kernels cannot rebuild their lines)
     long long dense_total;  // dense ingest: number of valid entries, counted in 64 bits
 };
 
@@ -148,12 +149,19 @@ __global__ __launch_bounds__(256) void k_init_state(Ctl *ctl, double *price, Pri
 }
 
 __global__ __launch_bounds__(256) void k_max_row_len(const int *row_ptr, int n_rows, IngestStats *st) {
-    int m = 0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_rows; i += gridDim.x * blockDim.x)
-        m = max(m, row_ptr[i + 1] - row_ptr[i]);
-    for (int off = 32; off >= 1; off >>= 1) m = max(m, __shfl_xor(m, off));
+    int m = 0, nl = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_rows; i += gridDim.x * blockDim.x) {
+        const int len = row_ptr[i + 1] - row_ptr[i];
+        m = max(m, len);
+        nl += len > kCandRowMax;
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        m = max(m, __shfl_xor(m, off));
+        nl += __shfl_xor(nl, off);
+    }
     if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(&st->max_row_len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
         atomicMax(&st->max_row_len, m);
+    if ((threadIdx.x & 63) == 0 && nl) atomicAdd(&st->long_rows, nl);
 }
 
 // ---- dense ingest (_from_matrix, auction_.pyx:546-557): keep v >= 0 in row-major order -----------------

@@ -98,6 +98,7 @@ constexpr int kDefaultTailThreshold = 192;
 // 13.7 ms, 40: 13.1
 constexpr int kDefaultTailThresholdNoLines = 40;
 constexpr int kLongRowsFrom = 1024;
+constexpr int kLongRowsMixedPercent = 20;
 constexpr long long kLongRowsAfterTailRoundsMin = 100;  // ... or n_rows / 64 tail rounds, whichever is more (launch_tail)
 // Tail rounds between two maintenance passes of a long-row handle (the tail kernels cannot rebuild the line of a long
 // row in place: a missed line stays missed until the next pass, and every miss is a scan of the whole row).  Dense
@@ -1098,7 +1099,16 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
     h->long_rows = st.max_row_len > kCandRowMax && avg_row >= long_from_env && avg_row <= kCandLongMax;
     // ... below that (C4's 300 edges per row, a dense 600^2) only once the solve has shown that its tail is long:
     // launch_tail switches the builder on after max(100, n_rows / 64) tail rounds
-    h->long_rows_later = !h->long_rows && avg_row > kCandRowMax && avg_row <= kCandLongMax && cand_mode != 1;
+    // (... and so do the long rows of a handle whose AVERAGE row keeps a line, where they are many: 40 000 rows of 256
+    // edges on average, half of them longer: 208 -> 119 ms per solve; a few stragglers -- C3 has rows of 260 edges -- are left
+    // to their scans, a pass over all rows every few hundred tail rounds costs more than they do)
+    static const int mixed_pct_env = [] {
+        const char *e = std::getenv("MISSLAP_LONG_MIXED_PCT");
+        return e ? std::atoi(e) : kLongRowsMixedPercent;
+    }();
+    const bool many_long = (long long)st.long_rows * 100 >= (long long)mixed_pct_env * h->n_rows;
+    h->long_rows_later = !h->long_rows && (avg_row > kCandRowMax || (st.max_row_len > kCandRowMax && many_long)) &&
+                         avg_row <= kCandLongMax && cand_mode != 1;
     if (h->thr < 0) {  // library default: by whether the persons will have candidate lines (rows of <= 256 edges)
         const bool lines = cand_mode != 1 && (avg_row <= kCandRowMax || h->long_rows);
         h->thr = lines ? kDefaultTailThreshold : kDefaultTailThresholdNoLines;
