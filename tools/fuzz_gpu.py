@@ -24,6 +24,10 @@ for seed in range(first, first + count):
         n = int(r.choice([1030, 1200]))
         m = n if r.random() < 0.5 else n + int(r.integers(1, 400))
         density = float(r.choice([0.9, 1.0]))
+    if seed % 10 == 8:  # rows around / above the 256 edges a bid kernel's scan can rebuild a line from: lines by the
+        n = int(r.choice([600, 900, 1400]))  # maintenance pass only, switched on after ~100 tail rounds (mixed handles too)
+        m = n if r.random() < 0.5 else n + int(r.integers(1, 300))
+        density = float(r.choice([250.0, 262.0, 300.0, 520.0])) / m
     loc, val = synth.gen_sparse(n, m, density, seed=900 + seed, integer_values=ints)
     if seed % 3 == 2:  # values that are not fp32-exact: the 12 B/edge layout (lines with fp64 cost lines)
         val = val + r.random(val.shape[0]) * 1e-7
