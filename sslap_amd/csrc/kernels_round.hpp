@@ -942,7 +942,11 @@ __global__ __launch_bounds__(1024) void k_round_fused(RoundArgs a, E ed) {
     Ctl *ctl = a.ctl;
     const CtlHead head(ctl);
     const int i_first = a.U[min(first, a.n_rows - 1)];
-    if (!head.live(a.thr, i_first < -1)) {  // (uniform over the launch: nobody counts in)
+    // (the exit below depends on the control block ALONE -- it must be the same in every workgroup of the launch, or
+    // the count-in would never complete -- and the list entry is requested ahead of it all the same: the empty asm
+    // makes it a value the code in front of the exit needs)
+    asm volatile("" ::"v"(i_first));
+    if (!head.live(a.thr, false)) {  // (uniform over the launch: nobody counts in)
         if (blockIdx.x == 0 && t == 0) post_live_status(a.live, a.ticket, head.K, head.err, head.nits);
         return;
     }
@@ -1010,6 +1014,7 @@ __global__ __launch_bounds__(256) void k_reset_phase(Ctl *ctl, int *p2o, int *o2
         ctl->K = n_rows;
         ctl->nholes = 0;
         ctl->nleft = 0;
+        ctl->arrive = 0;  // (k_round_fused leaves it at 0 itself; a phase starts from a known count whatever came before)
     }
 }
 
