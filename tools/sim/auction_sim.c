@@ -104,6 +104,9 @@ int main(int argc, char **argv) {
     for (int a = 0; a < NL; ++a) ltag[a] = malloc(sizeof(int) * lsz[a]), memset(ltag[a], 0xff, sizeof(int) * lsz[a]);
     for (int a = 0; a < NR; ++a) rtag[a] = malloc(sizeof(int) * rsz[a]), memset(rtag[a], 0xff, sizeof(int) * rsz[a]);
     int64_t lds_bids[7] = {0}, lds_lhit[7][NL] = {{0}}, lds_recs[7] = {0}, lds_rhit[7][NR] = {{0}}, lds_allrec[7][NR] = {{0}};
+    const int f32_mode = getenv("SIM_F32") ? atoi(getenv("SIM_F32")) : 0;
+    const int f32_min_K = (int)(0.3 * N);
+    int64_t f32_hist[17] = {0}, f32_bids = 0, f32_round_over4 = 0;
     FILE *trace = getenv("SIM_TRACE") ? fopen(getenv("SIM_TRACE"), "wb") : NULL;
     const int trace_thr = getenv("SIM_TRACE_THR") ? atoi(getenv("SIM_TRACE_THR")) : 256;
     for (;;) {
@@ -123,6 +126,23 @@ int main(int argc, char **argv) {
                 const double v = val[g] - p[col[g]];
                 if (v >= vbest || g == s) jbest = col[g], wi = vbest, vbest = v, costbest = val[g];
                 else if (v > wi) wi = v;
+            }
+            if (f32_mode && K >= f32_min_K) { /* how many edges a single-precision filter could not tell from the top two */
+                float b32 = -INFINITY, w32 = -INFINITY;
+                double pmax = 0, vmax = 0;
+                for (int g = s; g < e; ++g) {
+                    const float v = (float)val[g] - (float)p[col[g]];
+                    if (v >= b32) w32 = b32, b32 = v;
+                    else if (v > w32) w32 = v;
+                    if (fabs(p[col[g]]) > pmax) pmax = fabs(p[col[g]]);
+                    if (fabs(val[g]) > vmax) vmax = fabs(val[g]);
+                }
+                const double delta = (pmax + 2.0 * (pmax + vmax)) * 0x1p-24; /* rounding of the price + of the difference, generous */
+                int cnt = 0;
+                for (int g = s; g < e; ++g) cnt += (double)((float)val[g] - (float)p[col[g]]) >= (double)w32 - 2.0 * delta;
+                f32_hist[cnt < 2 ? 2 : cnt > 16 ? 16 : cnt]++;
+                f32_bids++;
+                if (cnt > 4) f32_round_over4++;
             }
             if (C > 0 && (use || build)) {
                 int hit = 0, alive = 0;
@@ -304,6 +324,11 @@ int main(int argc, char **argv) {
             for (int a = 0; a < NR; ++a) printf("%s\"%d\": %.4f", a ? ", " : "", rsz[a], (double)lds_allrec[m][a] / lds_bids[m]);
             printf("}}");
         }
+    }
+    if (f32_mode) {
+        fprintf(stderr, "f32 filter, bids of rounds with K >= 0.3 N: %lld; edges within the margin of the second-best (2, 3, ..., 16+): ", (long long)f32_bids);
+        for (int k = 2; k <= 16; ++k) fprintf(stderr, "%.5f ", (double)f32_hist[k] / (double)(f32_bids ? f32_bids : 1));
+        fprintf(stderr, "; more than 4: %.5f\n", (double)f32_round_over4 / (double)(f32_bids ? f32_bids : 1));
     }
     printf("],\n \"rounds_by_K\": [");
     for (int k = 1; k <= 32; ++k) printf("%s%lld", k > 1 ? ", " : "", (long long)khist[k]);
