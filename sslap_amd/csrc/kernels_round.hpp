@@ -980,6 +980,11 @@ __global__ __launch_bounds__(1024) void k_round_fused(RoundArgs a, E ed) {
 __global__ void k_post_status(const Ctl *ctl, unsigned long long *live, unsigned ticket) {
     post_live_status(live, ticket, ctl->K, ctl->err, ctl->nits);
 }
+// ... and, behind the eCE pass of a phase end, its verdict in a fifth word
+__global__ void k_post_ece(const Ctl *ctl, unsigned long long *live, unsigned ticket) {
+    post_live_status(live, ticket, ctl->K, ctl->err, ctl->nits);
+    __hip_atomic_store(&live[4], ((unsigned long long)ticket << 32) | (unsigned)ctl->ece_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 __global__ void k_round_end(RoundArgs a) {
     Ctl *ctl = a.ctl;
@@ -1015,6 +1020,7 @@ __global__ __launch_bounds__(256) void k_reset_phase(Ctl *ctl, int *p2o, int *o2
         ctl->nholes = 0;
         ctl->nleft = 0;
         ctl->arrive = 0;  // (k_round_fused leaves it at 0 itself; a phase starts from a known count whatever came before)
+        ctl->ece_fail = 0;  // (the eCE test at the end of this phase finds its flag clear: no fill launch in front of it)
     }
 }
 

@@ -298,7 +298,9 @@ struct misslap_solver {
     bool profile = false;
     int K_ub = 0;  // host-side upper bound of K (K never grows inside a phase)
     bool K_exact = false;  // K_ub was read from the device and no round has been enqueued since
-    bool ctl_fresh = false;  // the pinned mirror h_ctl equals the device's control block (nothing enqueued since the read)
+    bool ece_flag_clear = false;  // Ctl::ece_fail is 0 on the device (k_init_state, k_reset_phase) and no test has run since
+    int ctl_fresh = 0;  // nothing enqueued since the last read and the pinned mirror h_ctl holds: 2 = the device's whole
+                        // control block (read_ctl), 1 = its K / nits / error bits (a live status read), 0 = neither
     bool phase_fresh = true;  // no round of the current eps-phase has been enqueued yet
     std::vector<ProfRec> prof;
     size_t prof_used = 0;
@@ -547,14 +549,14 @@ void count_tail_rounds(misslap_solver *h) {
 }
 
 int read_ctl(misslap_solver *h) {
-    if (h->ctl_fresh) {
+    if (h->ctl_fresh == 2) {
         if (h->h_ctl->err)
             return fail(MISSLAP_ERR_STATE, "device-side invariant violated (error bits 0x%x)", h->h_ctl->err);
         return MISSLAP_OK;
     }
     HIP_TRY(hipMemcpyAsync(h->h_ctl, h->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    h->ctl_fresh = true;
+    h->ctl_fresh = 2;
     h->K_ub = h->h_ctl->K;
     h->K_exact = true;
     count_tail_rounds(h);
@@ -596,7 +598,11 @@ void ensure_posted(misslap_solver *h) {
     h->live_valid = true;
 }
 int read_status(misslap_solver *h) {
-    if (h->ctl_fresh || h->live_off) return read_ctl(h);
+    if (h->ctl_fresh == 2 || h->live_off) return read_ctl(h);
+    if (h->ctl_fresh == 1) {  // (K, nits and the error bits of the mirror are current)
+        if (h->h_ctl->err) return fail(MISSLAP_ERR_STATE, "device-side invariant violated (error bits 0x%x)", h->h_ctl->err);
+        return MISSLAP_OK;
+    }
     ensure_posted(h);
     int K = 0, err = 0;
     long long nits = 0;
@@ -996,11 +1002,42 @@ int run_ece(misslap_solver *h, float eps, int *ok) {
         return MISSLAP_OK;
     }
     h->ctl_fresh = false;
-    HIP_TRY(hipMemsetAsync(&h->ctl->ece_fail, 0, sizeof(int), h->stream));
+    // (the flag is clear behind the state initialisation and behind every k_reset_phase: one runtime fill kernel less
+    // per phase; a second test on the same state -- misslap_check_ece -- clears it itself)
+    if (!h->ece_flag_clear) HIP_TRY(hipMemsetAsync(&h->ctl->ece_fail, 0, sizeof(int), h->stream));
+    h->ece_flag_clear = false;
     const FinalOut fo{0, h->maximize, h->o2p, h->contrib, h->nmatch, h->n_rows, h->n_cols, nullptr};
     const int sample = std::min(h->n_rows, kEceSampleRows);
     if ((rc = launch_rows_gather(h, eps, fo, sample))) return rc;
     if (sample < h->n_rows && (rc = launch_rows_all(h, eps, fo))) return rc;
+    if (!h->live_off) {  // the verdict through the live words: no copy of the control block, no stream drain
+        hipLaunchKernelGGL(k_post_ece, dim3(1), dim3(1), 0, h->stream, h->ctl, h->live_dev, ++h->ticket);
+        h->live_valid = true;
+        int K = 0, err = 0;
+        long long nits = 0;
+        if (live_poll(h, h->ticket, true, &K, &err, &nits)) {
+            volatile unsigned long long *w = h->live + 4;
+            unsigned long long v = *w;
+            for (unsigned spins = 0; (unsigned)(v >> 32) != h->ticket && spins < (1u << 26); ++spins) {
+                __builtin_ia32_pause();
+                v = *w;
+            }
+            if ((unsigned)(v >> 32) == h->ticket) {
+                h->h_ctl->K = K;
+                h->h_ctl->nits = nits;
+                h->h_ctl->err = err;
+                h->h_ctl->ece_fail = (int)(unsigned)(v & 0xffffffffull);
+                h->K_ub = K;
+                h->K_exact = true;
+                h->ctl_fresh = 1;
+                count_tail_rounds(h);
+                if (err) return fail(MISSLAP_ERR_STATE, "device-side invariant violated (error bits 0x%x)", err);
+                *ok = h->h_ctl->ece_fail ? 0 : 1;
+                return MISSLAP_OK;
+            }
+        }
+        h->live_off = true;  // timed out: from here on by copy + drain
+    }
     rc = read_ctl(h);
     if (rc) return rc;
     *ok = h->h_ctl->ece_fail ? 0 : 1;
@@ -1328,7 +1365,7 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
         char *base = reinterpret_cast<char *>(h->h_ctl + 3);
         base += (64 - (reinterpret_cast<uintptr_t>(base) & 63)) & 63;
         h->live = reinterpret_cast<volatile unsigned long long *>(base);
-        for (int k = 0; k < 4; ++k) h->live[k] = 0ull;  // ticket 0 = nothing posted (tickets start at 1)
+        for (int k = 0; k < 5; ++k) h->live[k] = 0ull;  // ticket 0 = nothing posted (tickets start at 1); [4]: the eCE verdict
         void *dev = nullptr;
         if (hipHostGetDevicePointer(&dev, base, 0) == hipSuccess) h->live_dev = static_cast<unsigned long long *>(dev);
         const char *e = std::getenv("MISSLAP_LIVE_STATUS");
@@ -1353,6 +1390,7 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
                        h->ctl, h->price, h->rec, h->p2o, h->o2p, h->U, h->best_key, h->best_pos, h->cand, h->n_rows, h->n_cols,
                        (long long)h->max_iter);
     HIP_TRY(hipGetLastError());
+    h->ece_flag_clear = true;
     // eps schedule, fp32 exactly as the generated C of the reference
     double max_abs;
     {
@@ -2095,6 +2133,7 @@ MISSLAP_API int misslap_phase_end(misslap_solver *h, int32_t *finished) {
             h->h_ctl->nholes = 0;
             h->h_ctl->nleft = 0;
             h->phase_fresh = true;
+            h->ece_flag_clear = true;
         }
     }
     if (finished) *finished = h->finished ? 1 : 0;
