@@ -694,14 +694,23 @@ __device__ __forceinline__ void compact_small_body(const RoundArgs &a, Ctl *ctl,
     __shared__ int s_w[2][2][kQ][16];  // [pass parity][left holes / movers][quarter][wavefront]
     if (nholes > 0) {
         int run_l = 0, run_m = 0, par = 0;  // (uniform)
+        // The list entries of pass p + 1 are requested while pass p is worked on, and the barrier of a pass is an
+        // LDS-only one (the per-wavefront counts are all that crosses it; the list stores are read behind the full
+        // barrier at the end), so the request stays in flight across it: one exposed memory latency per CALL instead
+        // of one per pass (K = 20 000: 5 passes; the kernel 10 -> 6 us at C4's mid rounds).
+        int un[kQ];
+#pragma unroll
+        for (int q = 0; q < kQ; ++q) un[q] = a.U[min(q * 1024 + t, K - 1)];
         for (int base = 0; base < K; base += kQ * 1024, par ^= 1) {
             int u[kQ];
             unsigned long long bl[kQ], bm[kQ];
             bool isl[kQ], ism[kQ];
 #pragma unroll
-            for (int q = 0; q < kQ; ++q) {
-                const int n = base + q * 1024 + t;
-                u[q] = a.U[min(n, K - 1)];  // unconditional (a load inside a branch is waited for at once), masked below
+            for (int q = 0; q < kQ; ++q) u[q] = un[q];
+#pragma unroll
+            for (int q = 0; q < kQ; ++q) {  // unconditional (a load inside a branch is waited for at once), masked below
+                const int n = base + kQ * 1024 + q * 1024 + t;
+                un[q] = a.U[min(n, K - 1)];
             }
 #pragma unroll
             for (int q = 0; q < kQ; ++q) {
@@ -715,19 +724,25 @@ __device__ __forceinline__ void compact_small_body(const RoundArgs &a, Ctl *ctl,
                     s_w[par][1][q][wave] = __popcll(bm[q]);
                 }
             }
-            __syncthreads();
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (LDS only: the next pass's loads stay in flight)
+            const int wave_s = __builtin_amdgcn_readfirstlane(wave);
 #pragma unroll
             for (int q = 0; q < kQ; ++q) {
                 const int n = base + q * 1024 + t;
-                int wl = 0, wm = 0, tl = 0, tm = 0;
-#pragma unroll
-                for (int w2 = 0; w2 < 16; ++w2) {
-                    const int x = s_w[par][0][q][w2], y = s_w[par][1][q][w2];
-                    wl += w2 < wave ? x : 0;
-                    wm += w2 < wave ? y : 0;
-                    tl += x;
-                    tm += y;
-                }
+                // the 16 wavefronts' counts in lanes 0..15 (one DPP row): inclusive scan by row shifts, my wavefront's
+                // exclusive prefix and the total by readlane -- 2 LDS reads per quarter instead of 32
+                const int cx = lane < 16 ? s_w[par][0][q][lane & 15] : 0, cy = lane < 16 ? s_w[par][1][q][lane & 15] : 0;
+                int x = cx, y = cy;
+                x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);  // row_shr:1 (lanes shifted in from outside read 0)
+                y += __builtin_amdgcn_update_dpp(0, y, 0x111, 0xF, 0xF, true);
+                x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);
+                y += __builtin_amdgcn_update_dpp(0, y, 0x112, 0xF, 0xF, true);
+                x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);
+                y += __builtin_amdgcn_update_dpp(0, y, 0x114, 0xF, 0xF, true);
+                x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);
+                y += __builtin_amdgcn_update_dpp(0, y, 0x118, 0xF, 0xF, true);
+                const int wl = __builtin_amdgcn_readlane(x - cx, wave_s), wm = __builtin_amdgcn_readlane(y - cy, wave_s);
+                const int tl = __builtin_amdgcn_readlane(x, 15), tm = __builtin_amdgcn_readlane(y, 15);
                 if (isl[q]) a.hole_list[run_l + wl + __popcll(bl[q] & lanemask_lt())] = n;
                 if (ism[q]) {
                     a.mover_list[run_m + wm + __popcll(bm[q] & lanemask_lt())] = u[q];
@@ -864,15 +879,20 @@ __device__ __forceinline__ void round_small_body(const RoundArgs &a, Ctl *ctl, c
             s_wm[wave] = __popcll(bm);
         }
         __syncthreads();
-        int wl = 0, wm = 0, tl = 0, tm = 0;
-        for (int w2 = 0; w2 < 16; ++w2) {
-            if (w2 < wave) {
-                wl += s_wl[w2];
-                wm += s_wm[w2];
-            }
-            tl += s_wl[w2];
-            tm += s_wm[w2];
-        }
+        // (the 16 wavefronts' counts in one DPP row, scanned by row shifts: see compact_small_body)
+        const int cx = lane < 16 ? s_wl[lane & 15] : 0, cy = lane < 16 ? s_wm[lane & 15] : 0;
+        int x = cx, y = cy;
+        x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);
+        y += __builtin_amdgcn_update_dpp(0, y, 0x111, 0xF, 0xF, true);
+        x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);
+        y += __builtin_amdgcn_update_dpp(0, y, 0x112, 0xF, 0xF, true);
+        x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);
+        y += __builtin_amdgcn_update_dpp(0, y, 0x114, 0xF, 0xF, true);
+        x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);
+        y += __builtin_amdgcn_update_dpp(0, y, 0x118, 0xF, 0xF, true);
+        const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+        const int wl = __builtin_amdgcn_readlane(x - cx, wave_s), wm = __builtin_amdgcn_readlane(y - cy, wave_s);
+        const int tl = __builtin_amdgcn_readlane(x, 15), tm = __builtin_amdgcn_readlane(y, 15);
         if (ism) {
             s_mover[cm + wm + __popcll(bm & lanemask_lt())] = u[q];
             u[q] = -1;  // data[right_track] = -1   (:159)
