@@ -74,15 +74,22 @@ __device__ __forceinline__ int apply_winner(const TailArgs &a, int person, int p
     return prev;  // evicted owner inherits the slot (:409); -1 = hole (:412)
 }
 
-// After the tail kernel: price[j], o2p[j] from the records; p2o rebuilt as the inverse of o2p.
-__global__ __launch_bounds__(256) void k_sync_clear_p2o(Ctl *ctl, int *p2o, int n_rows) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_rows; i += gridDim.x * blockDim.x) p2o[i] = -1;
-    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->n_need = 0;  // the maintenance pass's work list has been consumed
-}
+// After the tail kernels: price[j], o2p[j] from the records, and p2o as the inverse of o2p.  p2o needs no clearing pass:
+// every person is either the owner of exactly one record (written below) or unassigned, and the unassigned persons are
+// the list U[0, K) -- K <= the tail threshold of them.
 __global__ __launch_bounds__(256) void k_sync_from_rec(Ctl *ctl, const PriceRec *rec, double *price, int *o2p, int *p2o,
-                                                       int n_cols, int lines, unsigned long long *live, unsigned ticket) {
+                                                       const int *U, int n_cols, int lines, unsigned long long *live,
+                                                       unsigned ticket) {
+    const int K = ctl->K;
     // (closes a run of tail kernels: K / nits are theirs; an error bit raised below reaches the host with the next status)
-    if (blockIdx.x == 0 && threadIdx.x == 0) post_live_status(live, ticket, ctl->K, ctl->err, ctl->nits);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        post_live_status(live, ticket, K, ctl->err, ctl->nits);
+        ctl->n_need = 0;  // the maintenance pass's work list has been consumed
+    }
+    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < K; n += gridDim.x * blockDim.x) {
+        const int i = U[n];
+        if (i >= 0) p2o[i] = -1;
+    }
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n_cols; j += gridDim.x * blockDim.x) {
         const PriceRec r = rec[j];
         // price[] still holds the prices the tail kernels started from: a price may only have risen since (the

@@ -929,10 +929,9 @@ int launch_tail(misslap_solver *h) {
 #undef MISSLAP_LAUNCH_TAIL
     if (pr) HIP_TRY(hipEventRecord(pr->stop, h->stream));
     // the tail keeps only the price records current: rebuild price / o2p / p2o from them
-    hipLaunchKernelGGL(k_sync_clear_p2o, dim3(blocks_for(h->n_rows, 256)), dim3(256), 0, h->stream, h->ctl, h->p2o, h->n_rows);
     h->live_valid = !h->live_off && h->live_dev != nullptr;
     hipLaunchKernelGGL(k_sync_from_rec, dim3(blocks_for(h->n_cols, 256)), dim3(256), 0, h->stream, h->ctl, h->rec, h->price,
-                       h->o2p, h->p2o, h->n_cols, h->cand != nullptr ? 1 : 0, h->live_valid ? h->live_dev : nullptr, ++h->ticket);
+                       h->o2p, h->p2o, h->U, h->n_cols, h->cand != nullptr ? 1 : 0, h->live_valid ? h->live_dev : nullptr, ++h->ticket);
     HIP_TRY(hipGetLastError());
     h->phase_fresh = false;
     if (h->tail_nits0 < 0) h->tail_nits0 = h->h_ctl->nits;  // (the status read in front of this launch)
