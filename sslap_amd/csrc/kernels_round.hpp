@@ -5,7 +5,8 @@
 //   k_tiebreak  "first bidder in list order wins equal bids" (strict '>' at :379)
 //   k_apply     ASSIGN phase (:388-427), one thread per object instead of the O(M) sequential walk
 //   k_compact_* push_all_left (:137-162, called at :430) as two counting passes + scatter
-//   k_round_end K += evicted - assigned (:429), nits += 1 (:273)
+//   round end   K += evicted - assigned (:429), nits += 1 (:273): by the kernel that closes the round (k_compact_fill,
+//               k_compact_small, k_round_fused)
 // Every kernel is a no-op unless the round is live (K > tail_threshold, nits < max_iter), so the
 // host can enqueue several rounds without reading K back.
 #pragma once
@@ -669,13 +670,34 @@ __global__ __launch_bounds__(256) void k_compact_scatter(RoundArgs a) {
     }
 }
 
+// ... and the round's end (K += evicted - assigned :429, nits += 1 :273; a launch of one thread until round 4): every
+// workgroup reads the control block when it starts and counts itself in on Ctl::arrive when it is done; the one that
+// arrives last knows that nobody reads the old K any more and writes the new one.
 __global__ __launch_bounds__(256) void k_compact_fill(RoundArgs a) {
-    const Ctl *ctl = a.ctl;
-    if (!round_live(ctl, a.thr)) return;
-    if (ctl->nholes == 0) return;
-    const int nl = ctl->nleft;
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nl; k += gridDim.x * blockDim.x)
-        a.U[a.hole_list[k]] = a.mover_list[k];  // data[left_track] = i   (:158)
+    Ctl *ctl = a.ctl;
+    const CtlHead head(ctl);
+    if (!head.live(a.thr, false)) {  // (uniform over the launch)
+        if (blockIdx.x == 0 && threadIdx.x == 0) post_live_status(a.live, a.ticket, head.K, head.err, head.nits);
+        return;
+    }
+    const int nholes = ctl->nholes;
+    if (nholes != 0) {
+        const int nl = ctl->nleft;
+        for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nl; k += gridDim.x * blockDim.x)
+            a.U[a.hole_list[k]] = a.mover_list[k];  // data[left_track] = i   (:158)
+    }
+    __syncthreads();  // (every thread of the workgroup has read what it needs of the control block)
+    if (threadIdx.x == 0 &&
+        __hip_atomic_fetch_add(&ctl->arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
+        __hip_atomic_store(&ctl->arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
+        const int Kn = head.K - nholes;
+        ctl->K = Kn;  // :429
+        ctl->nholes = 0;
+        ctl->nleft = 0;
+        ctl->nits = head.nits + 1;  // :273
+        ctl->grid_rounds += 1;
+        post_live_status(a.live, a.ticket, Kn, head.err, head.nits + 1);
+    }
 }
 
 // push_all_left + round end in ONE launch for moderate K: a single 1024-thread workgroup walks U[0,K) in
@@ -1004,22 +1026,6 @@ __global__ void k_post_status(const Ctl *ctl, unsigned long long *live, unsigned
 __global__ void k_post_ece(const Ctl *ctl, unsigned long long *live, unsigned ticket) {
     post_live_status(live, ticket, ctl->K, ctl->err, ctl->nits);
     __hip_atomic_store(&live[4], ((unsigned long long)ticket << 32) | (unsigned)ctl->ece_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-__global__ void k_round_end(RoundArgs a) {
-    Ctl *ctl = a.ctl;
-    const CtlHead head(ctl);
-    if (!head.live(a.thr, false)) {
-        post_live_status(a.live, a.ticket, head.K, head.err, head.nits);
-        return;
-    }
-    const int Kn = head.K - ctl->nholes;
-    ctl->K = Kn;  // :429
-    ctl->nholes = 0;
-    ctl->nleft = 0;
-    ctl->nits = head.nits + 1;      // :273
-    ctl->grid_rounds += 1;
-    post_live_status(a.live, a.ticket, Kn, head.err, head.nits + 1);
 }
 
 // eps-phase restart (auction_.pyx:286-290): forget assignments, keep prices.

@@ -253,17 +253,17 @@ __global__ __launch_bounds__(256) void k_tile_scatter(const int2 *edges, const i
 // lines: PMC showed up to 521 MB of reads for such a round at C3 -- more than the 337 MB of a FULL scan.  So the
 // bidders of a partial round are taken in person order: rank of person i = number of unassigned persons below i
 // (p2o[i] == -1), and the bid is stored at the person's true list position (the tie rule of :379 is about list
-// positions).  Four small launches ahead of the bid kernel: inverse of U, chunk counts, scan of the counts (the ingest's
-// k_scan_of_sums), ranks + scatter.
+// positions).  Two small launches ahead of the bid kernel (four until round 4): k_order_prepare -- the inverse of U and
+// the chunk counts, which do not depend on each other -- and k_order_scatter, whose workgroups add up the counts of the
+// chunks in front of theirs themselves (at most a few hundred) instead of waiting for a scan launch.
 // (thr / min_K: the scan these kernels prepare runs only in a live round with K >= min_K -- otherwise nothing to do)
 __device__ __forceinline__ bool order_needed(const Ctl *ctl, int thr, int min_K) { return round_live(ctl, thr) && ctl->K >= min_K; }
-__global__ __launch_bounds__(256) void k_order_inverse(const Ctl *ctl, const int *U, int *pos_of, int thr, int min_K) {
+__global__ __launch_bounds__(1024) void k_order_prepare(const Ctl *ctl, const int *U, int *pos_of, const int *p2o, int n_rows,
+                                                        int nchunks, int *sums, int thr, int min_K) {
     if (!order_needed(ctl, thr, min_K)) return;
     const int K = ctl->K;
     for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < K; n += gridDim.x * blockDim.x) pos_of[U[n]] = n;
-}
-__global__ __launch_bounds__(1024) void k_order_sums(const Ctl *ctl, const int *p2o, int n_rows, int *sums, int thr, int min_K) {
-    if (!order_needed(ctl, thr, min_K)) return;
+    if ((int)blockIdx.x >= nchunks) return;  // (uniform over the workgroup; the grid covers the list AND the chunks)
     __shared__ int s_w[16];
     const int base = blockIdx.x * kScanChunk;
     int v = 0;
@@ -280,13 +280,21 @@ __global__ __launch_bounds__(1024) void k_order_sums(const Ctl *ctl, const int *
         sums[blockIdx.x] = t;
     }
 }
-__global__ __launch_bounds__(1024) void k_order_scan(const Ctl *ctl, int *sums, int nblocks, int thr, int min_K);
 __global__ __launch_bounds__(1024) void k_order_scatter(const Ctl *ctl, const int *p2o, int n_rows, const int *sums, const int *pos_of,
                                                         int *order_person, int *order_pos, int thr, int min_K) {
     if (!order_needed(ctl, thr, min_K)) return;
     __shared__ int s_w[16];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    int carry = sums[blockIdx.x];  // (exclusive: unassigned persons in the chunks before this one)
+    // unassigned persons in the chunks before this one: the chunk counts of k_order_prepare, added up here
+    int carry = 0;
+    {
+        int v = 0;
+        for (int b = t; b < (int)blockIdx.x; b += 1024) v += sums[b];
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == 0) s_w[wave] = v;
+        __syncthreads();
+        for (int w = 0; w < 16; ++w) carry += s_w[w];
+    }
     for (int q = 0; q < 4; ++q) {
         const int i = blockIdx.x * kScanChunk + q * 1024 + t;
         const bool un = i < n_rows && p2o[i] == -1;
@@ -306,11 +314,6 @@ __global__ __launch_bounds__(1024) void k_order_scatter(const Ctl *ctl, const in
         }
         carry += tot;
     }
-}
-
-__global__ __launch_bounds__(1024) void k_order_scan(const Ctl *ctl, int *sums, int nblocks, int thr, int min_K) {
-    if (!order_needed(ctl, thr, min_K)) return;
-    scan_of_sums_body(sums, nblocks);
 }
 
 // ---- the kernel -------------------------------------------------------------------------------------------

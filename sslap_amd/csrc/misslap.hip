@@ -691,9 +691,8 @@ int launch_bid_tiled(misslap_solver *h) {
         int *pos_of = h->nmatch, *order_person = h->hole_list, *order_pos = h->mover_list, *sums = h->cnt;
         const int nchunks = (h->n_rows + kScanChunk - 1) / kScanChunk;
         // (each returns at once when the scan itself will: a round enqueued on a stale upper bound of K)
-        hipLaunchKernelGGL(k_order_inverse, dim3(blocks_for(h->K_ub, 256)), dim3(256), 0, h->stream, h->ctl, h->U, pos_of, h->thr, h->tiled_min_K);
-        hipLaunchKernelGGL(k_order_sums, dim3(nchunks), dim3(1024), 0, h->stream, h->ctl, h->p2o, h->n_rows, sums, h->thr, h->tiled_min_K);
-        hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(1024), 0, h->stream, h->ctl, sums, nchunks, h->thr, h->tiled_min_K);
+        hipLaunchKernelGGL(k_order_prepare, dim3(std::max(nchunks, blocks_for(h->K_ub, 1024))), dim3(1024), 0, h->stream, h->ctl, h->U,
+                           pos_of, h->p2o, h->n_rows, nchunks, sums, h->thr, h->tiled_min_K);
         hipLaunchKernelGGL(k_order_scatter, dim3(nchunks), dim3(1024), 0, h->stream, h->ctl, h->p2o, h->n_rows, sums, pos_of,
                            order_person, order_pos, h->thr, h->tiled_min_K);
         ta.order_person = order_person;
@@ -843,7 +842,6 @@ int launch_apply(misslap_solver *h) {
         hipLaunchKernelGGL(k_compact_count, dim3(cb), dim3(256), 0, h->stream, a);
         hipLaunchKernelGGL(k_compact_scatter, dim3(cb), dim3(256), 0, h->stream, a);
         hipLaunchKernelGGL(k_compact_fill, dim3(blocks_for(h->K_ub, 256)), dim3(256), 0, h->stream, a);
-        hipLaunchKernelGGL(k_round_end, dim3(1), dim3(1), 0, h->stream, a);
     }
     HIP_TRY(hipGetLastError());
     return MISSLAP_OK;
