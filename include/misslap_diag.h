@@ -10,7 +10,7 @@
 extern "C" {
 #endif
 /* Average duration (ms) of `reps` launches of an ablated full-scan bid kernel over the current unassigned list
- * (mode 0 complete, 1 no price gather, 2 no cross-lane reduction, 3 edge stream only; 10..16: the LDS-tiled kernel
+ * (mode 0 complete, 1 no price gather, 2 no cross-lane reduction, 3 edge stream only, 4 gather from 4-byte prices; 10..16: the LDS-tiled kernel
  * and its ablations); results are discarded, the solver state is untouched. */
 int misslap_debug_time_bid(misslap_solver *h, int32_t mode, int32_t reps, float *ms_avg);
 #ifdef __cplusplus

@@ -1,5 +1,6 @@
 // kernels_debug.hpp -- timing-only ablations of the full-scan bid kernel (diagnostics; results are
-// discarded).  MODE 0 = complete bid, 1 = no price gather, 2 = no cross-lane reduction, 3 = edge stream only.
+// discarded).  MODE 0 = complete bid, 1 = no price gather, 2 = no cross-lane reduction, 3 = edge stream only,
+// 4 = the gather from a table of 4-byte prices (what an fp32 price mirror would cost; values meaningless).
 #pragma once
 #include "device_common.hpp"
 
@@ -29,6 +30,7 @@ __global__ __launch_bounds__(256) void k_bid_ablate(const int *U, const int *row
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (MODE == 1 || MODE == 3) pr[u] = 0.0;
+                else if (MODE == 4) pr[u] = (c[u] >= 0) ? (double)reinterpret_cast<const float *>(price)[c[u]] : 0.0;  // a 4-byte table
                 else pr[u] = (c[u] >= 0) ? price[c[u]] : 0.0;
             }
 #pragma unroll
@@ -45,7 +47,7 @@ __global__ __launch_bounds__(256) void k_bid_ablate(const int *U, const int *row
                 }
             }
         }
-        if (MODE == 0 || MODE == 1) {
+        if (MODE == 0 || MODE == 1 || MODE == 4) {
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) {
                 const double v2 = shfl_xor_f64(v1, off);

@@ -2510,6 +2510,7 @@ MISSLAP_API int misslap_debug_time_bid(misslap_solver *h, int32_t mode, int32_t 
             case 0: hipLaunchKernelGGL((k_bid_ablate<EdgesF32, 0>), dim3(grid), dim3(256), 0, h->stream, h->U, h->row_ptr, h->price, ed, h->n_rows, (double)h->eps, sink); break;
             case 1: hipLaunchKernelGGL((k_bid_ablate<EdgesF32, 1>), dim3(grid), dim3(256), 0, h->stream, h->U, h->row_ptr, h->price, ed, h->n_rows, (double)h->eps, sink); break;
             case 2: hipLaunchKernelGGL((k_bid_ablate<EdgesF32, 2>), dim3(grid), dim3(256), 0, h->stream, h->U, h->row_ptr, h->price, ed, h->n_rows, (double)h->eps, sink); break;
+            case 4: hipLaunchKernelGGL((k_bid_ablate<EdgesF32, 4>), dim3(grid), dim3(256), 0, h->stream, h->U, h->row_ptr, h->price, ed, h->n_rows, (double)h->eps, sink); break;
             default: hipLaunchKernelGGL((k_bid_ablate<EdgesF32, 3>), dim3(grid), dim3(256), 0, h->stream, h->U, h->row_ptr, h->price, ed, h->n_rows, (double)h->eps, sink); break;
         }
     };
