@@ -326,16 +326,20 @@ int misslap_matching_gpu(const int32_t *loc, int64_t nnz, int32_t n_rows, int32_
 int misslap_matching_of(misslap_solver *h, int32_t *size, int32_t *phases);
 
 /* Host-side caches: a destroyed handle parks its idle HIP stream, pinned status mirror and events (at most 8 bundles)
- * and freed device blocks of <= 32 MB (at most 16 blocks / 256 MB) for the next handle.  This releases all of them
+ * and its freed device blocks for the next handle -- BY DEFAULT up to 4 GB in total (never more than 1 / 64 of the
+ * device's memory), blocks of up to 1 GB, at most 64 blocks: i.e. after misslap_destroy the process may still hold up to
+ * 4 GB of HBM that an embedding application (a PyTorch process, say) does not see as free until it calls
+ * misslap_trim_caches or lowers the limits (misslap_set_cache_limits(0, 0, 0) = park nothing).  This releases all of them
  * (streams destroyed, device and pinned memory freed); *freed_bytes (may be NULL) receives the device bytes returned.
  * Call it when the embedding application needs the memory back; never while another thread creates / destroys handles
  * on a stream that may still use a parked block (the entry point synchronises every device it frees on). */
 int misslap_trim_caches(int64_t *freed_bytes);
-/* Limits of the device-block cache: total bytes parked, largest block parked, number of blocks (defaults 256 MB /
- * 32 MB / 16: what a stream of small problems needs; MISSLAP_BLOCK_CACHE_MB in the environment sets the first two at
- * start-up).  An application that solves many LARGE problems at a time raises them -- hipFree waits for every stream
- * of the device, so a handle destroyed while other solves run stalls behind their kernels, and a cached block costs
- * neither hipMalloc nor hipFree (bench.py --concurrent: C3, 16 at a time). */
+/* Limits of the device-block cache: total bytes parked, largest block parked, number of blocks.  Defaults: min(4 GB,
+ * device memory / 64) / a quarter of that / 64 blocks -- the blocks of one or two problems of the BASELINE sizes (0.9 GB
+ * per C3 handle), because hipMalloc + hipFree of those cost a millisecond per create / destroy pair and hipFree waits
+ * for EVERY stream of the device; MISSLAP_BLOCK_CACHE_MB in the environment sets the first two at start-up (0 = park
+ * nothing).  An application that solves many LARGE problems at a time raises them (bench.py --concurrent: C3, 16 at a
+ * time: 4 GB per solve in flight); one that must not lose HBM to the library lowers them. */
 int misslap_set_cache_limits(int64_t max_total_bytes, int64_t max_block_bytes, int32_t max_blocks);
 
 const char *misslap_last_error(void);

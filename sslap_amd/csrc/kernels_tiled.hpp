@@ -36,10 +36,12 @@ constexpr int kTileColsBig = 157 * 128;   // 20096 -> 160768 B, one workgroup pe
 constexpr int kTileColsHalf = 79 * 128;   // 10112 ->  80896 B, two workgroups per CU: one computes while the
                                           //                     other waits for its tile fill
 constexpr int kTileRB = 128;      // persons per layout block
-// LDS behind the price buffers: statistics scratch of the epilogue (16 x 12 + 16 bytes), then 64 bytes per loader
-// wavefront for the L2 touches (see the loader wavefronts of k_bid_tiled)
+// LDS behind the price buffers: statistics scratch of the epilogue (16 x 12 + 16 bytes), then ONE 256-byte scratch region
+// that every loader wavefront's L2 touches land in (an LDS-DMA load writes one dword slot per lane, LDS base + 4 * lane,
+// whatever its element size: 256 bytes per wavefront; the data is junk and never read, so the loaders share the region)
 constexpr int kTileStatBytes = 16 * 12 + 16;
 constexpr int kTileTouchBytes = 64 * 4;
+static_assert((2 * (79 * 128) + 128) * 8 + kTileStatBytes + kTileTouchBytes <= 160 * 1024, "k_bid_tiled: price buffers + scratch exceed a CU's LDS");
 // Launch shapes (template parameters of k_bid_tiled): THREADS per workgroup (one workgroup per CU: the
 // price tile takes 128 of the 160 KB of LDS), ROWS persons per 8-lane group (register-resident running
 // top-2 per lane), BATCH persons whose segment loads are in flight together.
@@ -577,10 +579,11 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
         const int nx = max(1, (int)gridDim.x / 8), xr = ((int)blockIdx.x / 8) % nx;
         const int lines_per_wg = (kTileLines + nx - 1) / nx, lines_per_wave = (lines_per_wg + kLoaders - 1) / (kLoaders > 0 ? kLoaders : 1);
         // (always ONE load per call, all lanes active, addresses clamped into the table: the vmcnt(1) below relies on
-        // exactly one load behind the pieces of a fill.  The touch is an LDS-DMA of one byte per lane into 64 bytes of
-        // scratch behind the statistics words: a load WITHOUT a register destination -- an asynchronous inline-asm load
-        // into a VGPR would land whenever it lands, in a register the compiler may have re-used by then)
-        char *touch_dst = reinterpret_cast<char *>(s_price + (kDouble ? kBufDoubles + kTileCols : kTileCols + 2)) + kTileStatBytes + 64 * me;
+        // exactly one load behind the pieces of a fill.  The touch is an LDS-DMA of one byte per lane into the 256 bytes
+        // of scratch behind the statistics words (kTileTouchBytes, shared by all loaders): a load WITHOUT a register
+        // destination -- an asynchronous inline-asm load into a VGPR would land whenever it lands, in a register the
+        // compiler may have re-used by then)
+        char *touch_dst = reinterpret_cast<char *>(s_price + (kDouble ? kBufDoubles + kTileCols : kTileCols + 2)) + kTileStatBytes;
         auto touch = [&](int tile) {
             const int line = min(xr * lines_per_wg + me * lines_per_wave + min(lane, lines_per_wave - 1), kTileLines - 1);
             const char *src = reinterpret_cast<const char *>(a.price + (size_t)min(tile, T - 1) * kTileCols) + (size_t)line * 128;

@@ -424,6 +424,8 @@ struct BlockCache {
     // (C4: setup 4.0 -> 3.0 ms), and hipFree waits for every stream of the device, i.e. for other solves' kernels.  An
     // application that solves many large problems at a time raises them further
     size_t kMaxHeld = (size_t)4 << 30, kMaxEach = (size_t)1 << 30, kMaxEntries = 64;
+    bool explicit_limits = false;  // set by the caller (misslap_set_cache_limits / MISSLAP_BLOCK_CACHE_MB)
+    bool sized = false;            // the default total has been bounded by the device's memory (first block parked)
     BlockCache() {
         if (const char *e = std::getenv("MISSLAP_BLOCK_CACHE_MB")) {
             const long long mb = std::atoll(e);
@@ -431,8 +433,17 @@ struct BlockCache {
                 kMaxHeld = (size_t)mb << 20;
                 kMaxEach = kMaxHeld;
                 kMaxEntries = 4096;
+                explicit_limits = true;
             }
         }
+    }
+    // the DEFAULT total never exceeds 1 / 64 of the device's memory (4 GB of an MI355X's 288 GB; 1 GB of a 64 GB part)
+    void size_default(size_t device_bytes) {
+        std::lock_guard<std::mutex> g(m);
+        if (explicit_limits || sized) return;
+        sized = true;
+        kMaxHeld = std::min(kMaxHeld, device_bytes / 64);
+        kMaxEach = std::min(kMaxEach, kMaxHeld / 4);
     }
     void *take(int device, size_t bytes, size_t *got) {
         std::lock_guard<std::mutex> g(m);
@@ -472,7 +483,12 @@ int block_alloc(void **p, size_t bytes, size_t *got) {
     return MISSLAP_OK;
 }
 void block_free(int device, void *p, size_t bytes) {
-    if (p && !block_cache().give(device, p, bytes)) (void)hipFree(p);
+    BlockCache &bc = block_cache();
+    if (p && !bc.sized && !bc.explicit_limits) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) bc.size_default(total_b);
+    }
+    if (p && !bc.give(device, p, bytes)) (void)hipFree(p);
 }
 
 RoundArgs round_args(misslap_solver *h) {
@@ -948,6 +964,11 @@ int check_lanes(const misslap_solver *h) {
 #define MISSLAP_CHECK_KERNEL(GL) k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 3, 0, GL, 1, 1>
 
 // rows [0, n_rows) on the row-major CSR (the sample of run_ece; every row where there is no tile-major copy)
+// the largest grid launch_rows_all can ask for on n_rows persons (over every lanes-per-person shape of the check pass)
+size_t final_pass_grid_max(size_t n_rows, int n_cus) {
+    const size_t per_wg_min = (size_t)((1024 - 64 * 3) / 16) * 4;  // 16 lanes per person
+    return std::max<size_t>((n_rows + per_wg_min - 1) / per_wg_min, (size_t)n_cus);
+}
 int launch_rows_gather(misslap_solver *h, float eps, const FinalOut &fo, int n_rows, int *n_blocks = nullptr) {
     const int grid = blocks_for(n_rows, 4);
     if (n_blocks) *n_blocks = grid;
@@ -1013,10 +1034,14 @@ int run_ece(misslap_solver *h, float eps, int *ok) {
         int K = 0, err = 0;
         long long nits = 0;
         if (live_poll(h, h->ticket, true, &K, &err, &nits)) {
+            // (k_post_ece stores the verdict word right behind the four status words; the wait is bounded by time,
+            // like live_poll's)
             volatile unsigned long long *w = h->live + 4;
             unsigned long long v = *w;
-            for (unsigned spins = 0; (unsigned)(v >> 32) != h->ticket && spins < (1u << 26); ++spins) {
+            const double t_end = now_ms() + 2000.0;
+            for (unsigned spins = 0; (unsigned)(v >> 32) != h->ticket; ++spins) {
                 __builtin_ia32_pause();
+                if ((spins & 4095) == 4095 && now_ms() > t_end) break;
                 v = *w;
             }
             if ((unsigned)(v >> 32) == h->ticket) {
@@ -1333,7 +1358,10 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
         blk.want(&h->ctl, 1);
         blk.want(&h->contrib, N);
         blk.want(&h->nmatch, N);
-        h->fin_slots_n = (int)std::max<size_t>(kMaxGridBlocks, N / 256 + 256);  // >= any grid of the final pass
+        // >= any grid of the final pass: the gather form launches at most kMaxGridBlocks workgroups, the engine form
+        // (launch_rows_all) ceil(N / persons per workgroup) with at least (1024 - 192) / 16 lane groups x 4 persons = 208
+        // persons per workgroup (16 lanes per person), or one workgroup per CU
+        h->fin_slots_n = (int)std::max<size_t>(kMaxGridBlocks, final_pass_grid_max(N, h->n_cus) + 1);
         blk.want(&h->fin_slots, (size_t)h->fin_slots_n);
         h->wg_stats_slots = (int)std::min<size_t>(N / 64 + 4096, 1u << 22);  // >= kMaxGridBlocks and any scan grid
         blk.want(&h->wg_stats, (size_t)kStatWords * (size_t)h->wg_stats_slots);
@@ -1356,7 +1384,9 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
     if (h->profile)
         HIP_TRY(hipMemsetAsync(h->launch_edges, 0, sizeof(unsigned long long) * h->launch_edges_cap, h->stream));
     // the mirror, the two trailing status copies and the live status words (kept together: one pooled allocation)
-    if (!h->h_ctl) HIP_TRY(hipHostMalloc((void **)&h->h_ctl, 3 * sizeof(Ctl) + 128));
+    // (coherent + mapped EXPLICITLY: with HIP_HOST_COHERENT=0 in the environment a default allocation is not coherent,
+    // and the kernels' system-scope stores to the live words would become visible at sync points only)
+    if (!h->h_ctl) HIP_TRY(hipHostMalloc((void **)&h->h_ctl, 3 * sizeof(Ctl) + 128, hipHostMallocCoherent | hipHostMallocMapped));
     h->h_stat = h->h_ctl + 1;
     {
         char *base = reinterpret_cast<char *>(h->h_ctl + 3);
@@ -1746,6 +1776,7 @@ MISSLAP_API int misslap_set_cache_limits(int64_t max_total_bytes, int64_t max_bl
     bc.kMaxHeld = (size_t)max_total_bytes;
     bc.kMaxEach = (size_t)max_block_bytes;
     bc.kMaxEntries = (size_t)max_blocks;
+    bc.explicit_limits = true;
     return MISSLAP_OK;
 }
 
@@ -2152,6 +2183,7 @@ MISSLAP_API int misslap_finish(misslap_solver *h, int32_t *person_to_object_out,
     // (a workgroup without rows returns before it writes its slot)
     HIP_TRY(hipMemsetAsync(h->fin_slots, 0, sizeof(FinSlot) * (size_t)h->fin_slots_n, h->stream));
     if ((rc = launch_rows_all(h, h->target_eps, fo, &n_slots))) return rc;
+    h->ece_flag_clear = false;  // the final pass leaves its verdict in Ctl::ece_fail: the next test must clear it
     if (h->f32) {
         EdgesF32 ed{h->edges32};
         hipLaunchKernelGGL(k_obj_sum<EdgesF32>, dim3(1), dim3(1024), 0, h->stream, h->ctl, ed, h->row_ptr, h->p2o,
