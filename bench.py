@@ -14,7 +14,9 @@ Contract (one JSON line on rank 0):
   python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3] [--no-cpu] [--mode sharded|replicas]
 N > 1: one rank per GPU.  Under torch.distributed.run (RANK / WORLD_SIZE in the environment) this process IS a rank;
 without a launcher `python bench.py --gpus N` starts the N ranks itself -- fresh child processes, spawned before this
-process has imported torch or touched the GPU; the parent only relays rank 0's JSON line.  Mode 'sharded': persons of
+process has imported torch or touched the GPU; the parent only relays rank 0's JSON line.  MISSLAP_DIST_BACKEND=gloo lets
+the rank processes share ONE GPU (rehearsal; a one-GPU box admits about four of them on its card), MISSLAP_DIST_BACKEND=
+threads runs the N ranks as threads of this process (rehearsal of N = 8 on one GPU).  Mode 'sharded': persons of
 each big round sharded over the ranks, RCCL all-reduces on the per-object best bids issued by the library itself
 (misslap_solve_sharded, include/misslap.h; sslap_amd/dist.py only creates the communicator); mode 'replicas': one
 independent solve per GPU, no collective.
@@ -106,6 +108,59 @@ def launch_ranks(n, argv):
         sys.stdout.write(out0.read().decode())
         sys.stdout.flush()
     raise SystemExit(0 if all(rc == 0 for rc in rcs) else next(rc for rc in rcs if rc != 0) or 1)
+
+
+class TorchRanks:
+    """The ranks are processes of a torch.distributed group (RCCL, or gloo for a one-GPU rehearsal)."""
+
+    def __init__(self, rank, world, dist, torch):
+        self.rank, self.world, self._dist, self._torch = rank, world, dist, torch
+
+    def barrier(self):
+        if self.world > 1:
+            self._dist.barrier()
+        self._torch.cuda.synchronize()
+
+    def _reduce(self, x, dtype, op):
+        if self.world == 1:
+            return x
+        t = self._torch.tensor([x], dtype=dtype, device="cuda")
+        self._dist.all_reduce(t, op=op)
+        return t.item()
+
+    def max_f(self, x):
+        return float(self._reduce(x, self._torch.float64, self._dist.ReduceOp.MAX))
+
+    def sum_i(self, x):
+        return int(self._reduce(x, self._torch.int64, self._dist.ReduceOp.SUM))
+
+    def gather(self, obj):
+        if self.world == 1:
+            return [obj]
+        out = [None] * self.world
+        self._dist.all_gather_object(out, obj)
+        return out
+
+
+class ThreadRanks:
+    """The ranks are threads of this process (sslap_amd.dist.ThreadGroup): same interface."""
+
+    def __init__(self, rank, group, torch):
+        self.rank, self.world, self._g, self._torch = rank, group.world, group, torch
+
+    def barrier(self):
+        self._g.barrier()
+        self._torch.cuda.synchronize()
+        self._g.barrier()
+
+    def max_f(self, x):
+        return float(max(self._g.all_gather(self.rank, x)))
+
+    def sum_i(self, x):
+        return int(sum(self._g.all_gather(self.rank, x)))
+
+    def gather(self, obj):
+        return self._g.all_gather(self.rank, obj)
 
 
 def measured_hbm_peaks(device):
@@ -207,55 +262,101 @@ def main():
                          "no collective (weak scaling: how independent LAPs -- the reference's typical use -- scale)")
     args = ap.parse_args()
 
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    backend = os.environ.get("MISSLAP_DIST_BACKEND", "nccl")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and backend != "threads":
         launch_ranks(args.gpus, sys.argv[1:])  # does not return
     if args.concurrent > 1:
         # hardware queues for the concurrent streams (the runtime's default is 4 per process: streams beyond that
         # share a queue and their kernels serialise -- C3, 16 at a time: 2.8x the single-solve throughput with 4 queues,
         # 4.8x with 16, 6.4x with 32); must be in the environment before the HIP runtime starts
         os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(max(2 * args.concurrent, 4), 32)))
+    if backend == "threads" and args.gpus > 1:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(max(2 * args.gpus, 4), 32)))  # a queue per rank thread
 
     import numpy as np
     import torch
+
+    from sslap_amd import synth
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+
+    if backend == "threads" and args.gpus > 1:
+        # N rank THREADS on cuda:0 (one-GPU rehearsal of the N-rank line, e.g. N = 8: a one-GPU box admits only a few
+        # PROCESSES on its card).  Same code per rank as under a launcher; the exchange goes through the library's custom
+        # communicator (sslap_amd.dist.Comm.in_process), barriers and reductions through a ThreadGroup.
+        import threading
+        from sslap_amd import dist as mdist
+        torch.cuda.set_device(0)
+        loc, val = synth.gen_config(args.config)
+        shared = (torch.from_numpy(loc).cuda(), torch.from_numpy(val).cuda(), int(loc.shape[0]))
+        del loc, val
+        torch.cuda.synchronize()
+        group = mdist.ThreadGroup(args.gpus, timeout_s=float(os.environ.get("MISSLAP_BENCH_TIMEOUT_S", 3000)))
+        rcs = [1] * args.gpus
+
+        def rank_thread(r):
+            try:
+                torch.cuda.set_device(0)
+                comm = None if args.mode == "replicas" else mdist.Comm.in_process(r, group)
+                run_rank(args, r, args.gpus, 0, ThreadRanks(r, group, torch), comm, shared, "threads")
+                rcs[r] = 0
+            except BaseException as e:  # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                group.abort()
+                rcs[r] = e.code if isinstance(e, SystemExit) and isinstance(e.code, int) else 1
+        th = [threading.Thread(target=rank_thread, args=(r,)) for r in range(args.gpus)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        raise SystemExit(0 if all(rc == 0 for rc in rcs) else next(rc for rc in rcs if rc != 0) or 1)
+
     import torch.distributed as dist
-
-    from sslap_amd import AuctionSolver, synth
-
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     # one rank per GPU; MISSLAP_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsal of the
     # multi-rank path on a single-GPU box; RCCL needs a GPU per rank)
-    backend = os.environ.get("MISSLAP_DIST_BACKEND", "nccl")
     local_rank = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend, rank=rank, world_size=world)
-
     comm = None
-    replicas = world > 1 and args.mode == "replicas"
-    if world > 1 and not replicas:
+    if world > 1 and args.mode != "replicas":
         from sslap_amd import dist as mdist
         # RCCL communicator of the library (the 128-byte id travels through torch.distributed); with
         # MISSLAP_DIST_BACKEND=gloo several ranks share one GPU and the exchange is staged through the host
         comm = mdist.Comm.from_torch_distributed(local_rank) if backend == "nccl" else mdist.Comm.gloo_staged()
+    run_rank(args, rank, world, local_rank, TorchRanks(rank, world, dist, torch), comm, None, backend)
+    if world > 1:
+        dist.destroy_process_group()
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+
+def run_rank(args, rank, world, local_rank, ranks, comm, shared, backend):
+    """One rank's part of the benchmark; rank 0 prints the JSON line.  `ranks`: barrier / reductions / gather over the
+    ranks (processes or threads); `shared`: device-resident inputs generated once for all rank threads, or None."""
+    import numpy as np  # noqa: F401
+    import torch
+
+    from sslap_amd import AuctionSolver, synth
+
+    replicas = world > 1 and args.mode == "replicas"
+    barrier = ranks.barrier
 
     # synthetic workload, resident in HBM before anything is timed
-    loc, val = synth.gen_config(args.config)
-    nnz = int(loc.shape[0])
-    d_loc = torch.from_numpy(loc).cuda()
-    d_val = torch.from_numpy(val).cuda()
-    del loc, val
+    if shared is not None:
+        d_loc, d_val, nnz = shared
+    else:
+        loc, val = synth.gen_config(args.config)
+        nnz = int(loc.shape[0])
+        d_loc = torch.from_numpy(loc).cuda()
+        d_val = torch.from_numpy(val).cuda()
+        del loc, val
     # (device-resident inputs ordered behind the stream that produced them: no device-wide wait per create)
     gpu_opts = dict(device=local_rank, profile=True, input_stream=torch.cuda.current_stream().cuda_stream)
     if args.tail_threshold is not None:
@@ -287,32 +388,21 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if replicas:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        e = torch.tensor([sum(g["edges_scanned"] for _, g in runs)], dtype=torch.int64, device="cuda")
-        dist.all_reduce(e, op=dist.ReduceOp.SUM)
-        edges_all = int(e.item())  # N independent solves: every rank's edges are unique work
+        dt = ranks.max_f(dt)
+        edges_all = ranks.sum_i(sum(g["edges_scanned"] for _, g in runs))  # N independent solves: every rank's edges are unique work
         fs_all_edges, fs_max_ms = None, None
     elif world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = ranks.max_f(dt)
         # a rank counts the bids of its own shard in the exchanged (sharded) rounds plus all bids of the
         # replicated rounds, which every rank repeats: unique work = sum over ranks of the sharded part + the
         # replicated part ONCE (redundant scans are not throughput)
         sh = sum(g["shard_edges"] for _, g in runs)
         repl = sum(g["edges_scanned"] for _, g in runs) - sh
-        e = torch.tensor([sh], dtype=torch.int64, device="cuda")
-        dist.all_reduce(e, op=dist.ReduceOp.SUM)
-        edges_all = int(e.item()) + repl
+        edges_all = ranks.sum_i(sh) + repl
         # bid-phase throughput of the full scans over all ranks: every rank scans its shard of the K = N rounds at
         # the same time, so the aggregate rate is (sum of the shards' edges) / (slowest rank's kernel time)
-        fe = torch.tensor([sum(g["fullscan_edges"] for _, g in runs)], dtype=torch.int64, device="cuda")
-        fm = torch.tensor([sum(g["fullscan_ms"] for _, g in runs)], dtype=torch.float64, device="cuda")
-        dist.all_reduce(fe, op=dist.ReduceOp.SUM)
-        dist.all_reduce(fm, op=dist.ReduceOp.MAX)
-        fs_all_edges, fs_max_ms = int(fe.item()), float(fm.item())
+        fs_all_edges = ranks.sum_i(sum(g["fullscan_edges"] for _, g in runs))
+        fs_max_ms = ranks.max_f(sum(g["fullscan_ms"] for _, g in runs))
     else:
         edges_all = sum(g["edges_scanned"] for _, g in runs)
         fs_all_edges, fs_max_ms = None, None
@@ -328,10 +418,7 @@ def main():
     me = {"rank": rank, "device": name.value.decode(), "device_uuid": uuid.value.decode(), "local_rank": local_rank,
           "sol_sha256": synth.sol_digest(sol), "comm": comm.info() if comm is not None else None,
           "sharded_rounds_per_solve": runs[-1][1].get("sharded_rounds", 0)}
-    ranks = [me]
-    if world > 1:
-        ranks = [None] * world
-        dist.all_gather_object(ranks, me)
+    rank_list = ranks.gather(me)
     if rank == 0:
         meta, gpu = runs[-1]
         bpe = gpu["bytes_per_edge"]
@@ -350,8 +437,17 @@ def main():
         # the roofline kernel: the one that performs the full CSR scans (K = N rounds)
         rk_name = "k_bid_tiled" if tiled else "k_bid"
         rk_ms, rk_edges, rk_launches = (til_ms, til_edges, til_launches) if tiled else (bid_ms, bid_edges, bid_launches)
+        # The gather engine (configs without the tile-major copy) answers part of a launch's bids from candidate lines:
+        # those rows are counted like the reference counts them but never read.  The roofline figures are formed from the
+        # edges a launch actually STREAMED (misslap_meta.bid_edges_read / fullscan_edges_read); the reference-equivalent
+        # figure goes next to them under its own key.  (The LDS-tiled engine reads every edge it counts: same number.)
+        rk_edges_counted, fs_edges_counted = rk_edges, fs_edges
+        if not tiled:
+            rk_edges = sum(g.get("bid_edges_read", g["bid_edges"]) for _, g in runs)
+            fs_edges = sum(g.get("fullscan_edges_read", g["fullscan_edges"]) for _, g in runs)
         achieved = rk_edges * bpe / (rk_ms * 1e-3) / 1e9 if rk_ms > 0 else 0.0
         fs_achieved = fs_edges * bpe / (fs_ms * 1e-3) / 1e9 if fs_ms > 0 else 0.0
+        achieved_counted = rk_edges_counted * bpe / (rk_ms * 1e-3) / 1e9 if rk_ms > 0 else 0.0
         # HBM traffic of the roofline kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on
         # this same command, summarised by tools/pmc_summary.py with the gfx950 corrections).  The file names the
         # kernel sources (sha256) and the commit it was measured on: any other code gets null, not a stale number.
@@ -459,6 +555,7 @@ def main():
                 "full_scan_kernel": rk_name,
                 "fullscan_launches": fs_launches, "fullscan_avg_us": round(1e3 * fs_ms / max(fs_launches, 1), 2),
                 "fullscan_medges_s": round(fs_edges / (fs_ms * 1e-3) / 1e6, 1) if fs_ms else None,
+                "fullscan_medges_s_reference_equivalent": round(fs_edges_counted / (fs_ms * 1e-3) / 1e6, 1) if fs_ms else None,
                 "fullscan_GBs": round(fs_achieved, 1), "fullscan_frac_of_hbm_peak": round(fs_achieved / HBM_PEAK_GBS, 4),
                 # N > 1: the full scans of all ranks together (rank 0's own share is the line above)
                 "fullscan_all_ranks_medges_s": (round(fs_all_edges / (fs_max_ms * 1e-3) / 1e6, 1)
@@ -493,22 +590,27 @@ def main():
                 "traffic_source": "rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction calibrated on known-size "
                                   "kernels + WRITE_SIZE), bytes per launch" if traffic else None,
                 **traffic_meta,
-                # (gather engine only -- configs without the tile-major copy: its launches answer part of their bids from
-                # candidate lines, whose rows are counted like the reference counts them but never read; a dense matrix
-                # can so exceed the peak on paper.  The full-scan engine k_bid_tiled reads every edge it counts.)
-                "counts_rows_answered_from_lines": (not tiled) and gpu.get("lines_active", 0) == 1,
+                # (gather engine only) what the same launches come to when the rows that candidate lines answered are
+                # counted as well -- the reference-equivalent count, NOT bytes moved; never to be read as a bandwidth
+                "edges_counted_incl_rows_answered_from_lines": rk_edges_counted,
+                "edges_read": rk_edges,
+                "reference_equivalent_GBs": round(achieved_counted, 2),
+                "counts_rows_answered_from_lines": False,
             },
             "device": name.value.decode(), "compute_units": int(cus.value),
             # N > 1: proof that N ranks took part and agree -- what the transport itself reports (ncclCommCount), every
             # rank's device and assignment hash, the exchanges a solve issued
-            "ranks": ranks,
-            "rccl_nranks": (ranks[0]["comm"]["transport_ranks"] if ranks[0]["comm"] and ranks[0]["comm"]["kind"] == "rccl" else None),
-            "comm_kind": ranks[0]["comm"]["kind"] if ranks[0]["comm"] else None,
-            "comm_ranks_seen_by_every_rank": [r["comm"]["transport_ranks"] if r["comm"] else None for r in ranks],
-            "distinct_gpus": len({r["device_uuid"] for r in ranks}),
-            "sharded_rounds_per_solve": ranks[0]["sharded_rounds_per_solve"],
-            "exchanges_per_solve": 2 * ranks[0]["sharded_rounds_per_solve"],
-            "sol_sha256_equal_on_all_ranks": len({r["sol_sha256"] for r in ranks}) == 1,
+            "ranks": rank_list,
+            "rank_transport": ("one process per rank, RCCL" if backend == "nccl" else
+                               "one process per rank on a shared GPU, exchange staged through the host (gloo)" if backend == "gloo"
+                               else "one THREAD per rank on a shared GPU, exchange staged through the host") if world > 1 else None,
+            "rccl_nranks": (rank_list[0]["comm"]["transport_ranks"] if rank_list[0]["comm"] and rank_list[0]["comm"]["kind"] == "rccl" else None),
+            "comm_kind": rank_list[0]["comm"]["kind"] if rank_list[0]["comm"] else None,
+            "comm_ranks_seen_by_every_rank": [r["comm"]["transport_ranks"] if r["comm"] else None for r in rank_list],
+            "distinct_gpus": len({r["device_uuid"] for r in rank_list}),
+            "sharded_rounds_per_solve": rank_list[0]["sharded_rounds_per_solve"],
+            "exchanges_per_solve": 2 * rank_list[0]["sharded_rounds_per_solve"],
+            "sol_sha256_equal_on_all_ranks": len({r["sol_sha256"] for r in rank_list}) == 1,
             "concurrent": conc,
         }
         if world == 1 and not args.no_cpu:
@@ -519,8 +621,6 @@ def main():
         print(json.dumps(out))
         if not out["sol_sha256_equal_on_all_ranks"]:
             raise SystemExit("the ranks disagree on the assignment")
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

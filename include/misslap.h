@@ -121,8 +121,10 @@ typedef struct misslap_meta {
     uint64_t tiled_edges;
     int32_t tiled_active;        /* full-scan engine for big rounds: 0 none (k_bid only), 1 k_bid_tiled */
     int32_t tiled_min_K;         /* rounds with K >= this use it */
-    int64_t merge_launches;      /* DEPRECATED, always 0 (the 2-D scan engine of round 1 was removed); the two fields */
-    double merge_ms;             /* only keep the offsets of what follows */
+    uint64_t bid_edges_read;     /* of bid_edges: edges of the rows those launches actually streamed -- the rest are rows a
+                                    candidate line answered, counted like the reference counts them but never read.
+                                    (These two 8-byte fields were merge_launches / merge_ms, always 0, until round 5.) */
+    uint64_t fullscan_edges_read;/* the same for fullscan_edges (the LDS-tiled engine reads every edge it counts) */
     uint64_t shard_edges;        /* multi-GPU: edges scanned in sharded rounds (this rank's share); the rest of
                                     edges_scanned is replicated work, identical on every rank */
     uint64_t cand_hits;          /* bids answered from the person's candidate line (exactly the same bid, no row scan) */
@@ -249,6 +251,14 @@ typedef struct misslap_comm_ops {
     int (*allreduce_min_i32)(void *ctx, void *buf, int64_t count, void *hip_stream);
 } misslap_comm_ops;
 int misslap_rccl_unique_id(void *id_out /* MISSLAP_RCCL_ID_BYTES */);
+/* Self-check of the RCCL binding, needs no GPU: opens librccl exactly as misslap_comm_init_rccl does and reports how many
+ * of the entry points the exchange uses were resolved (*n_symbols of MISSLAP_RCCL_SYMBOLS: ncclGetUniqueId,
+ * ncclCommInitRank, ncclCommDestroy, ncclAllReduce, ncclGetErrorString, ncclCommCount), the enumerator VALUES the
+ * library passes to ncclAllReduce -- enums[0..3] = ncclInt32, ncclInt64, ncclMax, ncclMin as compiled in (rccl.h:
+ * ncclDataType_t, ncclRedOp_t) --, enums[4] = the size of the unique id it assumes, enums[5] = ncclGetVersion() of the
+ * copy it bound to, and that copy's path.  A test compares them with the installed rccl.h (tests/test_cabi.py). */
+#define MISSLAP_RCCL_SYMBOLS 6
+int misslap_rccl_selfcheck(int32_t *n_symbols, int32_t enums[6], char *lib_path, int32_t lib_path_len);
 int misslap_comm_init_rccl(misslap_comm **out, const void *unique_id, int32_t rank, int32_t world, int32_t device);
 int misslap_comm_init_custom(misslap_comm **out, const misslap_comm_ops *ops);
 int misslap_comm_destroy(misslap_comm *comm);

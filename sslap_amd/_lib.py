@@ -42,7 +42,7 @@ class Meta(C.Structure):
         ("tail_launches", C.c_int64), ("tail_ms", C.c_double), ("tail_edges", C.c_uint64),
         ("tiled_launches", C.c_int64), ("tiled_ms", C.c_double), ("tiled_edges", C.c_uint64),
         ("tiled_active", C.c_int32), ("tiled_min_K", C.c_int32),
-        ("merge_launches", C.c_int64), ("merge_ms", C.c_double),
+        ("bid_edges_read", C.c_uint64), ("fullscan_edges_read", C.c_uint64),
         ("shard_edges", C.c_uint64), ("cand_hits", C.c_uint64), ("cand_edges", C.c_uint64),
         ("tail_stats", C.c_double * 12),
         ("complete_assignment", C.c_int32), ("valid_assignment", C.c_int32), ("lines_active", C.c_int32),
@@ -113,6 +113,7 @@ SYMBOLS = {
     "misslap_device_info": (C.c_int, [C.c_int32, C.c_char_p, C.c_int32, _I32P, C.POINTER(C.c_int64)]),
     "misslap_matching_of": (C.c_int, [_VP, _I32P, _I32P]),
     "misslap_rccl_unique_id": (C.c_int, [_VP]),
+    "misslap_rccl_selfcheck": (C.c_int, [C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_char_p, C.c_int32]),
     "misslap_comm_init_rccl": (C.c_int, [C.POINTER(_VP), _VP, C.c_int32, C.c_int32, C.c_int32]),
     "misslap_comm_init_custom": (C.c_int, [C.POINTER(_VP), C.POINTER(CommOps)]),
     "misslap_comm_destroy": (C.c_int, [_VP]),

@@ -216,7 +216,8 @@ class AuctionSolver:
                      fullscan_launches=int(m.fullscan_launches), fullscan_ms=float(m.fullscan_ms),
                      fullscan_edges=int(m.fullscan_edges), tail_launches=int(m.tail_launches),
                      tail_ms=float(m.tail_ms), tiled_launches=int(m.tiled_launches), tiled_ms=float(m.tiled_ms),
-                     tiled_edges=int(m.tiled_edges))
+                     tiled_edges=int(m.tiled_edges), bid_edges_read=int(m.bid_edges_read),
+                     fullscan_edges_read=int(m.fullscan_edges_read))
         self.gpu = g
         self.meta["gpu"] = g
 

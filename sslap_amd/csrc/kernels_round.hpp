@@ -58,6 +58,7 @@ struct RoundArgs {
     unsigned ticket;              // nullptr: none.  ticket: the host's number of that launch
 };
 constexpr int kStatEdges = 0, kStatBids = 1, kStatHits = 2, kStatHitEdges = 3, kStatShardEdges = 4, kStatLaunchEdges = 5,
+              kStatLaunchHitEdges = 6,  // of kStatLaunchEdges: rows a candidate line answered (counted, never read)
               kStatWords = 8;
 
 __device__ __forceinline__ bool round_live(const Ctl *c, int thr) {
@@ -213,7 +214,10 @@ __device__ __forceinline__ void tally_flush(const RoundArgs &a, const BidTally &
             st[kStatEdges] += te;
             st[kStatBids] += (unsigned long long)tb;
             if (a.world > 1 && K >= a.shard_min_K) st[kStatShardEdges] += te;
-            if (a.launch_edges) st[kStatLaunchEdges] += te;  // a profiled launch: claimed by k_take_launch_edges
+            if (a.launch_edges) {  // a profiled launch: claimed by k_take_launch_edges / the round's k_tiebreak
+                st[kStatLaunchEdges] += te;
+                st[kStatLaunchHitEdges] += the;
+            }
             if (th) {
                 st[kStatHits] += (unsigned long long)th;
                 st[kStatHitEdges] += the;
@@ -444,15 +448,22 @@ __global__ __launch_bounds__(256) void k_tiebreak(RoundArgs a, const int *order_
     if (!round_live(ctl, a.thr)) return;
     if (ctl->K < order_min_K) order_pos = nullptr;
     if (take_n > 0 && blockIdx.x == 0 && threadIdx.x < kWave) {
-        unsigned long long v = 0;
+        unsigned long long v = 0, vh = 0;
         for (int k = threadIdx.x; k < take_n; k += kWave) {
             unsigned long long *st = a.wg_stats + (size_t)kStatWords * k;
             v += st[kStatLaunchEdges];
+            vh += st[kStatLaunchHitEdges];
             st[kStatLaunchEdges] = 0ull;
+            st[kStatLaunchHitEdges] = 0ull;
         }
-        for (int off = 32; off >= 1; off >>= 1)
+        for (int off = 32; off >= 1; off >>= 1) {
             v += ((unsigned long long)__shfl_xor((unsigned)(v >> 32), off) << 32) | (unsigned long long)__shfl_xor((unsigned)(v & 0xffffffffull), off);
-        if (threadIdx.x == 0) *take_out += v;
+            vh += ((unsigned long long)__shfl_xor((unsigned)(vh >> 32), off) << 32) | (unsigned long long)__shfl_xor((unsigned)(vh & 0xffffffffull), off);
+        }
+        if (threadIdx.x == 0) {  // {edges of the bidders' rows, of which answered from lines}
+            take_out[0] += v;
+            take_out[1] += vh;
+        }
     }
     int lo, hi;
     shard_range(ctl->K, a.rank, a.world, a.shard_min_K, lo, hi);
@@ -500,14 +511,20 @@ __global__ __launch_bounds__(1024) void k_collect_stats(Ctl *ctl, unsigned long 
 // ... and, behind a PROFILED bid launch, the edges that launch scanned (options.profile)
 __global__ __launch_bounds__(1024) void k_take_launch_edges(unsigned long long *wg_stats, int n_slots, unsigned long long *out) {
     __shared__ unsigned long long s_w[16];
-    unsigned long long v = 0;
+    unsigned long long v = 0, vh = 0;
     for (int k = threadIdx.x; k < n_slots; k += 1024) {
         unsigned long long *st = wg_stats + (size_t)kStatWords * k;
         v += st[kStatLaunchEdges];
+        vh += st[kStatLaunchHitEdges];
         st[kStatLaunchEdges] = 0ull;
+        st[kStatLaunchHitEdges] = 0ull;
     }
     const unsigned long long t = block_sum_u64(v, s_w);
-    if (threadIdx.x == 0) *out += t;
+    const unsigned long long th = block_sum_u64(vh, s_w);
+    if (threadIdx.x == 0) {
+        out[0] += t;
+        out[1] += th;
+    }
 }
 // list position n has won object j: price, eviction, assignment; returns 1 if the slot becomes a hole
 __device__ __forceinline__ int apply_winner_of(const RoundArgs &a, Ctl *ctl, int j, int n) {

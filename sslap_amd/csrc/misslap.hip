@@ -735,7 +735,7 @@ int launch_bid_tiled(misslap_solver *h) {
     }
     if (pr) {  // (the round's k_tiebreak adds the workgroups' counts up: no launch of its own inside a timed solve)
         h->take_edges_n = (int)grid;
-        h->take_edges_out = h->launch_edges + pr->launch_idx;
+        h->take_edges_out = h->launch_edges + 2 * (size_t)pr->launch_idx;
     }
     HIP_TRY(hipGetLastError());
     return MISSLAP_OK;
@@ -801,9 +801,9 @@ int launch_bid(misslap_solver *h) {
 #undef MISSLAP_LAUNCH_BID
     if (pr && !h->round_small) {
         h->take_edges_n = std::max(h->take_edges_n, grid);  // (a full-scan engine launch of the same round may be pending too)
-        h->take_edges_out = h->launch_edges + pr->launch_idx;
+        h->take_edges_out = h->launch_edges + 2 * (size_t)pr->launch_idx;
     } else if (pr) {  // (no k_tiebreak in a round that k_round_small finishes; such launches are profiled at level 2 / 3 only)
-        hipLaunchKernelGGL(k_take_launch_edges, dim3(1), dim3(1024), 0, h->stream, h->wg_stats, grid, h->launch_edges + pr->launch_idx);
+        hipLaunchKernelGGL(k_take_launch_edges, dim3(1), dim3(1024), 0, h->stream, h->wg_stats, grid, h->launch_edges + 2 * (size_t)pr->launch_idx);
     }
     HIP_TRY(hipGetLastError());
     h->phase_fresh = false;
@@ -1372,7 +1372,7 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
         }
         if (h->profile) {
             h->launch_edges_cap = 1 << 20;
-            blk.want(&h->launch_edges, (size_t)h->launch_edges_cap);
+            blk.want(&h->launch_edges, 2 * (size_t)h->launch_edges_cap);  // {edges, of which answered from lines} per launch
         }
         h->blocks.emplace_back();
         if ((rc = blk.commit(&h->blocks.back()))) return rc;
@@ -1382,7 +1382,7 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
     HIP_TRY(hipMemsetAsync(h->wg_stats, 0, sizeof(unsigned long long) * kStatWords * (size_t)h->wg_stats_slots, h->stream));
     if (h->split_cnt) HIP_TRY(hipMemsetAsync(h->split_cnt, 0, sizeof(int) * ((size_t)N / 256 + 1024), h->stream));
     if (h->profile)
-        HIP_TRY(hipMemsetAsync(h->launch_edges, 0, sizeof(unsigned long long) * h->launch_edges_cap, h->stream));
+        HIP_TRY(hipMemsetAsync(h->launch_edges, 0, sizeof(unsigned long long) * 2 * (size_t)h->launch_edges_cap, h->stream));
     // the mirror, the two trailing status copies and the live status words (kept together: one pooled allocation)
     // (coherent + mapped EXPLICITLY: with HIP_HOST_COHERENT=0 in the environment a default allocation is not coherent,
     // and the kernels' system-scope stores to the live words would become visible at sync points only)
@@ -2260,7 +2260,7 @@ MISSLAP_API int misslap_finish(misslap_solver *h, int32_t *person_to_object_out,
     meta->cand_edges = c.cand_edges;
     meta->sharded_rounds = h->sharded_rounds;
     if (h->profile && h->prof_used) {
-        std::vector<unsigned long long> le((size_t)h->launch_idx);
+        std::vector<unsigned long long> le(2 * (size_t)h->launch_idx);
         if (h->launch_idx)
             HIP_TRY(hipMemcpy(le.data(), h->launch_edges, sizeof(unsigned long long) * le.size(),
                               hipMemcpyDeviceToHost));
@@ -2269,11 +2269,12 @@ MISSLAP_API int misslap_finish(misslap_solver *h, int32_t *person_to_object_out,
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, r.start, r.stop) != hipSuccess) continue;
             if (r.kind == 0 || r.kind == 2) {
-                const unsigned long long e = le[(size_t)r.launch_idx];
+                const unsigned long long e = le[2 * (size_t)r.launch_idx], eh = le[2 * (size_t)r.launch_idx + 1];
                 if (r.kind == 0) {
                     meta->bid_launches += 1;  // self-skipped (no-op) launches included, like a kernel trace
                     meta->bid_ms += ms;
                     meta->bid_edges += e;
+                    meta->bid_edges_read += e - eh;
                 } else {
                     meta->tiled_launches += 1;
                     meta->tiled_ms += ms;
@@ -2283,6 +2284,7 @@ MISSLAP_API int misslap_finish(misslap_solver *h, int32_t *person_to_object_out,
                     meta->fullscan_launches += 1;
                     meta->fullscan_ms += ms;
                     meta->fullscan_edges += e;
+                    meta->fullscan_edges_read += e - (r.kind == 0 ? eh : 0ull);
                 }
             } else {
                 meta->tail_launches += 1;
@@ -2297,6 +2299,8 @@ MISSLAP_API int misslap_finish(misslap_solver *h, int32_t *person_to_object_out,
         static_assert(offsetof(misslap_meta, complete_assignment) - offsetof(misslap_meta, start_eps) == sizeof(misslap_meta_v1),
                       "misslap_meta = {struct_size, abi_version} + the version-1 fields + appended fields");
         std::memcpy(&v1, &full.start_eps, sizeof(v1));
+        v1.merge_launches = 0;  // (version 2 re-uses these two slots: bid_edges_read / fullscan_edges_read)
+        v1.merge_ms = 0.0;
         std::memcpy(meta_out, &v1, sizeof(v1));
     }
     return MISSLAP_OK;
@@ -2362,6 +2366,39 @@ MISSLAP_API int misslap_rccl_unique_id(void *id_out) {
     const int rc = api.GetUniqueId(&id);
     if (rc) return fail(MISSLAP_ERR_HIP, "ncclGetUniqueId failed: %s", api.GetErrorString(rc));
     std::memcpy(id_out, &id, sizeof(id));
+    return MISSLAP_OK;
+}
+
+MISSLAP_API int misslap_rccl_selfcheck(int32_t *n_symbols, int32_t enums[6], char *lib_path, int32_t lib_path_len) {
+    RcclApi &api = rccl_api();
+    if (!api.handle) return fail(MISSLAP_ERR_HIP, "%s", api.error.c_str());
+    int n = 0;
+    n += api.GetUniqueId != nullptr;
+    n += api.CommInitRank != nullptr;
+    n += api.CommDestroy != nullptr;
+    n += api.AllReduce != nullptr;
+    n += api.GetErrorString != nullptr;
+    n += api.CommCount != nullptr;
+    if (n_symbols) *n_symbols = n;
+    if (enums) {
+        enums[0] = kNcclInt32;
+        enums[1] = kNcclInt64;
+        enums[2] = kNcclMax;
+        enums[3] = kNcclMin;
+        enums[4] = (int32_t)sizeof(RcclApi::UniqueId);
+        enums[5] = 0;
+        if (auto ver = reinterpret_cast<int (*)(int *)>(dlsym(api.handle, "ncclGetVersion"))) {
+            int v = 0;
+            if (ver(&v) == 0) enums[5] = v;
+        }
+    }
+    if (lib_path && lib_path_len > 0) {
+        lib_path[0] = 0;
+        Dl_info di;
+        if (api.AllReduce && dladdr(reinterpret_cast<void *>(api.AllReduce), &di) && di.dli_fname)
+            snprintf(lib_path, (size_t)lib_path_len, "%s", di.dli_fname);
+    }
+    if (n != MISSLAP_RCCL_SYMBOLS) return fail(MISSLAP_ERR_HIP, "%s", api.error.empty() ? "librccl: a symbol is missing" : api.error.c_str());
     return MISSLAP_OK;
 }
 

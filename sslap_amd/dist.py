@@ -25,6 +25,9 @@ Communicators:
     Comm.custom(rank, world, max_cb, min_cb)   caller-provided all-reduces (ptr, count, stream) -- other transports
     Comm.gloo_staged(group=None)               rehearsal on ONE GPU: several ranks share cuda:0, the exchange is
                                                staged through the host with gloo (RCCL needs a GPU per rank)
+    Comm.in_process(rank, group)               rehearsal with the ranks as THREADS of one process (ThreadGroup): what a
+                                               one-GPU box allows beyond the handful of processes it admits on its card
+                                               (W = 8); the exchange is staged through the host and reduced with numpy
 """
 import ctypes as C
 
@@ -122,6 +125,63 @@ class Comm:
                 torch.cuda.synchronize()  # ... and may read it again
             return fn
         return cls.custom(rank, world, staged(dist.ReduceOp.MAX, "<i8"), staged(dist.ReduceOp.MIN, "<i4"))
+
+    @classmethod
+    def in_process(cls, rank, group):
+        """Rank `rank` of a ThreadGroup: the ranks are threads of ONE process that share a GPU (rehearsal / tests; a
+        one-GPU box admits only a handful of processes on its card, so W = 8 goes this way).  The exchange is the same
+        pair of callbacks as gloo_staged, reduced with numpy: the device buffer is copied out ON THE SOLVER'S STREAM
+        (ordered behind the bid kernel), reduced over the threads, copied back on that stream."""
+        import numpy as np
+        import torch
+
+        def staged(op, typestr):
+            def fn(ptr, count, stream):
+                st = torch.cuda.ExternalStream(int(stream or 0))
+                with torch.cuda.stream(st):
+                    t = torch.as_tensor(_DevArray(ptr, count, typestr), device=torch.device("cuda", torch.cuda.current_device()))
+                    h = t.cpu().numpy()  # (synchronous: the stream has produced the buffer)
+                    r = group.all_reduce(rank, h, op)
+                    t.copy_(torch.from_numpy(np.ascontiguousarray(r)))
+                    st.synchronize()  # the host array must outlive the copy
+            return fn
+        return cls.custom(rank, group.world, staged("max", "<i8"), staged("min", "<i4"))
+
+
+class ThreadGroup:
+    """The ranks of an in-process rehearsal (one thread per rank): barrier, all-reduce of host arrays, all-gather of
+    Python objects.  Every wait is bounded: a rank that fails breaks the barrier and the others raise instead of
+    hanging."""
+
+    def __init__(self, world, timeout_s=600.0):
+        import threading
+        self.world, self.timeout_s = int(world), float(timeout_s)
+        self._bar = threading.Barrier(self.world)
+        self._slots = [None] * self.world
+        self._result = None
+
+    def barrier(self):
+        self._bar.wait(self.timeout_s)
+
+    def abort(self):
+        self._bar.abort()
+
+    def all_gather(self, rank, obj):
+        self._slots[rank] = obj
+        self._bar.wait(self.timeout_s)
+        out = list(self._slots)
+        self._bar.wait(self.timeout_s)  # (everybody has read the slots before the next call rewrites them)
+        return out
+
+    def all_reduce(self, rank, arr, op):
+        """op: 'max' | 'min' | 'sum' over numpy arrays (or scalars) of equal shape; every rank gets the result."""
+        import numpy as np
+        parts = self.all_gather(rank, arr)
+        f = {"max": np.maximum, "min": np.minimum, "sum": np.add}[op]
+        out = parts[0]
+        for x in parts[1:]:  # (every rank reduces in the same order: identical results)
+            out = f(out, x)
+        return out
 
 
 class _DevArray:

@@ -133,3 +133,33 @@ def test_bench_gpus_2_launches_itself_on_one_gpu_under_gloo(mode, cfg, gpu_lib):
         assert d["sharded_rounds_per_solve"] > 0 and d["exchanges_per_solve"] == 2 * d["sharded_rounds_per_solve"]
     else:
         assert d["comm_kind"] is None and d["exchanges_per_solve"] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("backend,n,cfg", [("threads", 8, "C5"), ("gloo", 4, "C3")])
+def test_bench_line_of_the_many_rank_run_is_well_formed_on_one_gpu(backend, n, cfg, gpu_lib):
+    """BASELINE config 5 as stated -- C5 sharded over EIGHT ranks -- rehearsed on the one GPU a box has: the eight ranks
+    are threads of one bench.py process (MISSLAP_DIST_BACKEND=threads; eight rank processes would exceed the handful a
+    one-GPU box admits on its card), and C3 over four rank PROCESSES under gloo.  The line must be the N-rank line the
+    driver will read on an 8-GPU node: one JSON object, the reference's assignment on every rank, every rank's
+    communicator reporting N ranks, exchanges = 2 x sharded rounds."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(MISSLAP_DIST_BACKEND=backend)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0",
+                        "--no-cpu", "--config", cfg], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "large_cases.json")))["cases"][cfg]
+    assert d["n_gpus"] == n and d["scaling"] == "strong" and d["sol_sha256"] == g["sol_sha256"] and d["rounds"] == g["meta"]["its"]
+    assert [x["rank"] for x in d["ranks"]] == list(range(n)) and d["sol_sha256_equal_on_all_ranks"] is True
+    assert all(x["sol_sha256"] == g["sol_sha256"] for x in d["ranks"])
+    assert d["comm_kind"] == "custom" and d["comm_ranks_seen_by_every_rank"] == [n] * n
+    assert d["sharded_rounds_per_solve"] > 0 and d["exchanges_per_solve"] == 2 * d["sharded_rounds_per_solve"]
+    assert d["distinct_gpus"] == 1 and ("THREAD" in d["rank_transport"]) == (backend == "threads")
+    assert d["value"] > 0 and d["roofline"]["frac"] <= 1.0 and d["cpu_baseline"] is None
+    # unique work: the ranks' shares of the sharded rounds + the replicated rounds once = the single-GPU edge count
+    assert round(d["value"] * d["ms_per_step"] * 1e3) == pytest.approx(g["edges_scanned"], rel=1e-3)

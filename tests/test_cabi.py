@@ -33,7 +33,7 @@ def test_struct_layouts_match_header():
     import tempfile
     fields = {"misslap_options": ["max_iter", "tail_threshold", "rounds_per_sync", "tiled_min_K", "cand_mode",
                                   "cand_refresh_min", "reserved", "input_stream"],
-              "misslap_meta": ["struct_size", "start_eps", "its", "obj_f64", "edges_scanned", "bid_ms", "tail_edges", "tiled_min_K", "merge_ms", "shard_edges", "cand_hits", "tail_stats",
+              "misslap_meta": ["struct_size", "start_eps", "its", "obj_f64", "edges_scanned", "bid_ms", "tail_edges", "tiled_min_K", "bid_edges_read", "fullscan_edges_read", "shard_edges", "cand_hits", "tail_stats",
                                "complete_assignment", "valid_assignment", "lines_active", "sharded_rounds"],
               "misslap_status": ["K", "error_bits", "rounds_per_sync", "shard_min_K"]}
     prog = ['#include <stdio.h>', '#include <stddef.h>', '#include "misslap.h"', 'int main(void){']
@@ -171,3 +171,35 @@ def test_header_is_plain_c_and_the_c_client_compiles(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.check_call([cc, "-std=c11", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(root, "include"),
                            "-c", os.path.join(root, "tests", "cabi_client.c"), "-o", str(tmp_path / "client.o")])
+
+
+def test_rccl_binding_matches_the_installed_header():
+    """The RCCL path with more than one rank cannot run on a one-GPU box; what CAN be pinned without a GPU: the library's
+    own dlopen of librccl finds a copy, every entry point the exchange uses resolves, and the enumerator values and the
+    id size it compiled in equal the installed rccl.h (a silent change of ncclDataType_t / ncclRedOp_t would turn the
+    MAX all-reduce into something else on the first 8-GPU run)."""
+    hdr = None
+    for cand in ("/opt/rocm/include/rccl/rccl.h", "/opt/rocm/include/rccl.h"):
+        if os.path.exists(cand):
+            hdr = open(cand).read()
+            break
+    if hdr is None:
+        pytest.skip("rccl.h is not installed")
+    n, enums, path = C.c_int32(), (C.c_int32 * 6)(), C.create_string_buffer(512)
+    rc = _lib.load().misslap_rccl_selfcheck(C.byref(n), enums, path, 512)
+    assert rc == 0, _lib.load().misslap_last_error()
+    assert n.value == 6 and b"rccl" in path.value
+
+    def enum_value(name):
+        m = re.search(r"\b%s\s*=\s*(\d+)" % name, hdr)
+        assert m, name
+        return int(m.group(1))
+    assert [enums[k] for k in range(4)] == [enum_value("ncclInt32"), enum_value("ncclInt64"), enum_value("ncclMax"),
+                                            enum_value("ncclMin")]
+    assert enums[4] == int(re.search(r"#define\s+NCCL_UNIQUE_ID_BYTES\s+(\d+)", hdr).group(1)) == 128
+    assert enums[5] >= 20000  # ncclGetVersion of the copy the library bound to (2.x.y as 2xxyy)
+    # the prototypes the function pointers were declared from (argument order of the two calls that carry data)
+    assert re.search(r"ncclAllReduce\(const void\*\s*sendbuff,\s*void\*\s*recvbuff,\s*size_t count,\s*ncclDataType_t datatype,\s*"
+                     r"ncclRedOp_t op,\s*ncclComm_t comm,\s*hipStream_t stream\)", hdr)
+    assert re.search(r"ncclCommInitRank\(ncclComm_t\*\s*comm,\s*int nranks,\s*ncclUniqueId commId,\s*int rank\)", hdr)
+    assert re.search(r"ncclCommCount\(const ncclComm_t comm,\s*int\*\s*count\)", hdr)

@@ -1,5 +1,6 @@
 """CPU suite, part 3: the sharded solve loop of the LIBRARY (misslap_drive_sharded, csrc/host_comm.hpp -- the loop
-misslap_solve_sharded runs on a GPU handle) with world_size 2 on the gloo backend.  The per-rank round operations
+misslap_solve_sharded runs on a GPU handle) with world_size 2, 3 and 8 on the gloo backend (uneven shard ranges
+[K r / W, K (r + 1) / W), ranks with an EMPTY range when K < W).  The per-rank round operations
 are the numpy stand-ins of tests/_numpy_backend.py, handed to the C loop as callbacks; the exchange is a custom
 communicator whose callbacks all-reduce the (host) buffers with gloo.  Under test: shard ranges, MAX / MIN exchange
 sequence, replicated apply, loop control -- the result must be bit-identical to the single-process oracle, and
@@ -108,21 +109,30 @@ def _worker(rank, world, port, spec, prob, max_iter, shard_min_K, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("spec,prob,max_iter,shard_min_K", [
-    (dict(kind="sparse", n=64, m=64, density=0.1), "max", 10**8, 0),            # every round exchanged
-    (dict(kind="sparse", n=60, m=60, density=0.15, ints=3), "max", 10**8, 0),   # cross-rank equal bids
-    (dict(kind="sparse", n=40, m=60, density=0.2), "min", 10**8, 0),            # rectangular
-    (dict(kind="sparse", n=64, m=64, density=0.1), "max", 7, 0),                # stops at max_iter
-    (dict(kind="sparse", n=64, m=64, density=0.1), "max", 10**8, 20),           # big rounds sharded, rest replicated
-    (dict(kind="sparse", n=60, m=60, density=0.15, ints=3), "min", 10**8, 30),
+@pytest.mark.parametrize("world,spec,prob,max_iter,shard_min_K", [
+    (2, dict(kind="sparse", n=64, m=64, density=0.1), "max", 10**8, 0),            # every round exchanged
+    (2, dict(kind="sparse", n=60, m=60, density=0.15, ints=3), "max", 10**8, 0),   # cross-rank equal bids
+    (2, dict(kind="sparse", n=40, m=60, density=0.2), "min", 10**8, 0),            # rectangular
+    (2, dict(kind="sparse", n=64, m=64, density=0.1), "max", 7, 0),                # stops at max_iter
+    (2, dict(kind="sparse", n=64, m=64, density=0.1), "max", 10**8, 20),           # big rounds sharded, rest replicated
+    (2, dict(kind="sparse", n=60, m=60, density=0.15, ints=3), "min", 10**8, 30),
+    # three ranks: K r / 3 is uneven in almost every round
+    (3, dict(kind="sparse", n=64, m=64, density=0.1), "max", 10**8, 0),
+    (3, dict(kind="sparse", n=61, m=61, density=0.15, ints=3), "min", 10**8, 0),   # ties across uneven shards
+    (3, dict(kind="sparse", n=64, m=64, density=0.1), "max", 10**8, 20),
+    # eight ranks (BASELINE config 5's world size): shards of 8 positions and fewer, EMPTY shards as soon as K < 8
+    (8, dict(kind="sparse", n=64, m=64, density=0.1), "max", 10**8, 0),
+    (8, dict(kind="sparse", n=60, m=60, density=0.15, ints=3), "max", 10**8, 0),
+    (8, dict(kind="sparse", n=6, m=6, density=0.7), "max", 10**8, 0),              # K < W from the first round on
+    (8, dict(kind="sparse", n=40, m=60, density=0.2), "min", 10**8, 25),           # rectangular, mixed regime
 ])
-def test_sharded_c_loop_world2_matches_oracle(spec, prob, max_iter, shard_min_K, built_lib):
+def test_sharded_c_loop_matches_oracle(world, spec, prob, max_iter, shard_min_K, built_lib):
     import cases
     from oracle import oracle as orc
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, spec, prob, max_iter, shard_min_K, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, spec, prob, max_iter, shard_min_K, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=240) for _ in procs)
@@ -142,7 +152,7 @@ def test_sharded_c_loop_world2_matches_oracle(spec, prob, max_iter, shard_min_K,
             assert n_exchanges == 2 * n_bids                       # ... one pair per (sharded) round
         else:
             assert n_exchanges < 2 * n_bids                        # the small rounds are replicated, not exchanged
-    assert res[0][5] == res[1][5]                                  # both ranks issued the same collectives
+    assert len({r[5] for r in res}) == 1 and len(res) == world     # every rank issued the same collectives
 
 
 def test_single_rank_c_loop_matches_oracle(built_lib):

@@ -1177,65 +1177,154 @@ def test_falling_prices_without_lines_equal_the_reference(thr, gpu_lib):
     assert np.array_equal(sg["p2o"], so["p2o"]) and np.array_equal(sol, so["p2o"]) and np.array_equal(sg["U"], so["U"])
 
 
+_CFG_STORE = {}
+
+
+def _config_arrays(cfg):
+    """(loc, val) of a BASELINE config, generated once per session (C5 takes a minute) and kept on /dev/shm for the rank
+    processes of the sharded tests, which load the files instead of generating the input W more times."""
+    import os
+    import tempfile
+    if cfg not in _CFG_STORE:
+        loc, val = synth.gen_config(cfg)
+        d = tempfile.mkdtemp(prefix="misslap_cfg_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        paths = (os.path.join(d, cfg + "_loc.npy"), os.path.join(d, cfg + "_val.npy"))
+        np.save(paths[0], loc)
+        np.save(paths[1], val)
+        _CFG_STORE[cfg] = (loc, val, paths)
+    return _CFG_STORE[cfg]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _drop_config_store():
+    yield
+    import shutil
+    import os
+    for _, _, paths in _CFG_STORE.values():
+        shutil.rmtree(os.path.dirname(paths[0]), ignore_errors=True)
+    _CFG_STORE.clear()
+
+
+def _sharded_result(s, sol, comm):
+    return (synth.sol_digest(sol), s.meta["its"], s.meta["nreductions"], s.gpu["obj_f64"], s.gpu["edges_scanned"],
+            s.gpu["shard_edges"], s.gpu["sharded_rounds"], s.shard_min_K, comm.info())
+
+
 def _dist_cfg_worker(rank, world, port, cfgs, out):
     import os
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in (root, os.path.join(root, "tests"), os.path.join(root, "tests", "golden")):
         sys.path.insert(0, p)
+    import numpy as np
     import torch
     import torch.distributed as dist
-    from sslap_amd import from_sparse, synth
+    from sslap_amd import from_sparse
     from sslap_amd.dist import Comm, solve_sharded
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     comm = Comm.gloo_staged()
     res = {}
-    for cfg in cfgs:
-        loc, val = synth.gen_config(cfg)
+    for cfg, (loc_path, val_path) in cfgs.items():
+        loc, val = np.load(loc_path), np.load(val_path)
         s = from_sparse(loc, val, problem="max", cardinality_check=False, shard=(rank, world), max_iter=10**8)
         sol = solve_sharded(s, comm)  # library defaults: shard_min_K = the full-scan threshold
-        res[cfg] = (synth.sol_digest(sol), s.meta["its"], s.meta["nreductions"], s.gpu["obj_f64"], s.gpu["edges_scanned"],
-                    s.gpu["shard_edges"], s.gpu["sharded_rounds"], s.shard_min_K, comm.info())
-        del s
+        res[cfg] = _sharded_result(s, sol, comm)
+        del s, loc, val
     out.put((rank, res))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_sharded_solve_at_baseline_sizes_two_ranks_one_gpu(golden_large, gpu_lib):
-    """The sharded path at BASELINE sizes with the library's default shard threshold: C2 and C4 (the config with the
-    most sharded rounds per solve, 26 of 176) solved by two ranks that share cuda:0 and exchange through the custom
-    communicator (gloo, staged through the host).  Every rank must return the reference's assignment (sha256 of the
-    fixture captured from the real reference), and the sharded rounds' shares must add up to the single-GPU count."""
+def _check_sharded_results(got, world, cfgs, golden_large):
+    for cfg in cfgs:
+        g = golden_large["cases"][cfg]
+        for rank in range(world):
+            sha, its, nred, obj, edges, sh, rounds, smk, info = got[rank][cfg]
+            assert sha == g["sol_sha256"], (cfg, rank)
+            assert (its, nred, obj) == (g["meta"]["its"], g["meta"]["nreductions"], g["obj_f64"]), (cfg, rank)
+            assert info == dict(kind="custom", rank=rank, world=world, transport_ranks=world)
+            assert rounds > 0 and sh > 0 and smk >= 8192
+        per_rank = [got[r][cfg][4:7] for r in range(world)]
+        assert len({r for _, _, r in per_rank}) == 1                 # the same rounds were sharded on every rank
+        assert len({e - s for e, s, _ in per_rank}) == 1            # the replicated part is identical
+        e0, s0, _ = per_rank[0]
+        # unique work = the single-GPU (= the reference's) edge count: the ranks' shares of the sharded rounds add up
+        assert sum(s for _, s, _ in per_rank) + (e0 - s0) == g["edges_scanned"], cfg
+
+
+@pytest.mark.parametrize("world,cfgs", [(2, ("C2", "C4")), (4, ("C3", "C5"))])
+def test_sharded_solve_at_baseline_sizes_rank_processes_one_gpu(world, cfgs, golden_large, gpu_lib):
+    """The sharded path at BASELINE sizes with the library's default shard threshold, the ranks as PROCESSES that share
+    cuda:0 and exchange through the custom communicator (gloo, staged through the host): two ranks on C2 and C4 (the
+    config with the most sharded rounds per solve, 26 of 176), four ranks on C3 and C5 -- BASELINE config 5 is "C5
+    sharded".  (A one-GPU box of this pool admits six processes on its card: four ranks + this one; eight ranks run as
+    threads, below.)  Every rank must return the reference's assignment (sha256 of the fixture captured from the real
+    reference), and the sharded rounds' shares must add up to the single-GPU count."""
     import socket
     import torch.multiprocessing as mp
-    cfgs = ("C2", "C4")
+    paths = {cfg: _config_arrays(cfg)[2] for cfg in cfgs}
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_dist_cfg_worker, args=(r, 2, port, cfgs, q)) for r in range(2)]
+    procs = [ctx.Process(target=_dist_cfg_worker, args=(r, world, port, paths, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = dict(q.get(timeout=600) for _ in procs)
+    got = dict(q.get(timeout=900) for _ in procs)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    _check_sharded_results(got, world, cfgs, golden_large)
+    if "C4" in cfgs:
+        assert got[0]["C4"][6] >= 20  # 26 sharded rounds per C4 solve
+
+
+@pytest.mark.parametrize("world,cfgs", [(8, ("C2", "C3", "C4", "C5")), (3, ("C4",))])
+def test_sharded_solve_at_baseline_sizes_rank_threads_one_gpu(world, cfgs, golden_large, gpu_lib):
+    """Eight ranks -- BASELINE config 5's world size -- on every BASELINE GPU config, and three (uneven shard ranges on the
+    real kernels): the ranks are THREADS of this process (sslap_amd.dist.ThreadGroup / Comm.in_process: eight rank
+    processes would exceed what a one-GPU box admits on its card), each with its own handle, stream and communicator;
+    the library's loop issues the same exchange calls as with RCCL, the buffers are reduced on the host."""
+    import threading
+    from sslap_amd.dist import Comm, ThreadGroup, solve_sharded
+    got, errs = {}, []
     for cfg in cfgs:
-        g = golden_large["cases"][cfg]
-        for rank in (0, 1):
-            sha, its, nred, obj, edges, sh, rounds, smk, info = got[rank][cfg]
-            assert sha == g["sol_sha256"], (cfg, rank)
-            assert (its, nred, obj) == (g["meta"]["its"], g["meta"]["nreductions"], g["obj_f64"]), (cfg, rank)
-            assert info == dict(kind="custom", rank=rank, world=2, transport_ranks=2)
-            assert rounds > 0 and sh > 0 and smk >= 8192
-        (e0, s0, r0), (e1, s1, r1) = got[0][cfg][4:7], got[1][cfg][4:7]
-        assert r0 == r1 and e0 - s0 == e1 - s1  # the same rounds were sharded; the replicated part is identical
-        assert s0 + s1 + (e0 - s0) == g["edges_scanned"]  # unique work = the single-GPU (= the reference's) edge count
-    assert got[0]["C4"][6] >= 20  # 26 sharded rounds per C4 solve
+        loc, val, _ = _config_arrays(cfg)
+        group = ThreadGroup(world, timeout_s=600.0)
+
+        def rank_main(rank):
+            try:
+                comm = Comm.in_process(rank, group)
+                s = from_sparse(loc, val, problem="max", cardinality_check=False, shard=(rank, world), max_iter=10**8)
+                sol = solve_sharded(s, comm)
+                got.setdefault(rank, {})[cfg] = _sharded_result(s, sol, comm)
+            except Exception as e:  # noqa: BLE001
+                errs.append((cfg, rank, repr(e)))
+                group.abort()
+        th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs[:3]
+    _check_sharded_results(got, world, cfgs, golden_large)
+
+
+def test_final_pass_grid_fits_its_result_slots_at_any_size(gpu_lib):
+    """450 000 persons on the 16-lanes-per-person shape of the full-scan engine: the final pass (eCE / objective /
+    validity flags on the engine) launches ceil(N / 208) = 2164 workgroups, more than the 2048 + N / 256 result slots the
+    handle used to allocate -- misslap_finish then failed AFTER a complete solve.  Three rounds are enough to reach it."""
+    n = 450_000
+    loc, val = synth.gen_sparse(n, n, 16.0 / n, seed=11)
+    s = from_sparse(loc, val, problem="max", cardinality_check=False, max_iter=3, tiled_min_k=1, tiled_shape=9, engine=1)
+    sol = s.solve()
+    assert s.gpu["tiled_active"] == 1 and s.meta["its"] == 3
+    o = orc.from_sparse(loc, val.copy(), problem="max", max_iter=3, cardinality_check=False)
+    assert np.array_equal(sol, o.solve())
+    assert s.gpu["obj_f64"] == o.extra["obj_f64"] and s.gpu["edges_scanned"] == o.extra["edges_scanned"]
 
 
 def test_measured_hbm_rates_and_device_uuid(gpu_lib):
