@@ -33,13 +33,13 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); measured copy peak is ~6300
 
 
-def cpu_baseline(cfg, budget_rounds, whole):
+def cpu_baseline(cfg, budget_rounds, whole, args=None):
     """Oracle (port of the reference, single thread like the reference, faithful O(M) assignment walk) on the same
     workload: the first `budget_rounds` rounds as the bounded sample, and -- `whole` -- the complete solve in the
     same run (about 30-50 s at C3; the sample over-weights the big bandwidth-bound rounds of the first phase)."""
     from oracle import oracle as orc
     from sslap_amd import synth
-    loc, val = synth.gen_config(cfg)
+    loc, val = workload(args, synth) if args is not None else synth.gen_config(cfg)
     s = orc.from_sparse(loc, val, problem="max", max_iter=10**8, cardinality_check=False)
     s.set_timing(True)
     t0 = time.perf_counter()
@@ -71,6 +71,17 @@ def cpu_baseline(cfg, budget_rounds, whole):
         out.update(whole_solve_medges_s=round(int(m.edges_scanned) / dt / 1e6, 2), whole_solve_s=round(dt, 2),
                    whole_solve_rounds=int(m.its), whole_solve_edges=int(m.edges_scanned))
     return out
+
+
+def workload(args, synth):
+    """The synthetic input of the run: a BASELINE config (sslap_amd.synth, seed 1), optionally with values that are not
+    fp32-exact and / or a random stored order inside the rows."""
+    loc, val = synth.gen_config(args.config)
+    if args.values == "f64":
+        val = val * (1.0 + 2.0 ** -30)  # no longer fp32-representable: the 12 B/edge layout
+    if args.shuffle_rows:
+        loc, val = synth.shuffle_within_rows(loc, val, 5)
+    return loc, val
 
 
 def launch_ranks(n, argv):
@@ -253,6 +264,12 @@ def main():
     ap.add_argument("--cpu-rounds", type=int, default=100_000)
     ap.add_argument("--cpu-sample-only", action="store_true", help="cpu_baseline: the bounded sample only")
     ap.add_argument("--tail-threshold", type=int, default=None)
+    ap.add_argument("--values", choices=("f32", "f64", "f32-as-f64"), default="f32",
+                    help="f32: the BASELINE configs' fp32-exact costs (8 B/edge, the default and the metric's config); f64: the "
+                         "same draws times (1 + 2^-30) -- arbitrary doubles, the reference's native value type: 12 B/edge; "
+                         "f32-as-f64: the fp32-exact costs in the 12 B/edge layout (same assignment as the fixture)")
+    ap.add_argument("--shuffle-rows", action="store_true",
+                    help="random stored order inside every row (columns not ascending: the engine carries the stored index)")
     ap.add_argument("--concurrent", type=int, default=0,
                     help="N = 1 only: after the timed single-solve steps, B independent solves at a time from B host "
                          "threads (B handles, B streams); reported beside the single-solve `value`, never instead of it")
@@ -288,7 +305,7 @@ def main():
         import threading
         from sslap_amd import dist as mdist
         torch.cuda.set_device(0)
-        loc, val = synth.gen_config(args.config)
+        loc, val = workload(args, synth)
         shared = (torch.from_numpy(loc).cuda(), torch.from_numpy(val).cuda(), int(loc.shape[0]))
         del loc, val
         torch.cuda.synchronize()
@@ -352,7 +369,7 @@ def run_rank(args, rank, world, local_rank, ranks, comm, shared, backend):
     if shared is not None:
         d_loc, d_val, nnz = shared
     else:
-        loc, val = synth.gen_config(args.config)
+        loc, val = workload(args, synth)
         nnz = int(loc.shape[0])
         d_loc = torch.from_numpy(loc).cuda()
         d_val = torch.from_numpy(val).cuda()
@@ -361,6 +378,8 @@ def run_rank(args, rank, world, local_rank, ranks, comm, shared, backend):
     gpu_opts = dict(device=local_rank, profile=True, input_stream=torch.cuda.current_stream().cuda_stream)
     if args.tail_threshold is not None:
         gpu_opts["tail_threshold"] = args.tail_threshold
+    if args.values == "f32-as-f64":
+        gpu_opts["force_f64"] = True
 
     def one_step():
         if world == 1 or replicas:
@@ -492,7 +511,7 @@ def run_rank(args, rank, world, local_rank, ranks, comm, shared, backend):
         # COO input (16 B per entry, pageable numpy memory)
         incl_h2d = None
         if world == 1 and args.config != "C5":
-            loc_h, val_h = synth.gen_config(args.config)
+            loc_h, val_h = workload(args, synth)
             t_h = time.perf_counter()
             sh = AuctionSolver(loc_h, val_h, problem="max", max_iter=10**8, device=local_rank)
             sh.solve()
@@ -535,7 +554,12 @@ def run_rank(args, rank, world, local_rank, ranks, comm, shared, backend):
             "config": {"workload": f"{args.config} {int(s.num_rows)}x{int(s.num_cols)} sparse LAP "
                                    f"(BASELINE.json configs), one full auction_solve per step",
                        "n_rows": int(s.num_rows), "n_cols": int(s.num_cols), "nnz": nnz,
-                       "problem": "max", "values": "fp32-exact, carried as f64 (prices/bids f64, eps f32)",
+                       "problem": "max",
+                       "values": {"f32": "fp32-exact, carried as f64 (prices/bids f64, eps f32)",
+                                  "f64": "arbitrary doubles (fp32 draws x (1 + 2^-30)): int32 col + fp64 val",
+                                  "f32-as-f64": "fp32-exact values in the 12 B/edge layout (int32 col + fp64 val)"}[args.values],
+                       "rows": "stored order shuffled inside every row" if args.shuffle_rows else "columns ascending",
+                       "tile_major_format": gpu.get("tiled_format") if gpu.get("tiled_active") else None,
                        "bytes_per_edge": bpe, "generator": "sslap_amd.synth seed=1"},
             "solve_ms": round(sum(g["solve_ms"] for _, g in runs) / len(runs), 3),
             "setup_ms": round(sum(g["setup_ms"] for _, g in runs) / len(runs), 3),
@@ -615,7 +639,7 @@ def run_rank(args, rank, world, local_rank, ranks, comm, shared, backend):
         }
         if world == 1 and not args.no_cpu:
             whole = not args.cpu_sample_only and args.config != "C5"  # (C5: ~20 min of oracle time)
-            out["cpu_baseline"] = cpu_baseline(args.config, args.cpu_rounds, whole)
+            out["cpu_baseline"] = cpu_baseline(args.config, args.cpu_rounds, whole, args)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

@@ -145,6 +145,14 @@ typedef struct misslap_meta {
     int32_t reserved_i;
     int64_t sharded_rounds;      /* multi-GPU: rounds whose bidders were sharded over the ranks -- each of them issued the
                                     two all-reduces of the exchange step on this rank (0 on a single GPU) */
+    /* appended in round 5 */
+    int32_t tiled_format;        /* record format of the full-scan engine's tile-major copy (tiled_active = 1): 0 = 6 B/edge
+                                    {u16 price slot, f32 value}, 1 = 10 B/edge {slot, f64 value}, 2 / 3 = the same + the u16
+                                    stored index of every edge (rows whose columns are not ascending) */
+    int32_t phases_with_lines;   /* eps-phases of the solve that ran WITH candidate lines (all of them unless eps fell below
+                                    the rounding error of a price update on the way: see misslap_create) */
+    int32_t eps_phases;          /* eps-phases of the solve (nreductions + 1 when it ran to its end) */
+    int32_t reserved_j;
 } misslap_meta;
 
 /* Snapshot of the round state (tests / multi-GPU driver). */

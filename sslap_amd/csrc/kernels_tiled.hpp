@@ -1,25 +1,34 @@
-// kernels_tiled.hpp -- the full-scan bid kernel with object prices tiled in LDS.
+// kernels_tiled.hpp -- the full-scan engine: the bid kernel (and the eCE / objective pass) with object prices tiled in LDS.
 //
-// Why: in the wave-per-row kernel (k_bid) every edge gathers an 8-byte price from a 1.6 MB table; the
-// table lives in L2 but every random 8-byte read moves a whole sector L2 -> L1, ~8x the bytes of the
-// edge stream, and that traffic -- not HBM -- bounds the kernel (measured: 259 us with the gather,
-// 106 us without, C3).  Here a workgroup owns one CU's LDS, loads a tile of kTileCols = 20096 prices
-// (157 KB) at a time and looks prices up with ds_read_b64.
+// Why: in the wave-per-row kernel (k_bid) every edge gathers an 8-byte price from a table of M x 8 bytes; the table lives
+// in L2 but every random 8-byte read moves a whole sector L2 -> L1, ~8x the bytes of the edge stream, and that traffic --
+// not HBM -- bounds the kernel (measured: 259 us with the gather, 106 us without, C3).  Here a workgroup owns one CU's
+// LDS, holds TWO tiles of kTileColsHalf = 10 112 prices (79 KB each, double-buffered: three loader wavefronts fill the
+// next tile by LDS-DMA while thirteen compute wavefronts look prices up in the current one with ds_read_b64) and walks
+// the column tiles of its persons once.
 //
-// Second layout of the edges in HBM ("tile-major", built once at ingest, next to the row-major CSR; HBM
-// capacity is not a constraint): persons are cut into layout blocks of kTileRB = 128; inside a block
-// the edges are ordered by (column tile, person, stored order).  The segment of (person i, tile t) is
-// [S[idx], S[idx+1]) with idx = ((i / RB) * T + t) * RB + i % RB.  For a full scan consecutive 8-lane
-// groups read adjacent segments, so a wavefront streams ~1 KB of contiguous edges per step.  The layout
-// requires column tiles to be non-decreasing along every row (true for column-sorted rows: the
-// `mat=` entry and the generator); otherwise the solver keeps to k_bid.  The in-row tie rule ("last
-// stored index wins", auction_.pyx:351) is preserved because the tile-major position of an edge is
-// monotone in its stored index within a row.
+// Second layout of the edges in HBM ("tile-major", built once at ingest, next to the row-major CSR; HBM capacity is not
+// a constraint): persons are cut into layout blocks of kTileRB = 128; inside a block the edges are ordered by (column
+// tile, person, stored order).  The segment of (person i, tile t) is [S[idx], S[idx+1]) with idx = ((i / RB) * T + t) *
+// RB + i % RB (a 4-byte table entry per segment: start | odd-length flag).  Edges are PACKED, two per record, as a
+// 16-bit price slot (the index of the edge's price inside the kernel's LDS buffers, tile parity included: a look-up is
+// `slot << 3`, no column arithmetic) plus the value -- the record formats (template parameter kFmt):
+//     0   6 B/edge  {u16 slot x 2, f32 value x 2}                     fp32-exact values, column-sorted rows
+//     1  10 B/edge  {u16 slot x 2, f64 value x 2}                     arbitrary doubles, column-sorted rows
+//     2   8 B/edge  {u16 slot x 2, u16 stored index x 2, f32 x 2}     rows whose columns are NOT ascending
+//     3  12 B/edge  {u16 slot x 2, u16 stored index x 2, f64 x 2}     ... with arbitrary doubles
+// The in-row tie rule ("the last stored index attaining the maximum wins", auction_.pyx:351) needs no data in formats
+// 0 / 1: with ascending columns the tile-major position of an edge is monotone in its stored index, so a lane meets its
+// elements in stored order and ">=" is the rule.  Formats 2 / 3 carry every edge's stored index within its row (rows of
+// at most 65 536 edges) and compare it where two values are equal; the running "position of the best" is then the
+// stored index itself.
 //
-// Work split: a 1024-thread workgroup = 128 groups of 8 lanes; a group owns up to kTileRows persons
-// and keeps, PER LANE, the running top-2 of the elements that lane has seen (registers, ascending
-// position => the reference's ">=" rule applies unchanged).  Lanes of a group are merged only once,
-// after the last tile, with three 3-step DPP all-reduces inside the 8 lanes.
+// Work split: a 1024-thread workgroup = 13 compute wavefronts cut into lane groups of kGL = 4, 8 or 16 lanes (chosen at
+// create from the average (person, tile) segment length: C3 10 edges -> 4, C4 20 -> 8, C2 50 -> 16) + 3 loader
+// wavefronts.  A group owns up to kTileRows = 4 persons and keeps, PER LANE, the running top-2 of the elements that
+// lane has seen (registers); the lanes of a group are merged once, after the last tile, with DPP all-reduces inside
+// the group.  The edges of a segment beyond what the software-pipelined loads of a step cover (2 x kGL x kTileDepth)
+// sit on per-person overflow lists that are read once, after the last tile.
 #pragma once
 #include <type_traits>
 
@@ -46,6 +55,36 @@ static_assert((2 * (79 * 128) + 128) * 8 + kTileStatBytes + kTileTouchBytes <= 1
 // price tile takes 128 of the 160 KB of LDS), ROWS persons per 8-lane group (register-resident running
 // top-2 per lane), BATCH persons whose segment loads are in flight together.
 
+// Record formats of the tile-major copy (see the header): two edges per record.
+//   byte 0: u16 slot x 2;  formats 2 / 3: byte 4: u16 stored index (within the row) x 2;  then the two values.
+template <int kFmt>
+struct TileFmt {
+    static_assert(kFmt >= 0 && kFmt <= 3, "tile-major record formats 0..3");
+    static constexpr bool kF64 = (kFmt & 1) != 0;  // values as fp64 (arbitrary doubles) instead of fp32 bits
+    static constexpr bool kG = kFmt >= 2;          // stored index carried (rows whose columns are not ascending)
+    static constexpr int kValOff = kG ? 8 : 4;     // byte offset of the first value
+    static constexpr int kRec = kValOff + (kF64 ? 16 : 8);  // bytes per record: 12, 20, 16, 24
+    typedef typename std::conditional<kF64, double, int>::type VT;  // a value as held in a register
+    static __device__ __forceinline__ double val(VT v) {
+        if constexpr (kF64) return v;
+        else return (double)__int_as_float(v);  // exact widening
+    }
+};
+__host__ __device__ constexpr int tile_rec_bytes(int fmt) { return (fmt >= 2 ? 8 : 4) + ((fmt & 1) ? 16 : 8); }
+// entry q of a tile-major copy in format `fmt`: its value (as two dwords; the high one is 0 for fp32), its stored index
+__device__ __forceinline__ void tile_entry(const unsigned *tpk, int fmt, int q, unsigned &vlo, unsigned &vhi, int &g) {
+    const unsigned *rec = tpk + (size_t)(q >> 1) * (tile_rec_bytes(fmt) / 4);
+    const int vo = fmt >= 2 ? 2 : 1;
+    if (fmt & 1) {
+        vlo = rec[vo + 2 * (q & 1)];
+        vhi = rec[vo + 2 * (q & 1) + 1];
+    } else {
+        vlo = rec[vo + (q & 1)];
+        vhi = 0u;
+    }
+    g = fmt >= 2 ? (int)((rec[1] >> (16 * (q & 1))) & 0xffffu) : q;
+}
+
 // index of segment (person, tile) in the pointer table; the host enables the tiled path only while the
 // table has < 2^31 entries, so 32-bit arithmetic is enough (and saves address registers in the kernel)
 __host__ __device__ __forceinline__ int tile_idx(int person, int t, int T, int rb = kTileRB) {
@@ -58,14 +97,15 @@ __host__ __device__ __forceinline__ int tile_idx(int person, int t, int T, int r
 // column-order check.
 // cnt = the count rounded up to an even number (every segment starts 16-byte aligned, so that a lane can
 // take two edges with one dwordx4 load); len = the real count.
-__global__ __launch_bounds__(256) void k_tile_count(const int2 *edges, const int *row_ptr, int n_rows, int T,
+// (the columns of the row-major CSR: `cols[cs * g]` -- cs = 2 for the interleaved 8 B/edge layout, 1 for the 12 B/edge one)
+__global__ __launch_bounds__(256) void k_tile_count(const int *cols, int cs, const int *row_ptr, int n_rows, int T,
                                                     int kTileCols, int rb, int *cnt, int *len, int *lrel,
                                                     int *unsorted) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int i = blockIdx.x * 4 + wave; i < n_rows; i += gridDim.x * 4) {
         const int s = row_ptr[i], e = row_ptr[i + 1];
         int bad = 0;
-        for (int g = s + 1 + lane; g < e; g += kWave) bad |= (edges[g].x < edges[g - 1].x);
+        for (int g = s + 1 + lane; g < e; g += kWave) bad |= (cols[(size_t)cs * g] < cols[(size_t)cs * (g - 1)]);
         if (__ballot(bad) && lane == 0) atomicOr(unsorted, 1);
         for (int t0 = 0; t0 <= T; t0 += kWave) {
             const int t = t0 + lane;
@@ -78,7 +118,7 @@ __global__ __launch_bounds__(256) void k_tile_count(const int2 *edges, const int
                     int hi = e - s;
                     while (lo < hi) {
                         const int mid = (lo + hi) >> 1;
-                        if (edges[s + mid].x < bound) lo = mid + 1;
+                        if (cols[(size_t)cs * (s + mid)] < bound) lo = mid + 1;
                         else hi = mid;
                     }
                 }
@@ -92,7 +132,7 @@ __global__ __launch_bounds__(256) void k_tile_count(const int2 *edges, const int
                 else {
                     while (l2 < hi) {
                         const int mid = (l2 + hi) >> 1;
-                        if (edges[s + mid].x < bound) l2 = mid + 1;
+                        if (cols[(size_t)cs * (s + mid)] < bound) l2 = mid + 1;
                         else hi = mid;
                     }
                 }
@@ -106,6 +146,22 @@ __global__ __launch_bounds__(256) void k_tile_count(const int2 *edges, const int
             }
         }
     }
+}
+
+// The same counts for rows whose columns are NOT ascending (formats 2 / 3): one thread per edge, an atomic per edge on
+// the segment's length (`len` zeroed by the caller); k_tile_even then forms the padded counts.  No binary search, no
+// order requirement: the tile-major copy only needs the edges GROUPED by tile, in stored order inside a segment.
+__global__ __launch_bounds__(256) void k_tile_count_any(const int *cols, int cs, const int *row_ptr, int n_rows, int T,
+                                                        int kTileCols, int rb, int *len) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int i = blockIdx.x * 4 + wave; i < n_rows; i += gridDim.x * 4) {
+        const int s = row_ptr[i], e = row_ptr[i + 1];
+        for (int g = s + lane; g < e; g += kWave) atomicAdd(&len[tile_idx(i, cols[(size_t)cs * g] / kTileCols, T, rb)], 1);
+    }
+}
+__global__ __launch_bounds__(256) void k_tile_even(const int *len, long long n, int *cnt) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) cnt[k] = (len[k] + 1) & ~1;
 }
 
 // exclusive scan of a long int array in three launches (chunk sums, scan of the sums, rescan + offset)
@@ -205,8 +261,10 @@ __global__ __launch_bounds__(256) void k_ovf_count(const int *len, int n_rows, i
 // its list with ONE sequential 16-byte load per edge and goes to memory once more, for the price (two random 4-byte
 // reads per edge into the tile-major arrays pulled a 128-byte line each: + 25 MB per full scan at C3).  Runs after
 // k_tile_scatter (it copies from the tile-major arrays).
+// (formats: .x = the tile-major position in formats 0 / 1, the stored index within the row in formats 2 / 3 -- whatever
+// orders equal values in the kernel; .z / .w = the value's dwords, .w = 0 for fp32 values)
 __global__ __launch_bounds__(256) void k_ovf_fill(const int *len, const int *start, int n_rows, int T, int rb, int cap,
-                                                  const int *ovf_ptr, const unsigned *tpk, const int *tcol, int4 *ovf) {
+                                                  const int *ovf_ptr, const unsigned *tpk, const int *tcol, int4 *ovf, int fmt) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_rows; i += gridDim.x * blockDim.x) {
         int at = ovf_ptr[i];
         for (int t = 0; t < T; ++t) {
@@ -214,35 +272,69 @@ __global__ __launch_bounds__(256) void k_ovf_fill(const int *len, const int *sta
             const int n = len[idx], s0 = start[idx];
             for (int k = cap; k < n; ++k) {
                 const int q = s0 + k;
-                ovf[at++] = make_int4(q, tcol[q], (int)tpk[(q >> 1) * 3 + 1 + (q & 1)], 0);
+                unsigned vlo, vhi;
+                int g;
+                tile_entry(tpk, fmt, q, vlo, vhi, g);
+                ovf[at++] = make_int4(g, tcol[q], (int)vlo, (int)vhi);
             }
         }
     }
 }
 
-// pass 3: copy every edge to its tile-major position.  The copy is PACKED to 6 bytes per edge, two edges per 12-byte record
-//   { u16 slot0, u16 slot1, f32 val0, f32 val1 }
-// where slot = (col - tile * cols) + (tile & 1) * buf_stride is the index of the edge's price inside the kernel's
-// LDS buffers (a look-up is `slot << 3`, no column arithmetic), and the real column goes to the parallel array
-// `tcol` (read once per bidder, for the winner).  A quarter less HBM traffic than {int32 col, f32 val}.
-__global__ __launch_bounds__(256) void k_tile_scatter(const int2 *edges, const int *row_ptr, int n_rows, int T,
-                                                      int kTileCols, int rb, const int *start, const int *lrel,
-                                                      int2 *tiled, int *tcol, int buf_stride) {
+// pass 3: copy every edge to its tile-major position, PACKED two edges per record in format kFmt (TileFmt above): the
+// 16-bit slot = (col - tile * cols) + (tile & 1) * buf_stride is the index of the edge's price inside the kernel's LDS
+// buffers (a look-up is `slot << 3`, no column arithmetic); the real column goes to the parallel array `tcol` (read by
+// the ingest of the overflow lists and by the column-split shape).
+// Formats 0 / 1 (ascending columns): the position inside the segment is the stored index minus the first stored index
+// of the tile (lrel, from the binary search of k_tile_count).  Formats 2 / 3 (any column order): the wavefront walks the
+// row in stored order, 64 edges at a time, and ranks the edges of each tile present in the chunk behind the running
+// fill of that segment (`fill`, zeroed by the caller; one wavefront owns a row and walks it in order).
+template <class E, int kFmt>
+__global__ __launch_bounds__(256) void k_tile_scatter(E ed, const int *row_ptr, int n_rows, int T, int kTileCols, int rb,
+                                                      const int *start, const int *lrel, int *fill, unsigned *tpk,
+                                                      int *tcol, int buf_stride) {
+    typedef TileFmt<kFmt> F;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int i = blockIdx.x * 4 + wave; i < n_rows; i += gridDim.x * 4) {
         const int s = row_ptr[i], e = row_ptr[i + 1];
-        for (int g = s + lane; g < e; g += kWave) {
-            const int2 x = edges[g];
-            const int t = x.x / kTileCols;
+        for (int g0 = s; g0 < e; g0 += kWave) {
+            const int g = g0 + lane;
+            const bool ok = g < e;
+            int col = 0;
+            double val = 0.0;
+            ed.load(ok ? g : e - 1, col, val);
+            const int t = col / kTileCols;
             const int idx = tile_idx(i, t, T, rb);
-            const int pos = start[idx] + (g - s - lrel[idx]);
-            if (tcol) {
-                tcol[pos] = x.x;
-                const int slot = (x.x - t * kTileCols) + (t & 1) * buf_stride;
-                reinterpret_cast<unsigned short *>(tiled)[(size_t)(pos >> 1) * 6 + (pos & 1)] = (unsigned short)slot;
-                reinterpret_cast<int *>(tiled)[(size_t)(pos >> 1) * 3 + 1 + (pos & 1)] = x.y;
+            int pos;
+            if (!F::kG) {
+                pos = start[idx] + (g - s - lrel[idx]);
             } else {
-                tiled[pos] = x;
+                pos = 0;
+                unsigned long long todo = __ballot(ok);
+                while (todo) {  // wave-uniform: one pass per tile present among the chunk's edges
+                    const int src = __ffsll((long long)todo) - 1;
+                    const int t0 = __builtin_amdgcn_readlane(t, src);
+                    const int idx0 = __builtin_amdgcn_readlane(idx, src);
+                    const unsigned long long m = __ballot(ok && t == t0);
+                    int base = 0;  // (an atomic: performed at L2, so the next chunk's read of the same counter sees it)
+                    if (lane == src) base = atomicAdd(&fill[idx0], __popcll(m));
+                    base = __builtin_amdgcn_readlane(base, src);
+                    if (ok && t == t0) pos = start[idx0] + base + __popcll(m & lanemask_lt());
+                    todo &= ~m;
+                }
+            }
+            if (ok) {
+                tcol[pos] = col;
+                const int slot = (col - t * kTileCols) + (t & 1) * buf_stride;
+                unsigned *rec = tpk + (size_t)(pos >> 1) * (F::kRec / 4);
+                reinterpret_cast<unsigned short *>(rec)[pos & 1] = (unsigned short)slot;
+                if (F::kG) reinterpret_cast<unsigned short *>(rec)[2 + (pos & 1)] = (unsigned short)(g - s);
+                if (F::kF64) {
+                    rec[F::kValOff / 4 + 2 * (pos & 1)] = (unsigned)__double2loint(val);
+                    rec[F::kValOff / 4 + 2 * (pos & 1) + 1] = (unsigned)__double2hiint(val);
+                } else {
+                    rec[F::kValOff / 4 + (pos & 1)] = (unsigned)__float_as_int((float)val);  // exact: the layout is chosen for fp32-exact values
+                }
             }
         }
     }
@@ -458,8 +550,12 @@ __device__ __forceinline__ T split_load(const T *p) {
 // val - price and the last stored edge whose column is the person's object -- the column is known before the scan, so
 // inside the tile that holds it the edge is recognised by its 16-bit price slot, with no column arithmetic per
 // element.  No bids, no statistics; the result of a person is handled by final_person().  a.eps = the eps of the test.
-template <int kTileThreads, int kTileRows, int kTileBatch, int kTileDepth, int kTileCols, int kLoaders, int ABL = 0, int kGL = 4, int kCS = 1, int MODE = 0>
+// kFmt: the record format of the tile-major copy (TileFmt; the host launches the instance of the handle's format).
+template <int kTileThreads, int kTileRows, int kTileBatch, int kTileDepth, int kTileCols, int kLoaders, int ABL = 0, int kGL = 4, int kCS = 1, int MODE = 0, int kFmt = 0>
 __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledArgs ta) {
+    typedef TileFmt<kFmt> F;
+    typedef typename F::VT VT;
+    static_assert(kFmt == 0 || (kCS == 1 && ABL == 0), "column split and ablations exist for the 6 B/edge format only");
     static_assert(kCS == 1 || kCS == 2 || kCS == 4, "column split: none, halves or quarters of the tiles");
     static_assert(MODE == 0 || (MODE == 1 && kCS == 1 && ABL == 0), "the check pass runs on the unsplit shapes");
     static_assert(kGL == 4 || kGL == 8 || kGL == 16, "lanes per person: 4, 8 or 16 (one DPP row at most)");
@@ -511,7 +607,8 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
     // that moved sg the winner is picked from the step's registers (see `note_best`).  Re-reading them at the end through
     // the position -- two random 4-byte reads per bidder into the tile-major arrays -- pulled 51 MB of lines per full
     // scan at C3 and put a memory latency in front of the bids.
-    int scol[kTileRows], scost[kTileRows];
+    int scol[kTileRows];
+    VT scost[kTileRows];
     // MODE 1 keeps in the same registers: sv = running maximum, sg = position of the last match (-1: none), scost = its
     // value bits; and per person the tile of the wanted column, its price slot there as an LDS byte offset, the number
     // of matches
@@ -527,7 +624,7 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
         sw[j] = ninf;
         sg[j] = -1;
         scol[j] = 0;
-        scost[j] = 0;
+        scost[j] = VT(0);
         wtile[j] = -1;
         wslot8[j] = 0;
         mcnt[j] = 0;
@@ -617,8 +714,9 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
     auto seg_s0 = [](const Seg &g, int jj) { return g.x[jj] & ~1; };
     auto seg_s1 = [](const Seg &g, int jj) { return (g.y[jj] & ~1) - (g.x[jj] & 1); };  // start + padded length - pad
     struct Edges {
-        unsigned c[kTileBatch][kTileDepth];  // two 16-bit price slots
-        int v0[kTileBatch][kTileDepth], v1[kTileBatch][kTileDepth];  // two fp32 values
+        unsigned c[kTileBatch][kTileDepth];   // two 16-bit price slots
+        unsigned gg[kTileBatch][F::kG ? kTileDepth : 1];  // (formats 2 / 3) two 16-bit stored indices
+        VT v0[kTileBatch][kTileDepth], v1[kTileBatch][kTileDepth];  // two values (fp32 bits or fp64)
     };
     // Addresses are base (SGPR pair) + 32-bit unsigned BYTE offset (VGPR): the global_load "saddr" form, no
     // 64-bit address arithmetic per load (the host enables this kernel only while both tables are < 4 GiB).
@@ -645,14 +743,37 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
                     e.c[jj][d] = (unsigned)(seg_s0(sg_, jj) & 1023) * 0x10001u;
                     e.v0[jj][d] = e.v1[jj][d] = gl;
                 } else {  // s0 is even: record s0 / 2; a group of kGL lanes covers 2 * kGL consecutive edges per load
+                    typedef unsigned v2u_t __attribute__((ext_vector_type(2), aligned(4)));
                     typedef unsigned v3u_t __attribute__((ext_vector_type(3)));
-                    const unsigned boff = ((unsigned)seg_s0(sg_, jj) >> 1) * 12u + (unsigned)(12 * gl);
-                    const char *src =  // + 12 * kGL * d bytes goes into the instruction's immediate offset
-                        reinterpret_cast<const char *>(ta.tpk) + boff;
-                    const v3u_t y = *reinterpret_cast<const v3u_t *>(src + 12 * kGL * d);
-                    e.c[jj][d] = y.x;
-                    e.v0[jj][d] = (int)y.y;
-                    e.v1[jj][d] = (int)y.z;
+                    typedef unsigned v4u_t __attribute__((ext_vector_type(4), aligned(4)));
+                    constexpr unsigned kRec = (unsigned)F::kRec;
+                    const unsigned boff = ((unsigned)seg_s0(sg_, jj) >> 1) * kRec + kRec * (unsigned)gl;
+                    const char *src =  // + kRec * kGL * d bytes goes into the instruction's immediate offset
+                        reinterpret_cast<const char *>(ta.tpk) + boff + kRec * kGL * d;
+                    if constexpr (kFmt == 0) {         // 12 B: {slots, f32, f32}
+                        const v3u_t y = *reinterpret_cast<const v3u_t *>(src);
+                        e.c[jj][d] = y.x;
+                        e.v0[jj][d] = (int)y.y;
+                        e.v1[jj][d] = (int)y.z;
+                    } else if constexpr (kFmt == 1) {  // 20 B: {slots, f64, f64}: one dword + four
+                        e.c[jj][d] = *reinterpret_cast<const unsigned *>(src);
+                        const v4u_t y = *reinterpret_cast<const v4u_t *>(src + 4);
+                        e.v0[jj][d] = __hiloint2double((int)y.y, (int)y.x);
+                        e.v1[jj][d] = __hiloint2double((int)y.w, (int)y.z);
+                    } else if constexpr (kFmt == 2) {  // 16 B: {slots, stored indices, f32, f32}
+                        const v4u_t y = *reinterpret_cast<const v4u_t *>(src);
+                        e.c[jj][d] = y.x;
+                        e.gg[jj][d] = y.y;
+                        e.v0[jj][d] = (int)y.z;
+                        e.v1[jj][d] = (int)y.w;
+                    } else {                           // 24 B: {slots, stored indices, f64, f64}: two dwords + four
+                        const v2u_t x = *reinterpret_cast<const v2u_t *>(src);
+                        const v4u_t y = *reinterpret_cast<const v4u_t *>(src + 8);
+                        e.c[jj][d] = x.x;
+                        e.gg[jj][d] = x.y;
+                        e.v0[jj][d] = __hiloint2double((int)y.y, (int)y.x);
+                        e.v1[jj][d] = __hiloint2double((int)y.w, (int)y.z);
+                    }
                 }
             }
     };
@@ -770,22 +891,28 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
                             }
 #pragma unroll
                             for (int h = 0; h < 2; ++h) {
-                                const int vb = h ? e_cur.v1[jj][d] : e_cur.v0[jj][d];
+                                const VT vb = h ? e_cur.v1[jj][d] : e_cur.v0[jj][d];
                                 // a masked-off element has v = -inf and changes neither sv nor sw; `ok` keeps it from
                                 // taking sg when sv is still -inf (rows whose objects all have an infinite price)
-                                const double v = (double)__int_as_float(vb) - prs[jj][d][h];  // vi = cost - p[j]   (:350)
-                                const int q = q0 + 2 * kGL * d + h;
+                                const double v = F::val(vb) - prs[jj][d][h];  // vi = cost - p[j]   (:350)
+                                // what orders equal values: the tile-major position (ascending columns: monotone in
+                                // the stored index) or the stored index itself (formats 2 / 3)
+                                const int q = F::kG ? (int)((h ? e_cur.gg[jj][F::kG ? d : 0] >> 16 : e_cur.gg[jj][F::kG ? d : 0] & 0xffffu))
+                                                    : q0 + 2 * kGL * d + h;
                                 if (MODE == 1) {  // (:467-471, :480-482) a lane meets its elements in stored order: the last match stays
                                     const int a8 = (int)((h ? e_cur.c[jj][d] >> 16 : e_cur.c[jj][d] & 0xffffu) << 3);
                                     const bool m = (2 * kGL * d + h < rem[jj]) & (a8 == want8);
+                                    const bool last = F::kG ? (m & (q > sg[j])) : m;  // (formats 2 / 3: by stored index)
                                     sv[j] = __builtin_fmax(sv[j], v);  // a masked-off element has v = -inf
-                                    sg[j] = m ? q : sg[j];
-                                    scost[j] = m ? vb : scost[j];
+                                    sg[j] = last ? q : sg[j];
+                                    scost[j] = last ? vb : scost[j];
                                     mcnt[j] += m;
                                     continue;
                                 }
-                                // a lane meets its elements in stored order: ">=" is the reference's tie rule
-                                const bool ge = (2 * kGL * d + h < rem[jj]) & (v >= sv[j]);  // :351
+                                // a lane meets its elements in stored order: ">=" is the reference's tie rule (formats
+                                // 2 / 3: in ANY order -- among equal values the larger stored index wins, spelled out)
+                                const bool ge = (2 * kGL * d + h < rem[jj]) &
+                                                (F::kG ? ((v > sv[j]) | ((v == sv[j]) & (q > sg[j]))) : (v >= sv[j]));  // :351
                                 sw[j] = __builtin_fmax(sw[j], __builtin_fmin(v, sv[j]));      // :353 / :357-358
                                 sv[j] = __builtin_fmax(sv[j], v);
                                 sg[j] = ge ? q : sg[j];
@@ -906,7 +1033,8 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
                 }
             }
             while (__any(more)) {
-                int q[kOB], vb[kOB];
+                int q[kOB];
+                VT vb[kOB];
                 double pr[kOB];
                 int4 en[kOB];
 #pragma unroll
@@ -914,7 +1042,8 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
 #pragma unroll
                 for (int jj = 0; jj < kOB; ++jj) {
                     q[jj] = en[jj].x;
-                    vb[jj] = en[jj].z;
+                    if constexpr (F::kF64) vb[jj] = __hiloint2double(en[jj].w, en[jj].z);
+                    else vb[jj] = en[jj].z;
                     pr[jj] = a.price[en[jj].y];
                 }
                 more = false;
@@ -922,7 +1051,7 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
                 for (int jj = 0; jj < kOB; ++jj) {
                     const int j = j0 + jj;
                     const bool ok = (oi[jj] < oe[jj]) & (kCS == 1 || ((q[jj] >= ql[jj]) & (q[jj] < qh[jj])));
-                    const double v = ok ? (double)__int_as_float(vb[jj]) - pr[jj] : ninf;  // vi = cost - p[j]   (:350)
+                    const double v = ok ? F::val(vb[jj]) - pr[jj] : ninf;  // vi = cost - p[j]   (:350)
                     if (MODE == 1) {  // these edges are met out of stored order: the later stored POSITION is the last match
                         const int wcol = wtile[j] * kTileCols + (wslot8[j] >> 3) - (kDouble ? (wtile[j] & 1) * kBufDoubles : 0);
                         const bool m = ok & (wtile[j] >= 0) & (en[jj].y == wcol);
@@ -966,7 +1095,7 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
             const int Q = group_max_i32<kGL>(sg[j]);
             const int n = group_sum_i32<kGL>(mcnt[j]);
             const bool me = person[j] >= 0 && (Q >= 0 ? sg[j] == Q : gl == 0);
-            if (me) final_person(acc, ta.fo, person[j], pj_[j], Q >= 0, n, (double)__int_as_float(scost[j]), V, wp[j], eps);
+            if (me) final_person(acc, ta.fo, person[j], pj_[j], Q >= 0, n, F::val(scost[j]), V, wp[j], eps);
         }
         flag_ece_failure(a.ctl, acc.bad);
         if (ta.fo.fin) {  // uniform over the launch
@@ -978,7 +1107,8 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
     // merge the kGL lanes of each group, once per person (same three all-reduces as top2_wave_reduce)
     unsigned long long edges = 0;
     int nb = 0, err = 0;
-    int2 best[kTileRows];
+    int bcol[kTileRows];
+    VT bcost[kTileRows];
     int rlen[kTileRows];
     double W[kTileRows];
     int G[kTileRows];
@@ -1065,12 +1195,12 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
 #pragma unroll
     for (int j = 0; j < kTileRows; ++j) {
         const int pj = max(person[j], 0);
-        if (kCS == 1) {  // `mine` is the lane that met the best edge
-            best[j].x = scol[j];
-            best[j].y = scost[j];
+        if constexpr (kCS == 1) {  // `mine` is the lane that met the best edge
+            bcol[j] = scol[j];
+            bcost[j] = scost[j];
         } else {         // any workgroup of the slice may hold it: through its position (unconditional loads, used under `mine`)
-            best[j].x = ta.tcol[max(G[j], 0)];
-            best[j].y = (int)ta.tpk[(max(G[j], 0) >> 1) * 3 + 1 + (max(G[j], 0) & 1)];
+            bcol[j] = ta.tcol[max(G[j], 0)];
+            bcost[j] = (int)ta.tpk[(max(G[j], 0) >> 1) * 3 + 1 + (max(G[j], 0) & 1)];
         }
         rlen[j] = a.row_ptr[pj + 1] - a.row_ptr[pj];
     }
@@ -1078,15 +1208,15 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
 #pragma unroll
     for (int j = 0; j < kTileRows; ++j) {
         if (mine[j]) {
-            const double cost = (double)__int_as_float(best[j].y);
+            const double cost = F::val(bcost[j]);
             const double bid = (cost - W[j]) + eps;  // :360
             if (bid_is_bad(bid)) err |= kErrNegativeBid;
             const unsigned long long key = bid_to_key(bid);
             const int slot = p0 + j * kTileGroups + group;
             const int pos = ta.order_pos ? ta.order_pos[slot] : slot;
             a.bid_key[pos] = key;
-            a.bid_obj[pos] = best[j].x;
-            atomicMax(&a.best_key[best[j].x], key);
+            a.bid_obj[pos] = bcol[j];
+            atomicMax(&a.best_key[bcol[j]], key);
             edges += (unsigned long long)rlen[j];
             nb += 1;
         }

@@ -148,6 +148,10 @@ const int kTiledShapes[kNumTiledShapes][8] = {
     X(4, 1024, 8, 2, 2, kTileColsHalf, 3, 4, 2) X(5, 1024, 4, 1, 2, kTileColsHalf, 1, 4, 1)                          \
     X(6, 1024, 4, 2, 3, kTileColsHalf, 1, 4, 1) X(7, 1024, 4, 2, 2, kTileColsHalf, 2, 4, 1)                          \
     X(8, 1024, 4, 2, 2, kTileColsHalf, 3, 8, 1) X(9, 1024, 4, 2, 2, kTileColsHalf, 3, 16, 1)
+// ... and for the record formats 1..3 of the tile-major copy (fp64 values, rows with unsorted columns): the shapes 0 / 8 /
+// 9, i.e. {1024 threads, 4 persons per lane group, 2 in flight, 2 loads per segment, half tiles, 3 loaders} x lanes
+#define MISSLAP_BID_KERNEL_FMT(GL, FMT) k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 3, 0, GL, 1, 0, FMT>
+#define MISSLAP_FOR_FMT_LANES(X) X(1, 4) X(1, 8) X(1, 16) X(2, 4) X(2, 8) X(2, 16) X(3, 4) X(3, 8) X(3, 16)
 inline size_t tiled_lds_bytes(int tile_cols) {  // see the LDS map in k_bid_tiled; + statistics scratch
     const size_t doubles = tile_cols == kTileColsBig ? (size_t)tile_cols + 2 : 2 * (size_t)tile_cols + 128;
     return doubles * sizeof(double) + kTileStatBytes + kTileTouchBytes;  // + statistics scratch (incl. the arrival word of a column-split shape) + the loaders' touch scratch
@@ -196,7 +200,13 @@ void block_free(int device, void *p, size_t bytes);
 struct misslap_solver {
     int abi = MISSLAP_ABI_VERSION;  // 1: created with version-1 options (88 bytes) -> version-1 misslap_meta layout
     int n_cus = 256;                // compute units of the device (one k_bid_tiled workgroup per CU)
-    bool lines_guard_off = false;   // lines switched off at create: eps may fall below a price update's rounding error
+    // Candidate lines are exact only while prices never fall (device_common.hpp).  A price update is fl(fl(c - w) + eps)
+    // with w <= fl(c - p): it can land BELOW p once eps is smaller than the rounding error of those operations, i.e. for
+    // huge |cost| in the LAST eps-phases (eps falls to 0.15 / N).  The lines are used while the phase's eps is at or above
+    // lines_safe_eps = max|cost| x 2^-44 (2^9 ulps of the largest cost) and dropped for good from the first phase below it
+    // (begin_phase; the full scans never depend on the invariant; kErrPriceFell is the run-time backstop).
+    double lines_safe_eps = 0.0;
+    bool lines_dropped = false;     // ... that phase has been reached: the lines are no longer read or maintained
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -229,7 +239,8 @@ struct misslap_solver {
     unsigned long long *launch_edges = nullptr;
     int launch_edges_cap = 0;
     // tile-major second copy of the edges for k_bid_tiled (kernels_tiled.hpp)
-    int2 *tiled = nullptr;
+    unsigned *tiled = nullptr;  // packed records, two edges each, in format tiled_fmt (kernels_tiled.hpp: TileFmt)
+    int tiled_fmt = 0;          // 0: 6 B/edge {slot, f32}; 1: 10 B/edge {slot, f64}; 2 / 3: + the stored index (unsorted rows)
     int *seg4 = nullptr;  // k_bid_tiled's 4-byte segment table
     int *tcol = nullptr;  // real columns of the tile-major copy (k_bid_tiled stores LDS offsets in `tiled`)
     int *ovf_ptr = nullptr;  // per-person lists of the edges beyond ovf_cap in a (person, tile) segment
@@ -278,7 +289,7 @@ struct misslap_solver {
     // once the long-row builder runs (k_refresh_long).  Otherwise (C4: 300 edges per row) every line is empty for the
     // whole solve, and loading + evaluating it in front of every bid, and the maintenance pass over all of them, are
     // pure overhead: the kernels then run as for a handle without lines.
-    bool lines_live() const { return cand != nullptr && (avg_row_len <= kCandRowMax || long_rows); }
+    bool lines_live() const { return cand != nullptr && !lines_dropped && (avg_row_len <= kCandRowMax || long_rows); }
     bool long_rows_later = false;  // rows of a few hundred edges: k_refresh_long only if the tail turns out long
     long long tail_rounds_host = 0;  // rounds the tail kernels have run so far, from the round counts of the status reads
     long long tail_nits0 = -1;       // (the control block's own counter reaches the host with a full read only)
@@ -294,6 +305,7 @@ struct misslap_solver {
     bool rounds_per_sync_auto = true;  // not set by the caller: kRoundsPerSyncLive while the live status is in use
     int rank = 0, world = 1;
     long long sharded_rounds = 0;  // rounds of the last solve that were sharded and exchanged (misslap_solve_sharded)
+    int phases_run = 0, phases_with_lines = 0;  // eps-phases begun so far / of which with candidate lines in use
     int shard_min_K = 0;  // multi-GPU: only rounds with K >= this are sharded and exchanged
     bool profile = false;
     int K_ub = 0;  // host-side upper bound of K (K never grows inside a phase)
@@ -489,6 +501,14 @@ void block_free(int device, void *p, size_t bytes) {
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) bc.size_default(total_b);
     }
     if (p && !bc.give(device, p, bytes)) (void)hipFree(p);
+}
+
+// The start of an eps-phase (create: the first; misslap_phase_end: every later one): are the candidate lines still exact
+// at this phase's eps?  (fp32 eps promoted to double exactly as the bid does, auction_.pyx:360.)
+void begin_phase(misslap_solver *h) {
+    if (h->cand != nullptr && !h->lines_dropped && (double)h->eps < h->lines_safe_eps) h->lines_dropped = true;
+    h->phases_run += 1;
+    h->phases_with_lines += h->lines_live() ? 1 : 0;
 }
 
 RoundArgs round_args(misslap_solver *h) {
@@ -695,7 +715,7 @@ int launch_bid_tiled(misslap_solver *h) {
     const long long spread = std::min<long long>(resident, (share + groups - 1) / groups);
     if (grid < spread) grid = spread;
     grid *= cs;
-    TiledArgs ta{reinterpret_cast<const unsigned *>(h->tiled), h->tcol, h->seg4, h->T, h->tiled_min_K, h->n_tiled,
+    TiledArgs ta{h->tiled, h->tcol, h->seg4, h->T, h->tiled_min_K, h->n_tiled,
                  nullptr, nullptr, h->ovf_ptr, h->ovf_q, h->ovf_cap, h->part_vw, h->part_g, h->n_rows, h->split_cnt, FinalOut{}};
     // A partial round whose K the host knows: bidders in person order (kernels_tiled.hpp, k_order_*).  Scratch that
     // is idle during a bid phase: the compaction lists (the tie-break reads order_pos before they are rewritten),
@@ -726,12 +746,23 @@ int launch_bid_tiled(misslap_solver *h) {
     }
     const size_t lds = tiled_lds_bytes(shp[4]);
     const dim3 g((unsigned)grid);
-    switch (h->tiled_shape) {
+    if (h->tiled_fmt == 0) {
+        switch (h->tiled_shape) {
 #define X(I, TH, R, B, D, TC, LD, GL, CS) \
     case I: MISSLAP_LAUNCH_TIMED(pr, (k_bid_tiled<TH, R, B, D, TC, LD, 0, GL, CS>), g, dim3(TH), (unsigned)lds, h->stream, a, ta); break;
-        MISSLAP_FOR_TILED_SHAPES(X)
+            MISSLAP_FOR_TILED_SHAPES(X)
 #undef X
-        default: return fail(MISSLAP_ERR_STATE, "bad tiled shape");
+            default: return fail(MISSLAP_ERR_STATE, "bad tiled shape");
+        }
+    } else {  // formats 1..3 (fp64 values / unsorted rows): the three production shapes, 4 / 8 / 16 lanes per person
+        const int key = h->tiled_fmt * 100 + shp[6];
+        switch (key) {
+#define X(FMT, GL) \
+    case FMT * 100 + GL: MISSLAP_LAUNCH_TIMED(pr, (MISSLAP_BID_KERNEL_FMT(GL, FMT)), g, dim3(1024), (unsigned)lds, h->stream, a, ta); break;
+            MISSLAP_FOR_FMT_LANES(X)
+#undef X
+            default: return fail(MISSLAP_ERR_STATE, "no full-scan instance for format %d with %d lanes per person", h->tiled_fmt, shp[6]);
+        }
     }
     if (pr) {  // (the round's k_tiebreak adds the workgroups' counts up: no launch of its own inside a timed solve)
         h->take_edges_n = (int)grid;
@@ -945,7 +976,8 @@ int launch_tail(misslap_solver *h) {
     // the tail keeps only the price records current: rebuild price / o2p / p2o from them
     h->live_valid = !h->live_off && h->live_dev != nullptr;
     hipLaunchKernelGGL(k_sync_from_rec, dim3(blocks_for(h->n_cols, 256)), dim3(256), 0, h->stream, h->ctl, h->rec, h->price,
-                       h->o2p, h->p2o, h->U, h->n_cols, h->cand != nullptr ? 1 : 0, h->live_valid ? h->live_dev : nullptr, ++h->ticket);
+                       h->o2p, h->p2o, h->U, h->n_cols, (h->cand != nullptr && !h->lines_dropped) ? 1 : 0,
+                       h->live_valid ? h->live_dev : nullptr, ++h->ticket);
     HIP_TRY(hipGetLastError());
     h->phase_fresh = false;
     if (h->tail_nits0 < 0) h->tail_nits0 = h->h_ctl->nits;  // (the status read in front of this launch)
@@ -962,6 +994,7 @@ int check_lanes(const misslap_solver *h) {
 }
 #define MISSLAP_FOR_CHECK_LANES(X) X(4) X(8) X(16)
 #define MISSLAP_CHECK_KERNEL(GL) k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 3, 0, GL, 1, 1>
+#define MISSLAP_CHECK_KERNEL_FMT(GL, FMT) k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 3, 0, GL, 1, 1, FMT>
 
 // rows [0, n_rows) on the row-major CSR (the sample of run_ece; every row where there is no tile-major copy)
 // the largest grid launch_rows_all can ask for on n_rows persons (over every lanes-per-person shape of the check pass)
@@ -991,7 +1024,7 @@ int launch_rows_all(misslap_solver *h, float eps, const FinalOut &fo, int *n_blo
     RoundArgs a = round_args(h);
     a.eps = eps;
     a.launch_edges = nullptr;
-    TiledArgs ta{reinterpret_cast<const unsigned *>(h->tiled), h->tcol, h->seg4, h->T, 0, h->n_tiled,
+    TiledArgs ta{h->tiled, h->tcol, h->seg4, h->T, 0, h->n_tiled,
                  nullptr, nullptr, h->ovf_ptr, h->ovf_q, h->ovf_cap, nullptr, nullptr, h->n_rows, nullptr, fo};
     const int groups = (1024 - 64 * 3) / gl, per_wg_max = groups * 4;
     long long grid = ((long long)h->n_rows + per_wg_max - 1) / per_wg_max;
@@ -1000,11 +1033,20 @@ int launch_rows_all(misslap_solver *h, float eps, const FinalOut &fo, int *n_blo
     if (fo.fin && grid > h->fin_slots_n) return fail(MISSLAP_ERR_STATE, "final pass: grid %lld exceeds its result slots (%d)", grid, h->fin_slots_n);
     if (n_blocks) *n_blocks = (int)grid;
     const size_t lds = tiled_lds_bytes(kTileColsHalf);
-    switch (gl) {
+    if (h->tiled_fmt == 0) {
+        switch (gl) {
 #define X(GL) \
     case GL: hipLaunchKernelGGL((MISSLAP_CHECK_KERNEL(GL)), dim3((unsigned)grid), dim3(1024), (unsigned)lds, h->stream, a, ta); break;
-        MISSLAP_FOR_CHECK_LANES(X)
+            MISSLAP_FOR_CHECK_LANES(X)
 #undef X
+        }
+    } else {
+        switch (h->tiled_fmt * 100 + gl) {
+#define X(FMT, GL) \
+    case FMT * 100 + GL: hipLaunchKernelGGL((MISSLAP_CHECK_KERNEL_FMT(GL, FMT)), dim3((unsigned)grid), dim3(1024), (unsigned)lds, h->stream, a, ta); break;
+            MISSLAP_FOR_FMT_LANES(X)
+#undef X
+        }
     }
     HIP_TRY(hipGetLastError());
     return MISSLAP_OK;
@@ -1132,22 +1174,13 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
     if (st.max_col >= 0x7ffffffe) return fail(MISSLAP_ERR_INVALID, "column index too large (max + 1 must fit an int32)");
     h->n_cols = st.max_col + 1;  // auction_.pyx:210
     h->f32 = !st.not_f32 && !opt->force_f64_values;
-    // Candidate lines are exact only while prices never fall (device_common.hpp).  A price update is
-    // fl(fl(c - w) + eps) with w <= fl(c - p): it can land BELOW p once eps is smaller than the rounding error of
-    // those operations, i.e. for huge |cost| with a small target eps (1 / N).  Then the lines are switched off for
-    // the handle (the full scans never depend on the invariant); kErrPriceFell is the run-time backstop.
+    // (candidate lines and eps: see misslap_solver::lines_safe_eps; the decision is taken per eps-phase, begin_phase)
     int cand_mode = opt->cand_mode;
     {
         double max_abs_d;
         const long long b = (long long)st.max_abs_bits;
         std::memcpy(&max_abs_d, &b, sizeof(double));
-        const double target = 1.0 / (double)h->n_rows;
-        double eps_floor = 0.15 * target;  // the last phase runs with target > eps >= 0.15 target (:280-283)
-        if (opt->eps_start > 0 && (double)opt->eps_start < eps_floor) eps_floor = (double)opt->eps_start;
-        if (cand_mode != 1 && max_abs_d * 0x1p-44 > eps_floor) {  // < 2^9 ulps of the largest cost
-            cand_mode = 1;
-            h->lines_guard_off = true;
-        }
+        h->lines_safe_eps = max_abs_d * 0x1p-44;  // < 2^9 ulps of the largest cost
     }
     // Lines for long rows (k_refresh_long) pay where a row scan is long: dense 8000^2 1.79 -> 0.60 s.  At a few
     // hundred edges per row the pass costs more than the scans it saves (C4, 300 edges per row, 176 rounds: 13.4 ->
@@ -1198,15 +1231,15 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
     }
     trace.stage("edge layout");
     const size_t N = (size_t)h->n_rows, M = (size_t)h->n_cols;
-    // second, tile-major copy of the edges for the full-scan bid engines (8 B/edge layout, big rounds only)
-    // launch shape: options.reserved[1] = k + 1 picks shape k (tuning); 0 = by the average (person, tile) segment length
+    // second, tile-major copy of the edges for the full-scan engine (kernels_tiled.hpp; the big rounds and the eCE pass)
+    // launch shape: options.tiled_shape = k + 1 picks shape k (tuning); 0 = by the average (person, tile) segment length
     const bool shape_auto = !(opt->tiled_shape >= 1 && opt->tiled_shape <= kNumTiledShapes);
     h->tiled_shape = shape_auto ? 0 : opt->tiled_shape - 1;
 
     const int tiled_opt = opt->tiled_min_K;  // 0 default, < 0 never, > 0 minimum K for the full-scan engines
     size_t Mpad = M;
     const bool forced_engine = opt->tiled_force != 0 && tiled_opt > 0;  // tests / tuning: any size
-    if (h->f32 && tiled_opt >= 0 && (N >= 4096 || forced_engine)) {
+    if (tiled_opt >= 0 && (N >= 4096 || forced_engine)) {
         const bool forced = forced_engine;  // tests / tuning: skip the density heuristics
         const int tcols = kTiledShapes[h->tiled_shape][4];
         const int T = (int)((M + tcols - 1) / tcols);
@@ -1220,6 +1253,9 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
         const int rb = kTileRB;
         const long long nblk = ((long long)N + rb - 1) / rb;
         const long long L = nblk * T * rb;
+        // the columns of the row-major CSR, whichever layout it has
+        const int *cols = h->f32 ? reinterpret_cast<const int *>(h->edges32) : h->col;
+        const int cs = h->f32 ? 2 : 1;
         // both tables are addressed with 32-bit byte offsets (8 B per entry): < 2^29 entries each
         if ((forced || (double)nnz / ((double)N * T) >= 4.0) && L < 0x1fffffffLL) {
             h->T = T;
@@ -1236,41 +1272,79 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
                 tmp.blks.emplace_back();
                 if ((rc = blk.commit(&tmp.blks.back()))) return rc;
             }
-            HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)L, h->stream));
-            HIP_TRY(hipMemsetAsync(len, 0, sizeof(int) * (size_t)L, h->stream));
-            HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), h->stream));
-            hipLaunchKernelGGL(k_tile_count, dim3(blocks_for((long long)N, 4)), dim3(256), 0, h->stream, h->edges32,
-                               h->row_ptr, h->n_rows, T, tcols, rb, cnt, len, lrel, flag);
-            hipLaunchKernelGGL(k_scan_sums, dim3(nchunks), dim3(1024), 0, h->stream, cnt, L, sums);
-            hipLaunchKernelGGL(k_scan_of_sums, dim3(1), dim3(1024), 0, h->stream, sums, nchunks);
-            hipLaunchKernelGGL(k_scan_apply, dim3(nchunks), dim3(1024), 0, h->stream, cnt, L, sums, start);
-            // overflow lists (kernels_tiled.hpp, k_ovf_count): the edges of a (person, tile) segment beyond what the launch
-            // shape's pipelined loads cover.  `cnt` is free again: per-person counts, then their scan
-            const int *shp0 = kTiledShapes[h->tiled_shape];
-            h->ovf_cap = 2 * shp0[6] * shp0[3];
             {
                 DevBlock blk;
                 blk.want(&h->ovf_ptr, N + 2);
                 h->blocks.emplace_back();
                 if ((rc = blk.commit(&h->blocks.back()))) return rc;
             }
-            const int nch = (int)(((long long)N + 1 + kScanChunk - 1) / kScanChunk);
-            hipLaunchKernelGGL(k_ovf_count, dim3(blocks_for((long long)N, 256)), dim3(256), 0, h->stream, len, h->n_rows, T, rb,
-                               h->ovf_cap, cnt);
-            hipLaunchKernelGGL(k_scan_sums, dim3(nch), dim3(1024), 0, h->stream, cnt, (long long)N, sums);
-            hipLaunchKernelGGL(k_scan_of_sums, dim3(1), dim3(1024), 0, h->stream, sums, nch);
-            hipLaunchKernelGGL(k_scan_apply, dim3(nch), dim3(1024), 0, h->stream, cnt, (long long)N, sums, h->ovf_ptr);
-            trace.stage("tile counts + scans");
             int unsorted = 0, total = 0, n_ovf = 0;
-            HIP_TRY(hipMemcpyAsync(&unsorted, flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-            HIP_TRY(hipMemcpyAsync(&total, start + L, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-            HIP_TRY(hipMemcpyAsync(&n_ovf, h->ovf_ptr + N, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-            HIP_TRY(hipStreamSynchronize(h->stream));
+            // segment lengths (any = rows whose columns are not ascending: counted per edge, no binary search), their
+            // padded scan, the overflow lists' sizes; then the three numbers the host needs
+            auto count_and_scan = [&](bool any) -> int {
+                HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)L, h->stream));
+                HIP_TRY(hipMemsetAsync(len, 0, sizeof(int) * (size_t)L, h->stream));
+                if (!any) {
+                    HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), h->stream));
+                    hipLaunchKernelGGL(k_tile_count, dim3(blocks_for((long long)N, 4)), dim3(256), 0, h->stream, cols, cs,
+                                       h->row_ptr, h->n_rows, T, tcols, rb, cnt, len, lrel, flag);
+                } else {
+                    hipLaunchKernelGGL(k_tile_count_any, dim3(blocks_for((long long)N, 4)), dim3(256), 0, h->stream, cols, cs,
+                                       h->row_ptr, h->n_rows, T, tcols, rb, len);
+                    hipLaunchKernelGGL(k_tile_even, dim3(blocks_for(L, 256)), dim3(256), 0, h->stream, len, L, cnt);
+                }
+                hipLaunchKernelGGL(k_scan_sums, dim3(nchunks), dim3(1024), 0, h->stream, cnt, L, sums);
+                hipLaunchKernelGGL(k_scan_of_sums, dim3(1), dim3(1024), 0, h->stream, sums, nchunks);
+                hipLaunchKernelGGL(k_scan_apply, dim3(nchunks), dim3(1024), 0, h->stream, cnt, L, sums, start);
+                // overflow lists (kernels_tiled.hpp, k_ovf_count): the edges of a (person, tile) segment beyond what the
+                // launch shape's pipelined loads cover.  `cnt` is free again: per-person counts, then their scan
+                const int *shp0 = kTiledShapes[h->tiled_shape];
+                h->ovf_cap = 2 * shp0[6] * shp0[3];
+                const int nch = (int)(((long long)N + 1 + kScanChunk - 1) / kScanChunk);
+                hipLaunchKernelGGL(k_ovf_count, dim3(blocks_for((long long)N, 256)), dim3(256), 0, h->stream, len, h->n_rows, T, rb,
+                                   h->ovf_cap, cnt);
+                hipLaunchKernelGGL(k_scan_sums, dim3(nch), dim3(1024), 0, h->stream, cnt, (long long)N, sums);
+                hipLaunchKernelGGL(k_scan_of_sums, dim3(1), dim3(1024), 0, h->stream, sums, nch);
+                hipLaunchKernelGGL(k_scan_apply, dim3(nch), dim3(1024), 0, h->stream, cnt, (long long)N, sums, h->ovf_ptr);
+                if (!any) HIP_TRY(hipMemcpyAsync(&unsorted, flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+                HIP_TRY(hipMemcpyAsync(&total, start + L, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+                HIP_TRY(hipMemcpyAsync(&n_ovf, h->ovf_ptr + N, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+                HIP_TRY(hipStreamSynchronize(h->stream));
+                return MISSLAP_OK;
+            };
+            // MISSLAP_TILED_CARRY_INDEX=1 (A/B timing, tests): the stored-index formats also for column-sorted rows
+            static const bool carry_env = [] {
+                const char *e = std::getenv("MISSLAP_TILED_CARRY_INDEX");
+                return e && e[0] == '1';
+            }();
+            if ((rc = count_and_scan(false))) return rc;
+            bool carry = carry_env;
+            bool usable = true;
+            if (unsorted) {
+                // Rows whose columns are not ascending (legal in the reference: cumulative_idxs, auction_.pyx:33-48, only
+                // needs the ROWS sorted, and the bid loop takes the stored order, :343-357).  The copy only needs the edges
+                // grouped by tile; what the in-row tie rule (:351) needs -- the stored index -- travels with every edge
+                // (16 bits: rows of at most 65 536 edges; longer ones keep to the wave-per-row kernel).
+                carry = true;
+                usable = st.max_row_len <= 65536;
+                if (usable && (rc = count_and_scan(true))) return rc;
+            }
+            trace.stage("tile counts + scans");
+            h->tiled_fmt = (h->f32 ? 0 : 1) + (carry ? 2 : 0);
+            if (h->tiled_fmt != 0) {  // formats 1..3 exist for the three production shapes (4 / 8 / 16 lanes per person)
+                const int gl0 = kTiledShapes[h->tiled_shape][6];
+                const int want_shape = gl0 == 4 ? 0 : gl0 == 8 ? 8 : 9;
+                if (kTiledShapes[want_shape][3] * 2 * gl0 != h->ovf_cap) usable = false;  // (a tuning shape with another depth)
+                h->tiled_shape = want_shape;
+            }
+            const int rec_bytes = tile_rec_bytes(h->tiled_fmt);
             // The engine pays where segments fit the pipelined loads.  Where more than 1 / 16 of the edges would sit on
             // overflow lists (rows that are dense inside a tile: the `mat=` shapes) the wave-per-row scan is the better
             // full-scan kernel anyway -- a dense row reads the price table in order -- and the second copy is not built.
             const bool fits = forced || (long long)n_ovf * 16 <= (long long)nnz;
-            if (!unsorted && total > 0 && total < 0x1ffffff0 && fits) {
+            // (records are addressed with 32-bit byte offsets)
+            const long long total_max = std::min<long long>(0x1ffffff0LL, (0xfffff000LL / rec_bytes) * 2);
+            if (usable && total > 0 && total < total_max && fits) {
                 h->n_tiled = total;
                 {
                     DevBlock blk;
@@ -1279,25 +1353,32 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
                     if ((rc = blk.commit(&h->blocks.back()))) return rc;
                 }
                 HIP_TRY(hipMemsetAsync(h->ovf_q, 0, sizeof(int4), h->stream));  // (entry 0 is read by idle lanes)
+                const size_t tiled_words = ((size_t)total / 2 + 8) * (size_t)(rec_bytes / 4);  // + 16 entries of padding
                 {
                     DevBlock blk;
-                    blk.want(&h->tiled, (size_t)total + 16);
+                    blk.want(&h->tiled, tiled_words);
                     blk.want(&h->seg4, (size_t)L + 2);
                     blk.want(&h->tcol, (size_t)total + 16);
                     h->blocks.emplace_back();
                     if ((rc = blk.commit(&h->blocks.back()))) return rc;
                 }
-                HIP_TRY(hipMemsetAsync(h->tiled, 0, sizeof(int2) * ((size_t)total + 16), h->stream));
+                HIP_TRY(hipMemsetAsync(h->tiled, 0, sizeof(unsigned) * tiled_words, h->stream));
                 HIP_TRY(hipMemsetAsync(h->tcol, 0, sizeof(int) * ((size_t)total + 16), h->stream));
-                // k_bid_tiled: 6-byte packed edges holding price slots (buffer stride of the double-buffered shapes)
+                if (carry) HIP_TRY(hipMemsetAsync(lrel, 0, sizeof(int) * (size_t)L, h->stream));  // the segments' running fill
+                // packed edges holding price slots (buffer stride of the double-buffered shapes)
                 const int buf_stride = tcols == kTileColsBig ? 0 : tcols + 128;
-                hipLaunchKernelGGL(k_tile_scatter, dim3(blocks_for((long long)N, 4)), dim3(256), 0, h->stream,
-                                   h->edges32, h->row_ptr, h->n_rows, T, tcols, rb, start, lrel, h->tiled,
-                                   h->tcol, buf_stride);
+                const dim3 gs(blocks_for((long long)N, 4)), bs(256);
+                const EdgesF32 e32{h->edges32};
+                const EdgesF64 e64{h->col, h->val64};
+                switch (h->tiled_fmt) {
+                    case 0: hipLaunchKernelGGL((k_tile_scatter<EdgesF32, 0>), gs, bs, 0, h->stream, e32, h->row_ptr, h->n_rows, T, tcols, rb, start, lrel, lrel, h->tiled, h->tcol, buf_stride); break;
+                    case 1: hipLaunchKernelGGL((k_tile_scatter<EdgesF64, 1>), gs, bs, 0, h->stream, e64, h->row_ptr, h->n_rows, T, tcols, rb, start, lrel, lrel, h->tiled, h->tcol, buf_stride); break;
+                    case 2: hipLaunchKernelGGL((k_tile_scatter<EdgesF32, 2>), gs, bs, 0, h->stream, e32, h->row_ptr, h->n_rows, T, tcols, rb, start, lrel, lrel, h->tiled, h->tcol, buf_stride); break;
+                    default: hipLaunchKernelGGL((k_tile_scatter<EdgesF64, 3>), gs, bs, 0, h->stream, e64, h->row_ptr, h->n_rows, T, tcols, rb, start, lrel, lrel, h->tiled, h->tcol, buf_stride); break;
+                }
                 hipLaunchKernelGGL(k_pack_seg4, dim3(blocks_for(L + 1, 256)), dim3(256), 0, h->stream, start, len, L, h->seg4);
                 hipLaunchKernelGGL(k_ovf_fill, dim3(blocks_for((long long)N, 256)), dim3(256), 0, h->stream, len, start,
-                                   h->n_rows, T, rb, h->ovf_cap, h->ovf_ptr, reinterpret_cast<const unsigned *>(h->tiled),
-                                   h->tcol, h->ovf_q);
+                                   h->n_rows, T, rb, h->ovf_cap, h->ovf_ptr, h->tiled, h->tcol, h->ovf_q, h->tiled_fmt);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipStreamSynchronize(h->stream));
                 trace.stage("tile-major copy");
@@ -1307,9 +1388,9 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
                 h->tiled_min_K = tiled_opt > 0 ? tiled_opt : (int)std::max<size_t>((N * 3) / 10, 8192);
                 Mpad = (size_t)T * tcols;  // whole tiles: the LDS fills need no bounds test
                 const hipFuncAttribute at = hipFuncAttributeMaxDynamicSharedMemorySize;
-                {
-                    // per create, i.e. per device: the > 64 KB dynamic-LDS opt-in is a property of the function ON
-                    // the current device, so a process-wide "done" flag would leave a second device without it
+                // per create, i.e. per device: the > 64 KB dynamic-LDS opt-in is a property of the function ON
+                // the current device, so a process-wide "done" flag would leave a second device without it
+                if (h->tiled_fmt == 0) {
                     switch (h->tiled_shape) {
 #define X(I, TH, R, B, D, TC, LD, GL, CS)                                                                           \
     case I:                                                                                                          \
@@ -1325,6 +1406,17 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
         HIP_TRY(hipFuncSetAttribute((const void *)MISSLAP_CHECK_KERNEL(GL), at, (int)tiled_lds_bytes(kTileColsHalf)));  \
         break;
                         MISSLAP_FOR_CHECK_LANES(X)
+#undef X
+                        default: break;
+                    }
+                } else {
+                    switch (h->tiled_fmt * 100 + kTiledShapes[h->tiled_shape][6]) {
+#define X(FMT, GL)                                                                                                   \
+    case FMT * 100 + GL:                                                                                             \
+        HIP_TRY(hipFuncSetAttribute((const void *)MISSLAP_BID_KERNEL_FMT(GL, FMT), at, (int)tiled_lds_bytes(kTileColsHalf)));   \
+        HIP_TRY(hipFuncSetAttribute((const void *)MISSLAP_CHECK_KERNEL_FMT(GL, FMT), at, (int)tiled_lds_bytes(kTileColsHalf))); \
+        break;
+                        MISSLAP_FOR_FMT_LANES(X)
 #undef X
                         default: break;
                     }
@@ -1430,6 +1522,7 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
     h->theta = (float)0.15;                       // :248
     if (opt->eps_start > 0) h->eps = opt->eps_start;  // :251-252
     h->start_eps = h->eps;
+    begin_phase(h);
     h->K_ub = h->n_rows;
     h->K_exact = true;
     h->phase_fresh = true;
@@ -2162,6 +2255,7 @@ MISSLAP_API int misslap_phase_end(misslap_solver *h, int32_t *finished) {
             h->h_ctl->nleft = 0;
             h->phase_fresh = true;
             h->ece_flag_clear = true;
+            begin_phase(h);
         }
     }
     if (finished) *finished = h->finished ? 1 : 0;
@@ -2223,7 +2317,7 @@ MISSLAP_API int misslap_finish(misslap_solver *h, int32_t *person_to_object_out,
         const unsigned long long uniq = distinct + (n_neg ? 1ull : 0ull);  // np.unique counts -1 as one value
         meta->complete_assignment = (uniq == (unsigned long long)h->n_rows ? 1 : 0) | (n_neg == 0 ? 2 : 0) | (n_big == 0 ? 4 : 0);
         meta->valid_assignment = n_invalid == 0 ? 1 : 0;
-        meta->lines_active = h->cand != nullptr ? 1 : 0;
+        meta->lines_active = (h->cand != nullptr && !h->lines_dropped) ? 1 : 0;  // (at the END of the solve: see phases_with_lines)
     }
     meta->start_eps = h->start_eps;
     meta->final_eps = h->eps;
@@ -2259,6 +2353,9 @@ MISSLAP_API int misslap_finish(misslap_solver *h, int32_t *person_to_object_out,
     meta->cand_hits = c.cand_hits;
     meta->cand_edges = c.cand_edges;
     meta->sharded_rounds = h->sharded_rounds;
+    meta->tiled_format = h->tiled_ok ? h->tiled_fmt : 0;
+    meta->phases_with_lines = h->phases_with_lines;
+    meta->eps_phases = h->phases_run;
     if (h->profile && h->prof_used) {
         std::vector<unsigned long long> le(2 * (size_t)h->launch_idx);
         if (h->launch_idx)
@@ -2529,7 +2626,7 @@ MISSLAP_API int misslap_debug_time_bid(misslap_solver *h, int32_t mode, int32_t 
         HIP_TRY(hipFuncSetAttribute((const void *)k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 1, 6>, at, ldsb));
         RoundArgs a = round_args(h);
         a.launch_edges = nullptr;
-        TiledArgs ta{reinterpret_cast<const unsigned *>(h->tiled), h->tcol, h->seg4, h->T, 1, h->n_tiled,
+        TiledArgs ta{h->tiled, h->tcol, h->seg4, h->T, 1, h->n_tiled,
                      nullptr, nullptr, h->ovf_ptr, h->ovf_q, h->ovf_cap, h->part_vw, h->part_g, h->n_rows, h->split_cnt, FinalOut{}};
         hipEvent_t t0, t1;
         HIP_TRY(hipEventCreate(&t0));

@@ -148,3 +148,13 @@ def gen_config(name, seed=1):
     if c.get("dense"):
         return gen_dense(c["n_rows"], c["n_cols"], seed=seed)
     return gen_sparse(c["n_rows"], c["n_cols"], c["density"], seed=seed)
+
+
+def shuffle_within_rows(loc, val, seed):
+    """Permute the stored order of the entries inside every row (rows stay ascending): legal input for the reference
+    (cumulative_idxs, auction_.pyx:33-48, only needs the rows sorted), and its in-row tie rule follows the stored order
+    (:351)."""
+    n = loc.shape[0]
+    key = _stream(seed, 77, n)
+    order = np.lexsort((key, loc[:, 0]))
+    return np.ascontiguousarray(loc[order]), np.ascontiguousarray(val[order])

@@ -11,10 +11,7 @@ from sslap_amd import synth
 
 def _shuffle_within_rows(loc, val, seed):
     """Permute the stored order of entries inside every row (rows stay sorted)."""
-    n = loc.shape[0]
-    key = synth._stream(seed, 77, n)
-    order = np.lexsort((key, loc[:, 0]))
-    return np.ascontiguousarray(loc[order]), np.ascontiguousarray(val[order])
+    return synth.shuffle_within_rows(loc, val, seed)
 
 
 def _single_entry_rows(n, density, seed, n_single):

@@ -115,9 +115,9 @@ def test_baseline_configs_match_reference_hashes(name, golden_large, gpu_lib):
     if g is None:
         pytest.skip(f"{name} fixture not generated")
     spec, kw = cases.LARGE_CASES[name]
-    loc, val = cases.synth_inputs(spec)
+    loc, val = _config_arrays(spec["name"])[:2]  # (generated once per session: the sharded tests use the same arrays)
     assert synth.input_digest(loc, val) == g["input_sha256"]
-    res = auction_solve(loc=loc, val=val, cardinality_check=False, **kw)
+    res = auction_solve(loc=loc, val=val.copy(), cardinality_check=False, **kw)
     sol, meta = res["sol"], res["meta"]
     assert synth.sol_digest(sol) == g["sol_sha256"]
     for k in cases.META_KEYS:
@@ -292,18 +292,22 @@ def test_sharded_driver_two_ranks_one_gpu(gpu_lib):
     (dict(kind="sparse", n=4500, m=33000, density=0.0012, ints=3), "min"), # ties across tiles
 ])
 @pytest.mark.parametrize("engine", [1])
-def test_tiled_bid_kernel_round_by_round(spec, prob, engine, gpu_lib):
+@pytest.mark.parametrize("fmt", [0, 1, 2, 3])
+def test_tiled_bid_kernel_round_by_round(spec, prob, engine, fmt, gpu_lib):
     """The full-scan engine k_bid_tiled (prices tiled in LDS, tile loop) forced for every grid round
-    (tiled_min_k = 1, no tail kernel): full state vs the oracle after r rounds."""
-    loc, val = cases.synth_inputs(spec)
+    (tiled_min_k = 1, no tail kernel): full state vs the oracle after r rounds -- in each record format of the
+    tile-major copy: 0 = 6 B/edge (fp32-exact values), 1 = 10 B/edge (fp64 values: the 12 B/edge layout forced), 2 / 3 =
+    the same with the stored index carried, on rows whose stored order is a random permutation (the reference takes the
+    stored order, auction_.pyx:343-357, and its in-row tie rule is 'the last stored index wins', :351)."""
+    loc, val = cases.synth_inputs(dict(spec, kind="shuffled") if fmt >= 2 else spec)
     for r in [1, 2, 3, 5, 8, 13, 21, 40, 80, 200]:
         o = orc.from_sparse(loc, val.copy(), problem=prob, max_iter=r, cardinality_check=False)
         o.solve()
         so = o.state()
         g = from_sparse(loc, val.copy(), problem=prob, max_iter=r, cardinality_check=False, tail_threshold=0,
-                        tiled_min_k=1, engine=engine)
+                        tiled_min_k=1, engine=engine, force_f64=bool(fmt & 1))
         g.solve()
-        assert g.gpu["tiled_active"] == engine
+        assert g.gpu["tiled_active"] == engine and g.gpu["tiled_format"] == fmt
         sg = g.state()
         assert sg["its"] == so["its"] and sg["K"] == so["K"], r
         assert np.array_equal(sg["U"], so["U"]), r
@@ -324,14 +328,24 @@ def test_tiled_and_gather_kernels_agree_end_to_end(gpu_lib):
         assert s.gpu["obj_f64"] == ref["extra"]["obj_f64"]
 
 
-def test_unsorted_rows_fall_back_to_gather_kernel(gpu_lib):
-    spec = dict(kind="shuffled", n=5000, m=20000, density=0.002)
+@pytest.mark.parametrize("ints", [0, 3])
+def test_unsorted_rows_run_on_the_full_scan_engine(ints, gpu_lib):
+    """Rows whose columns are not ascending (legal in the reference) keep the full-scan engine and its eCE pass: the
+    tile-major copy carries every edge's stored index (formats 2 / 3), and equal values are ordered by it.  With integer
+    costs (ties in nearly every row) the result depends on that order."""
+    spec = dict(kind="shuffled", n=5000, m=20000, density=0.002, ints=ints)
     loc, val = cases.synth_inputs(spec)
     ref = orc.auction_solve(loc=loc, val=val.copy(), problem="max", cardinality_check=False)
-    s = from_sparse(loc, val.copy(), problem="max", cardinality_check=False, tiled_min_k=1)
-    sol = s.solve()
-    assert s.gpu["tiled_active"] == 0  # in-row order is the tie rule: no tile-major copy for unsorted rows
-    assert np.array_equal(sol, ref["sol"])
+    for f64 in (False, True):
+        s = from_sparse(loc, val.copy(), problem="max", cardinality_check=False, tiled_min_k=1, force_f64=f64)
+        sol = s.solve()
+        assert s.gpu["tiled_active"] == 1 and s.gpu["tiled_format"] == (3 if f64 else 2)
+        assert np.array_equal(sol, ref["sol"]) and s.meta["its"] == ref["meta"]["its"]
+        assert s.gpu["obj_f64"] == ref["extra"]["obj_f64"] and s.meta["eCE"] == ref["meta"]["eCE"]
+    if ints:  # the stored order matters here: the column-sorted version of the same instance has another solution
+        loc2, val2 = cases.synth_inputs(dict(spec, kind="sparse"))
+        ref2 = orc.auction_solve(loc=loc2, val=val2.copy(), problem="max", cardinality_check=False)
+        assert not np.array_equal(ref2["sol"], ref["sol"])
 
 
 def test_integration_md_binding_stub_works(gpu_lib):
@@ -681,17 +695,20 @@ def test_degenerate_shapes(thr, gpu_lib):
                 assert g.meta[k] == o.meta[k], k
 
 
-@pytest.mark.parametrize("lines", [True, False])
-def test_f64_layout_at_c2_size_matches_reference_hash(lines, golden_large, gpu_lib):
+@pytest.mark.parametrize("cfg,lines,engine", [("C2", True, True), ("C2", False, True), ("C2", True, False), ("C3", True, True),
+                                              ("C4", True, True)])
+def test_f64_layout_at_baseline_sizes_matches_reference_hash(cfg, lines, engine, golden_large, gpu_lib):
     """The 12 B/edge kernel instances (int32 col + fp64 val; candidate lines with a parallel line of fp64 costs, or --
-    lines off -- rows requested ahead) at a BASELINE size: C2's values are fp32-exact, so forcing the layout must
-    reproduce the reference's C2 assignment."""
-    g = golden_large["cases"]["C2"]
-    spec, kw = cases_mod.LARGE_CASES["C2"]
-    loc, val = cases_mod.synth_inputs(spec)
-    s = from_sparse(loc, val, cardinality_check=False, force_f64=True, cand=lines, **kw)
+    lines off -- rows requested ahead; full scans on the engine's 10 B/edge record format, or -- engine off -- on the
+    wave-per-row kernel) at the BASELINE sizes: the configs' values are fp32-exact, so forcing the layout must reproduce
+    the reference's assignment."""
+    g = golden_large["cases"][cfg]
+    spec, kw = cases_mod.LARGE_CASES[cfg]
+    loc, val = _config_arrays(cfg)[:2]
+    s = from_sparse(loc, val, cardinality_check=False, force_f64=True, cand=lines, tiled_min_k=None if engine else -1, **kw)
     sol = s.solve()
-    assert s.gpu["bytes_per_edge"] == 12 and (s.gpu["cand_hits"] > 0) == lines
+    assert s.gpu["bytes_per_edge"] == 12 and (s.gpu["cand_hits"] > 0) == (lines and cfg != "C4")
+    assert s.gpu["tiled_active"] == int(engine) and (not engine or s.gpu["tiled_format"] == 1)
     assert synth.sol_digest(sol) == g["sol_sha256"]
     assert s.meta["its"] == g["meta"]["its"] and s.gpu["obj_f64"] == g["obj_f64"]
     assert s.gpu["edges_scanned"] == g["edges_scanned"]
@@ -1007,22 +1024,46 @@ def test_validity_flags_equal_the_host_computation(gpu_lib):
         assert g["valid_assignment"] == want_valid, (n, m, prob, max_iter)
 
 
-def test_lines_are_switched_off_when_eps_is_below_the_rounding_error(gpu_lib):
+def test_lines_are_dropped_from_the_first_phase_whose_eps_is_below_the_rounding_error(gpu_lib):
     """Candidate lines rely on prices only rising; once eps (down to 0.15 / N) comes within 2^9 ulps of the largest
-    |cost|, a price update fl(fl(c - w) + eps) may round DOWN.  Such a handle runs without lines
-    (meta['gpu']['lines_active'] == 0) and still equals the oracle bit for bit."""
+    |cost|, a price update fl(fl(c - w) + eps) may round DOWN.  The guard is per eps-phase: the early phases (eps far above
+    the rounding error) run WITH lines, the lines are dropped for good from the first phase below the bound
+    (meta['gpu']['phases_with_lines'] < 'eps_phases', 'lines_active' == 0 at the end), and the result still equals the
+    oracle bit for bit."""
     loc, val = synth.gen_sparse(800, 800, 0.03, seed=9)
     big = np.float64(np.float32(1e10)) + val * 1024.0  # |cost| ~ 1e10 (ulp 1.9e-6) against eps >= 1.9e-4
     for v in (big, np.round(val * 1e8)):
         ref = orc.auction_solve(loc=loc, val=v.copy(), problem="max", cardinality_check=False, max_iter=10**7)
-        s = from_sparse(loc, v.copy(), problem="max", cardinality_check=False, max_iter=10**7)
-        sol = s.solve()
-        assert s.gpu["lines_active"] == 0
-        assert np.array_equal(sol, ref["sol"]) and s.meta["its"] == ref["meta"]["its"]
-        assert s.gpu["obj_f64"] == ref["extra"]["obj_f64"]
+        for thr in (None, 0):
+            s = from_sparse(loc, v.copy(), problem="max", cardinality_check=False, max_iter=10**7, tail_threshold=thr)
+            sol = s.solve()
+            g = s.gpu
+            assert g["eps_phases"] == s.meta["nreductions"] + 1
+            assert g["lines_active"] == 0 and 0 < g["phases_with_lines"] < g["eps_phases"], (g["phases_with_lines"], g["eps_phases"])
+            assert g["phases_with_lines"] >= g["eps_phases"] - 2  # only the last phase(s) are below the bound
+            assert g["cand_hits"] > 0
+            assert np.array_equal(sol, ref["sol"]) and s.meta["its"] == ref["meta"]["its"]
+            assert g["obj_f64"] == ref["extra"]["obj_f64"]
     s = from_sparse(loc, val.copy(), problem="max", cardinality_check=False)
     s.solve()
-    assert s.gpu["lines_active"] == 1
+    assert s.gpu["lines_active"] == 1 and s.gpu["phases_with_lines"] == s.gpu["eps_phases"] == s.meta["nreductions"] + 1
+
+
+def test_integer_costs_of_1e8_at_1e5_persons_keep_their_lines_until_the_last_phases(gpu_lib):
+    """Ordinary integer costs at scale (max |cost| = 1e8, N = 100 000: 1e8 x 2^-44 = 5.7e-6 against a last phase's eps of
+    1.5e-6 .. 1e-5): the all-or-nothing guard of round 4 ran the whole solve without lines; now only the phases below
+    the bound do.  Bit-equal to the oracle."""
+    n = 100_000
+    loc, val = synth.gen_sparse(n, n, 0.0005, seed=21)
+    v = np.round(val * 1e6)
+    assert v.max() > 9e7
+    ref = orc.auction_solve(loc=loc, val=v.copy(), problem="max", cardinality_check=False, max_iter=10**8)
+    s = from_sparse(loc, v.copy(), problem="max", cardinality_check=False, max_iter=10**8)
+    sol = s.solve()
+    g = s.gpu
+    assert np.array_equal(sol, ref["sol"]) and s.meta["its"] == ref["meta"]["its"] and g["obj_f64"] == ref["extra"]["obj_f64"]
+    assert g["eps_phases"] == s.meta["nreductions"] + 1 and g["phases_with_lines"] >= g["eps_phases"] - 2
+    assert g["cand_hits"] > g["bids_made"] // 2
 
 
 def test_rccl_world1_smoke(gpu_lib):
@@ -1047,24 +1088,27 @@ def test_rccl_world1_smoke(gpu_lib):
         solve_sharded(s, comm)
 
 
-@pytest.mark.parametrize("shape", [0, 4, 7, 8, 9])
+@pytest.mark.parametrize("shape,fmt", [(0, 0), (4, 0), (7, 0), (8, 0), (9, 0), (0, 1), (8, 1), (9, 1), (0, 2), (8, 2), (9, 2),
+                                       (0, 3), (8, 3), (9, 3)])
 @pytest.mark.parametrize("spec,prob", [
     (dict(kind="sparse", n=6000, m=40000, density=0.001), "max"),           # ~10 edges per (person, tile) segment
     (dict(kind="sparse", n=5000, m=25000, density=0.004, ints=5), "min"),   # ~33 edges per segment, ties
     (dict(kind="sparse", n=4200, m=12000, density=0.01), "max"),            # ~60 edges per segment
 ])
-def test_tiled_kernel_shapes_round_by_round(spec, prob, shape, gpu_lib):
+def test_tiled_kernel_shapes_round_by_round(spec, prob, shape, fmt, gpu_lib):
     """Every lanes-per-person variant of k_bid_tiled (4 / 8 / 16 lanes: shapes 0, 7 / 8 / 9; shape 4: the column split) on short, medium and long
-    (person, tile) segments, forced for every grid round: full state vs the oracle."""
-    loc, val = cases.synth_inputs(spec)
+    (person, tile) segments -- a shape that is too short for the segments sends their tails to the overflow lists --,
+    forced for every grid round: full state vs the oracle.  The three production shapes also in the record formats
+    1..3 (fp64 values; stored index carried on row-shuffled input)."""
+    loc, val = cases.synth_inputs(dict(spec, kind="shuffled") if fmt >= 2 else spec)
     for r in [1, 2, 3, 5, 8, 13, 30, 80]:
         o = orc.from_sparse(loc, val.copy(), problem=prob, max_iter=r, cardinality_check=False)
         o.solve()
         so = o.state()
         g = from_sparse(loc, val.copy(), problem=prob, max_iter=r, cardinality_check=False, tail_threshold=0,
-                        tiled_min_k=1, engine=1, tiled_shape=shape)
+                        tiled_min_k=1, engine=1, tiled_shape=shape, force_f64=bool(fmt & 1))
         g.solve()
-        assert g.gpu["tiled_active"] == 1
+        assert g.gpu["tiled_active"] == 1 and g.gpu["tiled_format"] == fmt
         sg = g.state()
         assert sg["its"] == so["its"] and sg["K"] == so["K"], r
         assert np.array_equal(sg["U"], so["U"]), r
@@ -1115,9 +1159,14 @@ def _drive_to_phase_end(g):
     # the same entry stored more than once: the LAST one is the choice (auction_.pyx:467-471)
     ("dups", dict(kind="dups", n=150, density=0.06, ints=6), "max", dict()),
     ("tiled_dups", dict(kind="dups", n=5000, density=0.004, ints=9, adjacent=True), "max", dict(tiled_min_k=1, engine=1)),
-    # 12 B/edge layout (values that are not fp32-exact): the pass on the row-major CSR
-    ("f64", dict(kind="f64", n=4500, density=0.004), "min", dict()),
-    ("forced_f64", dict(kind="sparse", n=6000, m=6000, density=0.003), "max", dict(force_f64=True)),
+    # 12 B/edge layout (values that are not fp32-exact): the pass on the row-major CSR, and on the engine (format 1)
+    ("f64", dict(kind="f64", n=4500, density=0.004), "min", dict(tiled_min_k=-1)),
+    ("forced_f64", dict(kind="sparse", n=6000, m=6000, density=0.003), "max", dict(force_f64=True, tiled_min_k=-1)),
+    ("tiled_f64", dict(kind="f64", n=4500, density=0.004), "min", dict(tiled_min_k=1, engine=1)),
+    ("tiled16_f64", dict(kind="sparse", n=4200, m=12000, density=0.01), "max", dict(tiled_min_k=1, engine=1, tiled_shape=9, force_f64=True)),
+    # rows in a random stored order: the engine's formats 2 / 3 (the LAST stored match is the choice, by stored index)
+    ("tiled_shuffled", dict(kind="shuffled", n=6000, m=40000, density=0.001, ints=7), "max", dict(tiled_min_k=1, engine=1)),
+    ("tiled8_shuffled_f64", dict(kind="shuffled", n=5000, m=25000, density=0.004, ints=5), "min", dict(tiled_min_k=1, engine=1, tiled_shape=8, force_f64=True)),
     # fewer rows than the sample: the sample IS the pass
     ("small", dict(kind="sparse", n=300, m=300, density=0.05), "max", dict()),
     ("tiled_rect", dict(kind="sparse", n=5000, m=7500, density=0.004), "max", dict(tail_threshold=0)),
@@ -1155,9 +1204,10 @@ def test_ece_pass_equals_the_reference_loop_at_every_phase_end(label, spec, prob
 @pytest.mark.parametrize("thr", [None, 0, 16])
 def test_falling_prices_without_lines_equal_the_reference(thr, gpu_lib):
     """Costs of ~2^50 over four binades against eps down to 0.15 / N: a price update fl(fl(c - w) + eps) rounds DOWN
-    now and then, i.e. prices FALL (the reference then cycles until max_iter).  The precision guard has switched the
-    candidate lines off for such a handle, nothing else depends on rising prices, so the solve must neither fail
-    (kErrPriceFell is raised only for handles with lines) nor differ from the reference in a single bit."""
+    now and then, i.e. prices FALL (the reference then cycles until max_iter).  The precision guard drops the candidate
+    lines from the first eps-phase in which that can happen (the phases before it -- eps from 2^50 down to 2^7 -- run with
+    them: the mixed regime), nothing else depends on rising prices, so the solve must neither fail (kErrPriceFell is
+    raised only while lines are in use) nor differ from the reference in a single bit."""
     n, max_iter = 300, 5000
     loc, _ = synth.gen_sparse(n, n, 0.05, seed=10)
     val = 2.0 ** 47 * (1.0 + 15.0 * np.random.RandomState(10).random_sample(loc.shape[0]))
@@ -1172,6 +1222,7 @@ def test_falling_prices_without_lines_equal_the_reference(thr, gpu_lib):
     g = from_sparse(loc, val.copy(), problem="max", max_iter=max_iter, cardinality_check=False, tail_threshold=thr)
     sol = g.solve()
     assert g.gpu["lines_active"] == 0 and g.meta["its"] == max_iter == so["its"]
+    assert 0 < g.gpu["phases_with_lines"] < g.gpu["eps_phases"]
     sg = g.state()
     assert np.array_equal(sg["p"].view(np.uint64), so["p"].view(np.uint64))
     assert np.array_equal(sg["p2o"], so["p2o"]) and np.array_equal(sol, so["p2o"]) and np.array_equal(sg["U"], so["U"])
@@ -1311,6 +1362,20 @@ def test_sharded_solve_at_baseline_sizes_rank_threads_one_gpu(world, cfgs, golde
             t.join()
         assert not errs, errs[:3]
     _check_sharded_results(got, world, cfgs, golden_large)
+
+
+def test_row_shuffled_c2_keeps_the_engine_and_matches_the_oracle(gpu_lib):
+    """C2 with the stored order of every row randomly permuted: the full-scan engine stays on (record format 2, stored
+    index carried), the result equals the oracle's on the same arrays."""
+    loc, val = _config_arrays("C2")[:2]
+    loc, val = cases._shuffle_within_rows(loc, val, 5)
+    ref = orc.auction_solve(loc=loc, val=val.copy(), problem="max", cardinality_check=False, max_iter=10**8)
+    s = from_sparse(loc, val.copy(), problem="max", cardinality_check=False, max_iter=10**8)
+    sol = s.solve()
+    assert s.gpu["tiled_active"] == 1 and s.gpu["tiled_format"] == 2
+    assert np.array_equal(sol, ref["sol"]) and s.meta["its"] == ref["meta"]["its"]
+    assert s.gpu["obj_f64"] == ref["extra"]["obj_f64"] and s.gpu["edges_scanned"] == ref["extra"]["edges_scanned"]
+    assert s.meta["eCE"] == 1 and s.meta["soln_found"] == 1
 
 
 def test_final_pass_grid_fits_its_result_slots_at_any_size(gpu_lib):
