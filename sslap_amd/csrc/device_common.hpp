@@ -749,4 +749,86 @@ __device__ __forceinline__ void wave_bid_lean(const E &ed, const Src &src, const
     out.key = bid_to_key(bid);
 }
 
+// ---- the same bid through a single-precision FILTER (full scans of the wave-per-row kernel on big price tables) --------
+// Where the prices do not fit an XCD's L2 (C5: 10^6 objects x 8 B = 8 MB against 4 MB) every 8-byte price gather that
+// misses costs a 128-byte fabric line, and that traffic -- 2.9x the algorithmic bytes -- bounds the scan (PMC,
+// profiles/r03_pmc_counters_C5_gather_scan.txt).  A 4-byte mirror of the prices (p32 = fl32(p), rebuilt in front of the
+// launch: kernels_round.hpp, k_price_mirror) is half the table and fits.  The result stays BIT-EXACT because the fp32
+// pass only decides WHICH two edges are looked at exactly:
+//     a_e = fl32(fl32(c_e) - p32[col_e])       |a_e - v_e| <= delta  for  v_e = fl64(c_e - p[col_e]), the reference's value,
+//                                              delta = 2^-22 (max|c| + max p)  (three roundings of <= 2^-24 relative each)
+//     a1 >= a2 >= a3 the three largest a of the row (multiplicity counted), e1 / e2 the edges holding a1 / a2
+//     if a2 - a3 > 2 delta:  v(e1), v(e2) >= a2 - delta > a3 + delta >= v(e) for every other edge e, so {e1, e2} ARE the
+//     row's two best edges, strictly: the bid is formed from their exact values (two fp64 gathers), best = the larger,
+//     the later stored index among equals (:351), w = the other (:357), bid = (cost - w) + eps (:360).
+//     otherwise (ties or near-ties at the top, rows of fewer than two finite values): the exact scan (wave_bid_lean).
+// `two_delta` = 2 delta as fp32 (+inf disables the filter for rows that have a finite third value).
+template <class E>
+__device__ __forceinline__ void wave_bid_filter(const E &ed, const double *price, const float *p32, const float two_delta,
+                                                const int s, const int e, const double eps, CandBid &out, int &err) {
+    const int lane = lane_id();
+    const float ninf = -__builtin_huge_valf();
+    float t1 = ninf, t2 = ninf, t3 = ninf;  // the lane's three largest a, and the stored indices of the first two
+    int g1 = -1, g2 = -1;
+    for (int base = s; base < e; base += 2 * kWave) {
+        int c[2];
+        double a[2];
+        float pr[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) ed.load(min(base + u * kWave + lane, e - 1), c[u], a[u]);  // unconditional, clamped
+#pragma unroll
+        for (int u = 0; u < 2; ++u) pr[u] = p32[c[u]];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int g = base + u * kWave + lane;
+            const float v = g < e ? (float)a[u] - pr[u] : ninf;
+            const bool b1 = v > t1, b2 = v > t2, b3 = v > t3;
+            t3 = b2 ? t2 : (b3 ? v : t3);
+            g2 = b1 ? g1 : (b2 ? g : g2);
+            t2 = b1 ? t1 : (b2 ? v : t2);
+            g1 = b1 ? g : g1;
+            t1 = b1 ? v : t1;
+        }
+    }
+    auto wave_max_f32 = [](float v) {
+        v = __builtin_fmaxf(v, __int_as_float(dppf_i32<kDppXor1>(__float_as_int(v))));
+        v = __builtin_fmaxf(v, __int_as_float(dppf_i32<kDppXor2>(__float_as_int(v))));
+        v = __builtin_fmaxf(v, __int_as_float(dppf_i32<kDppHalfMirror>(__float_as_int(v))));
+        v = __builtin_fmaxf(v, __int_as_float(dppf_i32<kDppMirror>(__float_as_int(v))));
+        v = __builtin_fmaxf(v, __int_as_float(dpp_i32<kDppBcast15, 0xA>(__float_as_int(v))));
+        v = __builtin_fmaxf(v, __int_as_float(dpp_i32<kDppBcast31, 0xC>(__float_as_int(v))));
+        return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+    };
+    // the wave's three largest: M1 in lane L1, M2 in lane L2 (possibly the same lane), M3
+    const float M1 = wave_max_f32(t1);
+    const int L1 = __ffsll((long long)__ballot(t1 == M1)) - 1;
+    const float c2 = lane == L1 ? t2 : t1;
+    const float M2 = wave_max_f32(c2);
+    const int L2 = __ffsll((long long)__ballot(c2 == M2)) - 1;
+    const float c3 = lane == L1 ? (L2 == L1 ? t3 : t2) : (lane == L2 ? t2 : t1);
+    const float M3 = wave_max_f32(c3);
+    const bool decided = (M2 > ninf) && ((M3 == ninf) || (M2 - M3 > two_delta));  // wave-uniform
+    if (!decided) {
+        wave_bid_lean(ed, PriceSource{price}, s, e, eps, out, err);
+        return;
+    }
+    const int e1 = __builtin_amdgcn_readlane(g1, L1);
+    const int e2 = L2 == L1 ? __builtin_amdgcn_readlane(g2, L1) : __builtin_amdgcn_readlane(g1, L2);
+    int col1, col2;
+    double cost1, cost2;
+    ed.load(e1, col1, cost1);  // (wave-uniform addresses; the lines were streamed a moment ago)
+    ed.load(e2, col2, cost2);
+    const double v1 = cost1 - price[col1], v2 = cost2 - price[col2];  // vi = cost - p[j]   (:350), exact
+    const bool second = (v2 > v1) | ((v2 == v1) & (e2 > e1));        // :351: the later stored index among equals
+    const double cost = second ? cost2 : cost1, w = second ? v1 : v2;
+    out.hit = false;
+    out.obj = second ? col2 : col1;
+    out.prev = -1;
+    out.pstart = 0;
+    out.len = e - s;
+    const double bid = (cost - w) + eps;  // bbest = costbest - wi + eps   (:360)
+    if (bid_is_bad(bid)) err |= kErrNegativeBid;
+    out.key = bid_to_key(bid);
+}
+
 }  // namespace misslap

@@ -56,6 +56,11 @@ struct RoundArgs {
                                   // them): the work list of k_refresh_long
     unsigned long long *live;     // pinned host words the round-closing kernel posts the status to (post_live_status);
     unsigned ticket;              // nullptr: none.  ticket: the host's number of that launch
+    // single-precision filter of the full scans (device_common.hpp, wave_bid_filter): the fp32 mirror of the prices built
+    // in front of this launch (nullptr: exact scans), the bit pattern of the largest price at that time, max |cost|
+    const float *price32;
+    const int *pmax_bits;
+    float cmax;
 };
 constexpr int kStatEdges = 0, kStatBids = 1, kStatHits = 2, kStatHitEdges = 3, kStatShardEdges = 4, kStatLaunchEdges = 5,
               kStatLaunchHitEdges = 6,  // of kStatLaunchEdges: rows a candidate line answered (counted, never read)
@@ -159,6 +164,11 @@ __device__ __forceinline__ void bid_positions(const RoundArgs &a, const E &ed, i
                 const typename E::Raw none[4] = {};
                 wave_bid_full<E, Src, false, false>(ed, src, s, e, none, eps, b[0], ba, tl.err);
                 if (lines && ba.want && hi > a.cand_build_min_K) cand_build(a.cand, a.cand64, i, ba, eps, hint);
+            } else if (!SrcOf<Src>::kOwners && a.price32 != nullptr) {  // (wave-uniform) big price table: through the fp32 filter
+                // 2 delta = 2^-21 (max |cost| + max price): see wave_bid_filter; an infinite price (one-entry rows bid
+                // +inf) makes it infinite, which sends every row with a finite third value to the exact scan
+                const float two_delta = 0x1p-21f * (a.cmax + __int_as_float(*a.pmax_bits));
+                wave_bid_filter(ed, a.price, a.price32, two_delta, s, e, eps, b[0], tl.err);
             } else {
                 wave_bid_lean(ed, src, s, e, eps, b[0], tl.err);
             }
@@ -242,6 +252,22 @@ __global__ __launch_bounds__(kBidBlock) void k_bid(RoundArgs a, E ed) {
     BidTally tl;
     bid_positions<E, Src, kLines, false>(a, ed, lo, hi, first, gridDim.x * wpb, i_first, tl);
     tally_flush<kBidBlock / kWave>(a, tl, head.K);
+}
+
+// The fp32 mirror of the prices for wave_bid_filter, and the largest price (bit pattern: prices are >= 0, so the patterns
+// order like integers; *pmax_bits is zeroed by the host in front of the launch).  Only in a live round that k_bid serves.
+__global__ __launch_bounds__(256) void k_price_mirror(const Ctl *ctl, const double *price, float *price32, int n_cols,
+                                                      int *pmax_bits, int thr, int gather_max_K) {
+    if (!round_live(ctl, thr) || (gather_max_K > 0 && ctl->K >= gather_max_K)) return;
+    float m = 0.f;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n_cols; j += gridDim.x * blockDim.x) {
+        const float p = (float)price[j];  // round to nearest
+        price32[j] = p;
+        m = __builtin_fmaxf(m, __builtin_fabsf(p));
+    }
+    int b = __float_as_int(m);
+    for (int off = 32; off >= 1; off >>= 1) b = max(b, __shfl_xor(b, off));
+    if ((threadIdx.x & 63) == 0 && b > 0) atomicMax(pmax_bits, b);
 }
 
 // Line maintenance ahead of the tail kernels (once per eps-phase, when K has fallen to the tail threshold).  The grid

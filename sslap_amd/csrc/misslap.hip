@@ -220,6 +220,9 @@ struct misslap_solver {
     double *val64 = nullptr;
     int *row_ptr = nullptr;
     double *price = nullptr;
+    float *price32 = nullptr;  // fp32 mirror of the prices for the filter scans of the wave-per-row kernel (wave_bid_filter);
+    int *pmax_bits = nullptr;  // nullptr: no filter.  pmax_bits: the largest price at the last rebuild of the mirror
+    float cmax32 = 0.f;        // (float) max |cost|
     PriceRec *rec = nullptr;
     int2 *cand = nullptr;  // candidate lines, 256 B per person
     double *cand64 = nullptr;  // ... and 256 B of fp64 costs per person in the 12 B/edge layout
@@ -551,6 +554,9 @@ RoundArgs round_args(misslap_solver *h) {
     }();
     a.cand_build_min_K = (h->thr > 0 && h->line_maintenance) ? build_min_env : 0;  // (no maintenance pass: nobody else rebuilds)
     a.cand_refresh_min = h->cand_refresh_min;
+    a.price32 = nullptr;  // (set by launch_bid for the launches that scan through the filter)
+    a.pmax_bits = h->pmax_bits;
+    a.cmax = h->cmax32;
     return a;
 }
 
@@ -819,6 +825,14 @@ int launch_bid(misslap_solver *h) {
     }
     // variant: 2 = lines used and rebuilt; 1 = lines used, lean scan, nothing built (the full-scan regime); 0 = no lines
     const int variant = !h->lines_live() ? 0 : h->K_ub > h->cand_build_max_K ? 1 : 2;
+    // big rounds of a handle whose price table does not fit an XCD's L2: the lean scans go through the fp32 filter
+    // (wave_bid_filter); the mirror is rebuilt from the prices in front of the launch (12 bytes per object)
+    if (h->price32 && !h->round_small && variant != 2 && (long long)h->K_ub * 8 >= h->n_rows) {
+        HIP_TRY(hipMemsetAsync(h->pmax_bits, 0, sizeof(int), h->stream));
+        hipLaunchKernelGGL(k_price_mirror, dim3(blocks_for(h->n_cols, 256 * 4)), dim3(256), 0, h->stream, h->ctl, h->price,
+                           h->price32, h->n_cols, h->pmax_bits, h->thr, a.gather_max_K);
+        a.price32 = h->price32;
+    }
 #define MISSLAP_LAUNCH_BID(E, ED)                                                                                   \
     do {                                                                                                            \
         if (fused) MISSLAP_LAUNCH_TIMED(pr, (k_round_fused<E>), g, b, 0, h->stream, a, ED);                         \
@@ -1430,6 +1444,23 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
         DevBlock blk;
         blk.want(&h->price, Mpad);
         blk.want(&h->rec, M);
+        {
+            // the fp32 filter of the wave-per-row kernel's full scans: where that kernel does the full scans (no tile-major
+            // copy) and the fp64 price table exceeds an XCD's L2 share (>= 3 MB); costs of ordinary magnitude only (the
+            // error bound of the filter is relative: no subnormal fp32 values, no overflow of fl32(price)).
+            // MISSLAP_F32_FILTER=0 / 1: never / whatever the table's size (A/B timing, tests)
+            const char *fe = std::getenv("MISSLAP_F32_FILTER");  // (read per create: the tests switch it)
+            const int env = fe ? std::atoi(fe) : -1;
+            double max_abs_d;
+            const long long b = (long long)st.max_abs_bits;
+            std::memcpy(&max_abs_d, &b, sizeof(double));
+            const bool range_ok = max_abs_d > 0x1p-100 && max_abs_d < 0x1p60;
+            if (!h->tiled_ok && range_ok && env != 0 && (env == 1 || M * sizeof(double) >= ((size_t)3 << 20))) {
+                blk.want(&h->price32, M);
+                blk.want(&h->pmax_bits, 1);
+                h->cmax32 = (float)max_abs_d;
+            }
+        }
         h->line_maintenance = cand_mode != 2;
         if (cand_mode != 1) {  // candidate lines (cand_mode 1: off -- A/B timing, parity tests, the precision guard)
             blk.want(&h->cand, N * (size_t)kCandLanes);

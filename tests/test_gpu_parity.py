@@ -1364,6 +1364,36 @@ def test_sharded_solve_at_baseline_sizes_rank_threads_one_gpu(world, cfgs, golde
     _check_sharded_results(got, world, cfgs, golden_large)
 
 
+@pytest.mark.parametrize("cand", [True, False])
+@pytest.mark.parametrize("spec,prob,f64", [
+    (dict(kind="sparse", n=3000, m=3000, density=0.01), "max", False),
+    (dict(kind="sparse", n=2500, m=4000, density=0.01, ints=4), "max", False),  # ties at the top: the exact scan decides
+    (dict(kind="single", n=1500, density=0.02, n_single=40), "min", False),      # one-entry rows: +inf bids, infinite prices
+    (dict(kind="f64", n=2500, density=0.01), "min", True),                        # values that are not fp32-exact
+    (dict(kind="shuffled", n=2500, m=2500, density=0.012, ints=9), "max", False),
+])
+def test_f32_filter_scan_round_by_round(spec, prob, f64, cand, gpu_lib, monkeypatch):
+    """The wave-per-row kernel's full scans through the single-precision filter (wave_bid_filter: an fp32 mirror of the
+    prices decides WHICH two edges are evaluated exactly; ties and near-ties go to the exact scan), forced on a small
+    instance (the library uses it where the price table exceeds an XCD's L2 share: C5): full state vs the oracle."""
+    monkeypatch.setenv("MISSLAP_F32_FILTER", "1")
+    loc, val = cases.synth_inputs(spec)
+    for r in [1, 2, 3, 4, 6, 9, 14, 30, 70, 160]:
+        o = orc.from_sparse(loc, val.copy(), problem=prob, max_iter=r, cardinality_check=False)
+        o.solve()
+        so = o.state()
+        g = from_sparse(loc, val.copy(), problem=prob, max_iter=r, cardinality_check=False, tail_threshold=0,
+                        tiled_min_k=-1, cand=cand)
+        g.solve()
+        sg = g.state()
+        assert g.gpu["tiled_active"] == 0 and g.gpu["bytes_per_edge"] == (12 if f64 else 8)
+        assert sg["its"] == so["its"] and sg["K"] == so["K"], r
+        assert np.array_equal(sg["U"], so["U"]), r
+        assert np.array_equal(sg["p"].view(np.uint64), so["p"].view(np.uint64)), r
+        assert np.array_equal(sg["p2o"], so["p2o"]) and np.array_equal(sg["o2p"], so["o2p"]), r
+        assert g.gpu["edges_scanned"] == o.extra["edges_scanned"], r
+
+
 def test_row_shuffled_c2_keeps_the_engine_and_matches_the_oracle(gpu_lib):
     """C2 with the stored order of every row randomly permuted: the full-scan engine stays on (record format 2, stored
     index carried), the result equals the oracle's on the same arrays."""
