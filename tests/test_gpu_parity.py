@@ -963,7 +963,8 @@ def test_abi1_caller_is_still_served(gpu_lib):
 
     class MetaV1(C.Structure):
         _fields_ = [f for f in _lib.Meta._fields_[2:] if f[0] not in ("complete_assignment", "valid_assignment",
-                                                                     "lines_active", "reserved_i", "sharded_rounds")]
+                                                                     "lines_active", "reserved_i", "sharded_rounds", "tiled_format",
+                                                                     "phases_with_lines", "eps_phases", "reserved_j")]
     assert C.sizeof(OptionsV1) == 88 and C.sizeof(MetaV1) == 376
     loc, val = synth.gen_sparse(1200, 1200, 0.02, seed=3)
     ref = orc.auction_solve(loc=loc, val=val.copy(), problem="max", cardinality_check=False)

@@ -25,6 +25,13 @@
  * record in direct-mapped caches of 1024 .. 16384 records (index = object mod size); the hit rates are printed per
  * mode ("lds_sim").  The caches are write-through in the design they stand for, so a hit is a tag match.
  *
+ * In-wavefront speculation gate (round 5): with SIM_SPEC=1 every person remembers the RUNNER-UP object of its last bid.
+ * In the rounds with K <= 2 (the chain / duo rounds of the tail kernel) the model asks, per bidder: is the object it bids
+ * on now the remembered runner-up (then the next bidder -- the owner of that object -- could have been fetched and
+ * evaluated one round ahead), does that object have an owner at all (the chain goes on), and is the object among the
+ * three best of the owner's row at the OLD prices (then the owner's top-2 after the price update follow from its top-3
+ * and the one patched value).  Printed to stderr.
+ *
  * usage: auction_sim <input.bin> C policy build_thr use_thr
  *   input.bin: int64 nnz, int32 maximize, int32 loc[nnz][2], double val[nnz]
  *   build_thr: caches are (re)built on a miss in rounds with K <= build_thr
@@ -107,6 +114,12 @@ int main(int argc, char **argv) {
     const int f32_mode = getenv("SIM_F32") ? atoi(getenv("SIM_F32")) : 0;
     const int f32_min_K = (int)(0.3 * N);
     int64_t f32_hist[17] = {0}, f32_bids = 0, f32_round_over4 = 0;
+    const int spec_mode = getenv("SIM_SPEC") ? atoi(getenv("SIM_SPEC")) : 0;
+    int *ru_obj = malloc(sizeof(int) * N);
+    for (int i = 0; i < N; ++i) ru_obj[i] = -1;
+    /* [K - 1][.]: bids, with a remembered runner-up, prediction right, ... and the object has an owner (chain goes on),
+     * ... and the object is in the owner's top-3 at the old prices; rounds, rounds with EVERY bidder fully predicted */
+    int64_t sp[2][5] = {{0}}, sp_rounds[2] = {0}, sp_rounds_ok[2] = {0};
     FILE *trace = getenv("SIM_TRACE") ? fopen(getenv("SIM_TRACE"), "wb") : NULL;
     const int trace_thr = getenv("SIM_TRACE_THR") ? atoi(getenv("SIM_TRACE_THR")) : 256;
     for (;;) {
@@ -117,16 +130,40 @@ int main(int argc, char **argv) {
         }
         const int mode = K == 1 ? 0 : K == 2 ? 1 : K <= 16 ? 2 : K <= 64 ? 3 : K <= 512 ? 4 : K <= 2048 ? 5 : 6;
         const int use = K <= use_thr, build = K <= build_thr;
-        int round_hits = 0;
+        int round_hits = 0, round_full = 0;
         for (int n = 0; n < K; ++n) {
             const int i = U[n], s = row_ptr[i], e = row_ptr[i + 1];
             double vbest = -INFINITY, wi = -INFINITY, costbest = 0;
-            int jbest = 0;
+            int jbest = 0, jsecond = -1;
             for (int g = s; g < e; ++g) {
                 const double v = val[g] - p[col[g]];
-                if (v >= vbest || g == s) jbest = col[g], wi = vbest, vbest = v, costbest = val[g];
-                else if (v > wi) wi = v;
+                if (v >= vbest || g == s) jsecond = jbest, jbest = col[g], wi = vbest, vbest = v, costbest = val[g];
+                else if (v > wi) wi = v, jsecond = col[g];
             }
+            if (spec_mode && K <= 2) {
+                int64_t *c = sp[K - 1];
+                c[0]++;
+                int full = 0;
+                if (ru_obj[i] >= 0) {
+                    c[1]++;
+                    if (ru_obj[i] == jbest) {
+                        c[2]++;
+                        const int nb = o2p[jbest];
+                        if (nb >= 0) {
+                            c[3]++;
+                            /* rank of jbest in the owner's row at the old prices (ties count against it) */
+                            double vj = -INFINITY;
+                            for (int g = row_ptr[nb]; g < row_ptr[nb + 1]; ++g)
+                                if (col[g] == jbest) vj = val[g] - p[jbest];
+                            int above = 0;
+                            for (int g = row_ptr[nb]; g < row_ptr[nb + 1]; ++g) above += (val[g] - p[col[g]]) > vj;
+                            if (above <= 2) c[4]++, full = 1;
+                        }
+                    }
+                }
+                round_full += full;
+            }
+            if (spec_mode) ru_obj[i] = jsecond;
             if (f32_mode && K >= f32_min_K) { /* how many edges a single-precision filter could not tell from the top two */
                 float b32 = -INFINITY, w32 = -INFINITY;
                 double pmax = 0, vmax = 0;
@@ -238,6 +275,7 @@ int main(int argc, char **argv) {
             rounds[mode]++;
             allhit[mode] += round_hits == K;
         }
+        if (spec_mode && K <= 2) sp_rounds[K - 1]++, sp_rounds_ok[K - 1] += round_full == K;
         phase_rounds[mode]++;
         if (K <= 32) khist[K]++;
         /* resolve */
@@ -330,6 +368,15 @@ int main(int argc, char **argv) {
         for (int k = 2; k <= 16; ++k) fprintf(stderr, "%.5f ", (double)f32_hist[k] / (double)(f32_bids ? f32_bids : 1));
         fprintf(stderr, "; more than 4: %.5f\n", (double)f32_round_over4 / (double)(f32_bids ? f32_bids : 1));
     }
+    if (spec_mode)
+        for (int k = 0; k < 2; ++k)
+            fprintf(stderr, "speculation gate, rounds with K = %d: %lld rounds, %lld bids; runner-up remembered %.4f; the bid goes to the "
+                    "remembered runner-up %.4f; ... and that object has an owner (the chain goes on) %.4f; ... and it is among "
+                    "the owner's three best at the old prices %.4f; rounds in which EVERY bidder is fully predicted %.4f\n",
+                    k + 1, (long long)sp_rounds[k], (long long)sp[k][0], (double)sp[k][1] / (double)(sp[k][0] ? sp[k][0] : 1),
+                    (double)sp[k][2] / (double)(sp[k][0] ? sp[k][0] : 1), (double)sp[k][3] / (double)(sp[k][0] ? sp[k][0] : 1),
+                    (double)sp[k][4] / (double)(sp[k][0] ? sp[k][0] : 1),
+                    (double)sp_rounds_ok[k] / (double)(sp_rounds[k] ? sp_rounds[k] : 1));
     printf("],\n \"rounds_by_K\": [");
     for (int k = 1; k <= 32; ++k) printf("%s%lld", k > 1 ? ", " : "", (long long)khist[k]);
     printf("]}\n");
