@@ -589,6 +589,15 @@ __device__ __forceinline__ void tail_duo_mode(const TailArgs &a, const E &ed, in
     auto request = [&](int person) { slot = line_of<E>(a, person, l32); };
     request(w ? pi[1] : pi[0]);
     tail_barrier_lds();  // (sU / sStart have been read by both)
+#ifdef MISSLAP_TAIL_STAMP_DUO
+    // diagnostic build: cycles of wavefront 0 per segment of a duo round -> Ctl::dbg[6..11]: [6] wait for the line, [7]
+    // record gather, [8] winner known + next line requested, [9] rest of the evaluation (+ a missed person's scan),
+    // [10] bid to LDS + barrier (= the other wavefront), [11] exchange / resolve / both stores / re-request
+    unsigned long long sacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sprev = __builtin_amdgcn_s_memtime();
+    const CycleStamp stamp{sacc, &sprev, w == 0};
+#else
+    const NoStamp stamp;
+#endif
     int par = 0;
     for (;;) {
         const int me = w ? pi[1] : pi[0], mys = w ? ps[1] : ps[0];
@@ -600,7 +609,7 @@ __device__ __forceinline__ void tail_duo_mode(const TailArgs &a, const E &ed, in
         cand_eval1(slot, cls, src, eps, b, st.err, [&](const CandBid &x) {
             sp = x.prev;
             request(sp);  // the owner my bidder evicts if it wins
-        });
+        }, stamp);
         if (!b.hit) {
             const typename E::Raw none[4] = {};
             const int e = a.row_ptr[me + 1 + lane_zero()];
@@ -612,6 +621,7 @@ __device__ __forceinline__ void tail_duo_mode(const TailArgs &a, const E &ed, in
         }
         st.edges += (unsigned long long)b.len;
         st.bids += 1;
+        stamp.light(4);
         if (lane == 0) {
             dKey[par][w] = b.key;
             dObj[par][w] = b.obj;
@@ -619,6 +629,7 @@ __device__ __forceinline__ void tail_duo_mode(const TailArgs &a, const E &ed, in
             dPst[par][w] = b.pstart;
         }
         tail_barrier_lds();  // both bids are in LDS and both gathers of the round are done
+        stamp.light(5);
         const int o = w ^ 1;
         const unsigned long long okey = readlane_u64(dKey[par][o], 0);
         const int oobj = __builtin_amdgcn_readfirstlane(dObj[par][o]);
@@ -661,8 +672,13 @@ __device__ __forceinline__ void tail_duo_mode(const TailArgs &a, const E &ed, in
         // the early request assumed "my bidder wins, nobody moves"; otherwise request again
         if (!done && sp != (w ? pi[1] : pi[0])) request(w ? pi[1] : pi[0]);
         if (bd_person >= 0) tail_build(a, bd_person, bd, eps, st);
+        stamp.light(6);
         if (done) break;
     }
+#ifdef MISSLAP_TAIL_STAMP_DUO
+    if (w == 0 && lane == 0)
+        for (int k = 1; k <= 6; ++k) a.ctl->dbg[5 + k] += sacc[k];
+#endif
     if (w == 0 && lane == 0) {  // (both wavefronts hold the same list)
         sU[0] = pi[0];
         sU[1] = pi[1];

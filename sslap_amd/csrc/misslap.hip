@@ -376,7 +376,7 @@ MISSLAP_API int misslap_finish(misslap_solver *h, int32_t *person_to_object_out,
     for (int k = 0; k < 6; ++k) meta->tail_stats[k] = (double)c.dbg[k];  // tail: rounds / 10-ns ticks per mode
     for (int k = 0; k < 4; ++k) meta->tail_stats[6 + k] = (double)c.dbg[12 + k];  // bids, line hits, builds, hit edges
 #if defined(MISSLAP_TAIL_STAMP) || defined(MISSLAP_TAIL_STAMP_SOLO) || defined(MISSLAP_TAIL_STAMP_TEAM) || \
-    defined(MISSLAP_TAIL_STAMP_BLOCK) || defined(MISSLAP_TILED_STAMP)
+    defined(MISSLAP_TAIL_STAMP_BLOCK) || defined(MISSLAP_TILED_STAMP) || defined(MISSLAP_TAIL_STAMP_DUO)
     for (int k = 0; k < 6; ++k) meta->tail_stats[k] = (double)c.dbg[6 + k];  // diagnostic build: solo-round segments (cycles)
 #endif
     meta->cand_hits = c.cand_hits;
