@@ -167,13 +167,24 @@ BlockCache &block_cache() {
     return *c;
 }
 // a device block of at least `bytes` on the current device, from the cache if one fits; *got = its real size
+// MISSLAP_DEBUG_POISON=<byte> (debugging): every block handed out is filled with that byte first (0xFF: NaN / -1 patterns),
+// so that a read of device memory nobody has written shows up whatever the process has run before
 int block_alloc(void **p, size_t bytes, size_t *got) {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
+    static const int poison = [] {
+        const char *e = std::getenv("MISSLAP_DEBUG_POISON");
+        return e ? (int)std::strtol(e, nullptr, 0) : -1;
+    }();
     *p = block_cache().take(dev, bytes, got);
-    if (*p) return MISSLAP_OK;
-    HIP_TRY(hipMalloc(p, bytes));
-    *got = bytes;
+    if (!*p) {
+        HIP_TRY(hipMalloc(p, bytes));
+        *got = bytes;
+    }
+    if (poison >= 0) {
+        HIP_TRY(hipMemset(*p, poison & 0xff, *got));
+        HIP_TRY(hipDeviceSynchronize());
+    }
     return MISSLAP_OK;
 }
 void block_free(int device, void *p, size_t bytes) {

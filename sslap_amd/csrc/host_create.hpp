@@ -248,7 +248,12 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
                     if ((rc = blk.commit(&h->blocks.back()))) return rc;
                 }
                 HIP_TRY(hipMemsetAsync(h->ovf_q, 0, sizeof(int4), h->stream));  // (entry 0 is read by idle lanes)
-                const size_t tiled_words = ((size_t)total / 2 + 8) * (size_t)(rec_bytes / 4);  // + 16 entries of padding
+                // + kTilePadRecords ZEROED records behind the copy: the unconditional loads of a lane group reach up to
+                // lanes x loads-per-segment records past a segment's start whatever its length (16 x 2 = 32 for the widest
+                // shape); what a masked-off lane reads must be a FINITE value (its price is +inf, and NaN - inf would
+                // poison the running second-best through fmin), so the bytes behind the last segment are zeros, not
+                // whatever the block held before
+                const size_t tiled_words = ((size_t)total / 2 + kTilePadRecords) * (size_t)(rec_bytes / 4);
                 {
                     DevBlock blk;
                     blk.want(&h->tiled, tiled_words);

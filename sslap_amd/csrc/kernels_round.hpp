@@ -197,55 +197,6 @@ __device__ __forceinline__ void bid_positions(const RoundArgs &a, const E &ed, i
     }
 }
 
-// The same for the rounds ABOVE the lines' build regime (kLines = 1: lines used where they still answer, nothing
-// built) -- throughput rounds: a wavefront takes TWO list positions per pass, one line in each 32-lane half (cand_eval2
-// evaluates both with the instructions of one; the one-position form left half of every wavefront idle through the
-// line, the gather and the three reductions: C5's big rounds, where the maintenance pass keeps every line fresh and a
-// K = N launch is one line evaluation per person, 417 us per launch).  A position whose line does not decide is
-// scanned (through the fp32 filter where the handle has the mirror).
-template <class E>
-__device__ __forceinline__ void bid_positions_pairs(const RoundArgs &a, const E &ed, int lo, int hi, int first, int stride,
-                                                    int i_first, BidTally &tl) {
-    const int lane = threadIdx.x & 63;
-    const double eps = (double)a.eps;  // float promoted to double, auction_.pyx:360
-    const PriceSource src{a.price};
-    for (int n0 = lo + first; n0 < hi; n0 += 2 * stride) {
-        const int n1 = n0 + stride;
-        const bool act1 = n1 < hi;  // wave-uniform
-        int pi[2];
-        pi[0] = n0 == first ? i_first : a.U[n0];
-        pi[1] = a.U[act1 ? n1 : n0];
-        const int ime = lane < kCandLanes ? pi[0] : pi[1];
-        typename E::Slot sl = LineIO<typename E::Slot>::load(a.cand, a.cand64, (size_t)ime * kCandLanes + (lane & (kCandLanes - 1)));
-        CandBid b[2];
-        cand_eval2(sl, true, act1, src, eps, b, tl.err, NoEarly());
-#pragma unroll
-        for (int X = 0; X < 2; ++X) {
-            if (X == 1 && !act1) continue;  // wave-uniform
-            const int n = X ? n1 : n0;
-            if (!b[X].hit) {  // wave-uniform
-                const int s = a.row_ptr[pi[X]], e = a.row_ptr[pi[X] + 1];
-                if (a.price32 != nullptr) {
-                    const float two_delta = 0x1p-21f * (a.cmax + __int_as_float(*a.pmax_bits));
-                    wave_bid_filter(ed, a.price, a.price32, two_delta, s, e, eps, b[X], tl.err);
-                } else {
-                    wave_bid_lean(ed, src, s, e, eps, b[X], tl.err);
-                }
-            } else {
-                tl.nh += 1;
-                tl.hit_edges += (unsigned long long)b[X].len;
-            }
-            if (lane == 0) {
-                a.bid_key[n] = b[X].key;
-                a.bid_obj[n] = b[X].obj;
-                atomicMax(&a.best_key[b[X].obj], b[X].key);
-            }
-            tl.edges += (unsigned long long)b[X].len;
-            tl.nb += 1;
-        }
-    }
-}
-
 template <int kWaves>
 __device__ __forceinline__ void tally_flush(const RoundArgs &a, const BidTally &tl, int K) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -299,12 +250,7 @@ __global__ __launch_bounds__(kBidBlock) void k_bid(RoundArgs a, E ed) {
     int lo, hi;
     shard_range(head.K, a.rank, a.world, a.shard_min_K, lo, hi);
     BidTally tl;
-    if constexpr (kLines == 1 && E::kCand && !SrcOf<Src>::kOwners) {
-        if (a.cand != nullptr) bid_positions_pairs<E>(a, ed, lo, hi, first, gridDim.x * wpb, i_first, tl);  // (uniform over the launch)
-        else bid_positions<E, Src, kLines, false>(a, ed, lo, hi, first, gridDim.x * wpb, i_first, tl);
-    } else {
-        bid_positions<E, Src, kLines, false>(a, ed, lo, hi, first, gridDim.x * wpb, i_first, tl);
-    }
+    bid_positions<E, Src, kLines, false>(a, ed, lo, hi, first, gridDim.x * wpb, i_first, tl);
     tally_flush<kBidBlock / kWave>(a, tl, head.K);
 }
 

@@ -45,6 +45,7 @@ constexpr int kTileColsBig = 157 * 128;   // 20096 -> 160768 B, one workgroup pe
 constexpr int kTileColsHalf = 79 * 128;   // 10112 ->  80896 B, two workgroups per CU: one computes while the
                                           //                     other waits for its tile fill
 constexpr int kTileRB = 128;      // persons per layout block
+constexpr int kTilePadRecords = 64;  // zeroed two-edge records behind the tile-major copy (see host_create.hpp)
 // LDS behind the price buffers: statistics scratch of the epilogue (16 x 12 + 16 bytes), then ONE 256-byte scratch region
 // that every loader wavefront's L2 touches land in (an LDS-DMA load writes one dword slot per lane, LDS base + 4 * lane,
 // whatever its element size: 256 bytes per wavefront; the data is junk and never read, so the loaders share the region)
@@ -559,6 +560,7 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
     static_assert(kCS == 1 || kCS == 2 || kCS == 4, "column split: none, halves or quarters of the tiles");
     static_assert(MODE == 0 || (MODE == 1 && kCS == 1 && ABL == 0), "the check pass runs on the unsplit shapes");
     static_assert(kGL == 4 || kGL == 8 || kGL == 16, "lanes per person: 4, 8 or 16 (one DPP row at most)");
+    static_assert(kGL * kTileDepth <= kTilePadRecords, "masked-off lanes read at most that far behind the copy");
     constexpr int kTileGroups = (kTileThreads - kLoaders * kWave) / kGL;  // kGL-lane groups; loader wavefronts own none
     // LDS (in doubles): buffer 0 at [0, kTileCols), the +inf slot at kTileCols, buffer 1 at [kBufDoubles, ...).
     // A price slot must fit the 16-bit field of a packed edge: 2 * kTileCols + 128 < 65536.
@@ -720,8 +722,8 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
     };
     // Addresses are base (SGPR pair) + 32-bit unsigned BYTE offset (VGPR): the global_load "saddr" form, no
     // 64-bit address arithmetic per load (the host enables this kernel only while both tables are < 4 GiB).
-    // `tiled` is allocated with 16 spare entries, so the unconditional loads of masked-off lanes (at most 15
-    // entries past a segment start) need no clamp.
+    // `tiled` is followed by kTilePadRecords zeroed records, so the unconditional loads of masked-off lanes (at most
+    // kGL x kTileDepth records past a segment start) need no clamp and never see a non-finite value.
     auto load_seg = [&](int tile, int b, Seg &sg_) {
         const int tl = min(tile, T - 1);
 #pragma unroll

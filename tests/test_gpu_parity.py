@@ -790,7 +790,10 @@ def runtimes():
     }
     outs = {}
     for name, code in progs.items():
-        p = subprocess.run([sys.executable, "-c", common + code], capture_output=True, text=True, timeout=600)
+        try:
+            p = subprocess.run([sys.executable, "-X", "faulthandler", "-c", common + code], capture_output=True, text=True, timeout=240)
+        except subprocess.TimeoutExpired as ex:  # (say WHICH order hangs, and where)
+            raise AssertionError((name, "timed out", (ex.stdout or b"")[-300:], (ex.stderr or b"")[-1500:]))
         assert p.returncode == 0, (name, p.stdout[-300:], p.stderr[-600:])
         line = [l for l in p.stdout.splitlines() if l.startswith("OK")][-1]
         outs[name] = line
@@ -1393,6 +1396,54 @@ def test_f32_filter_scan_round_by_round(spec, prob, f64, cand, gpu_lib, monkeypa
         assert np.array_equal(sg["p"].view(np.uint64), so["p"].view(np.uint64)), r
         assert np.array_equal(sg["p2o"], so["p2o"]) and np.array_equal(sg["o2p"], so["o2p"]), r
         assert g.gpu["edges_scanned"] == o.extra["edges_scanned"], r
+
+
+def test_no_kernel_depends_on_what_a_device_block_held_before(gpu_lib):
+    """Device blocks come back from a cache, so whatever a kernel reads without anybody having written it is the
+    previous handle's data -- or, in a fresh process, zeros, which hides the bug.  A fresh interpreter with
+    MISSLAP_DEBUG_POISON=0xFF (every block handed out is filled with NaN / -1 patterns first) solves instances across the
+    engines: the full-scan engine in every record format with 4 / 8 / 16 lanes per person on SHORT segments (the masked-off
+    lanes of a wide lane group read far past a segment's end: the copy is followed by zeroed records for them), the
+    wave-per-row kernel with and without lines, the fp32 filter, the tail kernels, dense rows -- all against the oracle."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = f"""
+import sys
+for p in ({root!r}, {os.path.join(root, 'tests')!r}, {os.path.join(root, 'tests', 'golden')!r}):
+    sys.path.insert(0, p)
+import numpy as np
+import cases
+from oracle import oracle as orc
+from sslap_amd import from_sparse
+n = 0
+def check(spec, prob, **kw):
+    global n
+    loc, val = cases.synth_inputs(spec)
+    ref = orc.auction_solve(loc=loc, val=val.copy(), problem=prob, cardinality_check=False, max_iter=10**7)
+    s = from_sparse(loc, val.copy(), problem=prob, cardinality_check=False, max_iter=10**7, **kw)
+    sol = s.solve()
+    assert np.array_equal(sol, ref['sol']) and s.meta['its'] == ref['meta']['its'], (spec, kw)
+    assert s.gpu['obj_f64'] == ref['extra']['obj_f64'] and s.meta['eCE'] == ref['meta']['eCE'], (spec, kw)
+    n += 1
+short = dict(kind='sparse', n=6000, m=40000, density=0.001)
+for shape in (0, 8, 9):
+    for fmt in (0, 1, 2, 3):
+        spec = dict(short, kind='shuffled', ints=5) if fmt >= 2 else short
+        for thr in (0, None):
+            check(spec, 'max', tiled_min_k=1, engine=1, tiled_shape=shape, force_f64=bool(fmt & 1), tail_threshold=thr)
+check(dict(kind='sparse', n=4200, m=12000, density=0.01), 'max', tiled_min_k=1, engine=1, tiled_shape=4)
+for cand in (True, False):
+    check(dict(kind='sparse', n=3000, m=3000, density=0.01), 'min', tiled_min_k=-1, cand=cand)
+    check(dict(kind='f64', n=2500, density=0.01), 'max', tiled_min_k=-1, cand=cand, tail_threshold=0)
+check(dict(kind='dense', n=600, m=600), 'max')
+check(dict(kind='single', n=1500, density=0.02, n_single=40), 'min')
+print('OK', n)
+"""
+    env = dict(os.environ, MISSLAP_DEBUG_POISON="0xFF", MISSLAP_F32_FILTER="1")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0 and "OK 33" in p.stdout, (p.stdout[-300:], p.stderr[-1500:])
 
 
 def test_row_shuffled_c2_keeps_the_engine_and_matches_the_oracle(gpu_lib):
