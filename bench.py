@@ -472,15 +472,24 @@ def run_rank(args, rank, world, local_rank, ranks, comm, shared, backend):
         # kernel sources (sha256) and the commit it was measured on: any other code gets null, not a stale number.
         traffic, traffic_meta = None, {}
         import glob
-        tpaths = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_pmc_traffic_{args.config}.json")))
+        variant = args.config + {"f32": "", "f64": "_f64", "f32-as-f64": "_f32asf64"}[args.values] + ("_shuffled" if args.shuffle_rows else "")
+        tpaths = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_pmc_traffic_{variant}.json")))
         tpath = tpaths[-1] if tpaths else ""  # the newest round's measurement
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             traffic_meta = dict(traffic_commit=tj.get("commit"), traffic_source_sha256=tj.get("source_sha256"),
                                 traffic_file=os.path.relpath(tpath, ROOT))
-            # (the bid instance of the full-scan engine: its last template argument is MODE = 0; MODE 1 is the eCE pass)
-            tk = [(k, v) for k, v in sorted(tj["kernels"].items())
-                  if (rk_name + "<") in k and not (rk_name == "k_bid_tiled" and not k.rstrip().endswith(", 0>"))]
+            # (the bid instance of the full-scan engine: template arguments <..., MODE, kFmt> with MODE = 0; MODE 1 is the
+            # eCE pass.  The gather engine: the instance with the most bytes, i.e. the one that does the full scans)
+            def is_bid_instance(k):
+                if (rk_name + "<") not in k:
+                    return False
+                if rk_name != "k_bid_tiled":
+                    return True
+                targs = k[k.index("<") + 1:k.rindex(">")].split(",")
+                return len(targs) >= 2 and targs[-2].strip() == "0"
+            tk = sorted(((k, v) for k, v in tj["kernels"].items() if is_bid_instance(k)),
+                        key=lambda kv: -(kv[1]["read_avg"] + kv[1]["write_avg"]) * kv[1]["launches"])
             if tk and tj.get("source_sha256") == source_digest():
                 traffic = round(tk[0][1]["read_avg"] + tk[0][1]["write_avg"])
                 traffic_meta["traffic_kernel"] = tk[0][0]

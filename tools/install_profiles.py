@@ -10,7 +10,7 @@ src, rnd, what = os.path.join(ROOT, "gpurun_out", sys.argv[1]), sys.argv[2], sys
 sha = source_digest()
 commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "HEAD"], text=True).strip()
 dirty = subprocess.run(["git", "-C", ROOT, "diff", "--quiet", "HEAD", "--", "sslap_amd/csrc"]).returncode != 0
-for c in ("C1", "C2", "C3", "C4", "C5", "D1"):
+for c in ("C1", "C2", "C3", "C4", "C5", "D1", "C2_f64", "C3_f64", "C4_f64", "C2_shuffled", "C3_f32asf64"):
     p = os.path.join(src, f"pmc_traffic_{c}.json")
     if "pmc" in what and os.path.exists(p):
         d = json.load(open(p))

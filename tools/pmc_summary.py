@@ -43,11 +43,13 @@ for k in sorted(set(fetch) | set(write)):
         launches=len(f), read_avg=sum(f) / len(f) * 1024 * 2, read_max=max(f) * 1024 * 2,
         write_avg=sum(w) / len(w) * 1024, write_max=max(w) * 1024)
 cal = out["kernels"]
-out["calibration"] = {
-    "k_ingest_vals_read_over_known": cal["misslap::k_ingest_vals"]["read_avg"] / (nnz * 8.0),
-    "k_build_edges_f32_read_over_known": cal["misslap::k_build_edges_f32"]["read_avg"] / (nnz * 16.0),
-    "k_build_edges_f32_write_over_known": cal["misslap::k_build_edges_f32"]["write_avg"] / (nnz * 8.0),
-}
+out["calibration"] = {"k_ingest_vals_read_over_known": cal["misslap::k_ingest_vals"]["read_avg"] / (nnz * 8.0)}
+if "misslap::k_build_edges_f32" in cal:  # 8 B/edge layout: reads 16 B, writes 8 B per entry
+    out["calibration"]["k_build_edges_f32_read_over_known"] = cal["misslap::k_build_edges_f32"]["read_avg"] / (nnz * 16.0)
+    out["calibration"]["k_build_edges_f32_write_over_known"] = cal["misslap::k_build_edges_f32"]["write_avg"] / (nnz * 8.0)
+if "misslap::k_build_edges_f64" in cal:  # 12 B/edge layout: reads 16 B, writes 12 B per entry
+    out["calibration"]["k_build_edges_f64_read_over_known"] = cal["misslap::k_build_edges_f64"]["read_avg"] / (nnz * 16.0)
+    out["calibration"]["k_build_edges_f64_write_over_known"] = cal["misslap::k_build_edges_f64"]["write_avg"] / (nnz * 12.0)
 json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
 for k, v in out["kernels"].items():
     if v["read_avg"] + v["write_avg"] > 1e6:
