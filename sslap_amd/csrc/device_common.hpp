@@ -768,8 +768,9 @@ __device__ __forceinline__ void wave_bid_filter(const E &ed, const double *price
                                                 const int s, const int e, const double eps, CandBid &out, int &err) {
     const int lane = lane_id();
     const float ninf = -__builtin_huge_valf();
-    float t1 = ninf, t2 = ninf, t3 = ninf;  // the lane's three largest a, and the stored indices of the first two
-    int g1 = -1, g2 = -1;
+    float t1 = ninf, t2 = ninf, t3 = ninf;  // the lane's three largest a, and stored index / column / cost of the first two
+    int g1 = -1, g2 = -1, k1 = 0, k2 = 0;
+    double a1 = 0.0, a2 = 0.0;
     for (int base = s; base < e; base += 2 * kWave) {
         int c[2];
         double a[2];
@@ -785,8 +786,12 @@ __device__ __forceinline__ void wave_bid_filter(const E &ed, const double *price
             const bool b1 = v > t1, b2 = v > t2, b3 = v > t3;
             t3 = b2 ? t2 : (b3 ? v : t3);
             g2 = b1 ? g1 : (b2 ? g : g2);
+            k2 = b1 ? k1 : (b2 ? c[u] : k2);
+            a2 = b1 ? a1 : (b2 ? a[u] : a2);
             t2 = b1 ? t1 : (b2 ? v : t2);
             g1 = b1 ? g : g1;
+            k1 = b1 ? c[u] : k1;
+            a1 = b1 ? a[u] : a1;
             t1 = b1 ? v : t1;
         }
     }
@@ -812,12 +817,12 @@ __device__ __forceinline__ void wave_bid_filter(const E &ed, const double *price
         wave_bid_lean(ed, PriceSource{price}, s, e, eps, out, err);
         return;
     }
-    const int e1 = __builtin_amdgcn_readlane(g1, L1);
-    const int e2 = L2 == L1 ? __builtin_amdgcn_readlane(g2, L1) : __builtin_amdgcn_readlane(g1, L2);
-    int col1, col2;
-    double cost1, cost2;
-    ed.load(e1, col1, cost1);  // (wave-uniform addresses; the lines were streamed a moment ago)
-    ed.load(e2, col2, cost2);
+    // the two edges, from the registers of the lanes that hold them (no second look at the row)
+    const bool same = L2 == L1;
+    const int e1 = __builtin_amdgcn_readlane(g1, L1), col1 = __builtin_amdgcn_readlane(k1, L1);
+    const int e2 = same ? __builtin_amdgcn_readlane(g2, L1) : __builtin_amdgcn_readlane(g1, L2);
+    const int col2 = same ? __builtin_amdgcn_readlane(k2, L1) : __builtin_amdgcn_readlane(k1, L2);
+    const double cost1 = readlane_f64(a1, L1), cost2 = same ? readlane_f64(a2, L1) : readlane_f64(a1, L2);
     const double v1 = cost1 - price[col1], v2 = cost2 - price[col2];  // vi = cost - p[j]   (:350), exact
     const bool second = (v2 > v1) | ((v2 == v1) & (e2 > e1));        // :351: the later stored index among equals
     const double cost = second ? cost2 : cost1, w = second ? v1 : v2;

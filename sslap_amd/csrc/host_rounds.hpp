@@ -326,7 +326,7 @@ int launch_bid(misslap_solver *h) {
     // (wave_bid_filter); the mirror is rebuilt from the prices in front of the launch (12 bytes per object)
     if (h->price32 && !h->round_small && variant != 2 && (long long)h->K_ub * 8 >= h->n_rows) {
         HIP_TRY(hipMemsetAsync(h->pmax_bits, 0, sizeof(int), h->stream));
-        hipLaunchKernelGGL(k_price_mirror, dim3(blocks_for(h->n_cols, 256 * 4)), dim3(256), 0, h->stream, h->ctl, h->price,
+        hipLaunchKernelGGL(k_price_mirror, dim3(std::min(blocks_for(h->n_cols, 1024 * 4), h->n_cus)), dim3(1024), 0, h->stream, h->ctl, h->price,
                            h->price32, h->n_cols, h->pmax_bits, h->thr, a.gather_max_K);
         a.price32 = h->price32;
     }

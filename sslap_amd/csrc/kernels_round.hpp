@@ -256,9 +256,10 @@ __global__ __launch_bounds__(kBidBlock) void k_bid(RoundArgs a, E ed) {
 
 // The fp32 mirror of the prices for wave_bid_filter, and the largest price (bit pattern: prices are >= 0, so the patterns
 // order like integers; *pmax_bits is zeroed by the host in front of the launch).  Only in a live round that k_bid serves.
-__global__ __launch_bounds__(256) void k_price_mirror(const Ctl *ctl, const double *price, float *price32, int n_cols,
-                                                      int *pmax_bits, int thr, int gather_max_K) {
+__global__ __launch_bounds__(1024) void k_price_mirror(const Ctl *ctl, const double *price, float *price32, int n_cols,
+                                                       int *pmax_bits, int thr, int gather_max_K) {
     if (!round_live(ctl, thr) || (gather_max_K > 0 && ctl->K >= gather_max_K)) return;
+    __shared__ int s_w[16];
     float m = 0.f;
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n_cols; j += gridDim.x * blockDim.x) {
         const float p = (float)price[j];  // round to nearest
@@ -267,7 +268,12 @@ __global__ __launch_bounds__(256) void k_price_mirror(const Ctl *ctl, const doub
     }
     int b = __float_as_int(m);
     for (int off = 32; off >= 1; off >>= 1) b = max(b, __shfl_xor(b, off));
-    if ((threadIdx.x & 63) == 0 && b > 0) atomicMax(pmax_bits, b);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = b;
+    __syncthreads();
+    if (threadIdx.x == 0) {  // ONE atomic per workgroup: same-address atomics retire one after the other, ~5.5 ns each
+        for (int w = 1; w < (int)blockDim.x / kWave; ++w) b = max(b, s_w[w]);
+        if (b > 0) atomicMax(pmax_bits, b);
+    }
 }
 
 // Line maintenance ahead of the tail kernels (once per eps-phase, when K has fallen to the tail threshold).  The grid

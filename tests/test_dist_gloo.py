@@ -194,3 +194,46 @@ def test_comm_argument_validation(built_lib):
     assert lib.misslap_comm_init_custom(C.byref(h), C.byref(ops)) == _lib.ERR_INVALID  # struct_size / callbacks unset
     assert lib.misslap_drive_sharded(None, None) == _lib.ERR_INVALID
     assert lib.misslap_comm_destroy(None) == _lib.MISSLAP_OK
+
+
+def test_thread_group_collectives():
+    """sslap_amd.dist.ThreadGroup (the ranks of an in-process rehearsal are threads): barrier, all-gather and all-reduce
+    give every rank the same result in rank order; a rank that fails breaks the barrier instead of hanging the others."""
+    import threading
+    from sslap_amd.dist import ThreadGroup
+    W = 8
+    g = ThreadGroup(W, timeout_s=30.0)
+    out = [None] * W
+
+    def rank_main(r):
+        got = []
+        for it in range(50):
+            a = np.arange(16, dtype=np.int64) * (r + 1) + it
+            got.append((g.all_reduce(r, a, "max").tolist(), g.all_reduce(r, a.astype(np.int32), "min").tolist(),
+                        g.all_gather(r, (r, it)), int(g.all_reduce(r, np.int64(r + it), "sum"))))
+            g.barrier()
+        out[r] = got
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(W)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(60)
+    assert all(o == out[0] for o in out) and len(out[0]) == 50
+    mx, mn, gathered, sm = out[0][3]
+    assert mx == (np.arange(16) * W + 3).tolist() and mn == (np.arange(16) + 3).tolist()
+    assert gathered == [(r, 3) for r in range(W)] and sm == sum(r + 3 for r in range(W))
+    # a failing rank: the others raise BrokenBarrierError within the timeout instead of waiting for ever
+    g2 = ThreadGroup(2, timeout_s=5.0)
+    res = []
+
+    def waiter():
+        try:
+            g2.barrier()
+            res.append("passed")
+        except threading.BrokenBarrierError:
+            res.append("broken")
+    t = threading.Thread(target=waiter)
+    t.start()
+    g2.abort()
+    t.join(10)
+    assert res == ["broken"]

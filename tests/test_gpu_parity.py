@@ -791,7 +791,7 @@ def runtimes():
     outs = {}
     for name, code in progs.items():
         try:
-            p = subprocess.run([sys.executable, "-X", "faulthandler", "-c", common + code], capture_output=True, text=True, timeout=240)
+            p = subprocess.run([sys.executable, "-X", "faulthandler", "-c", common + code], capture_output=True, text=True, timeout=150)
         except subprocess.TimeoutExpired as ex:  # (say WHICH order hangs, and where)
             raise AssertionError((name, "timed out", (ex.stdout or b"")[-300:], (ex.stderr or b"")[-1500:]))
         assert p.returncode == 0, (name, p.stdout[-300:], p.stderr[-600:])

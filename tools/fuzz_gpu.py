@@ -31,6 +31,12 @@ for seed in range(first, first + count):
     loc, val = synth.gen_sparse(n, m, density, seed=900 + seed, integer_values=ints)
     if seed % 3 == 2:  # values that are not fp32-exact: the 12 B/edge layout (lines with fp64 cost lines)
         val = val + r.random(val.shape[0]) * 1e-7
+    # round 5: rows in a random stored order (the engine's record formats 2 / 3: stored index carried); costs scaled up so
+    # that the last eps-phases fall below the rounding bound of a price update (candidate lines dropped mid-solve)
+    if (seed // 2) % 4 == 1:
+        loc, val = synth.shuffle_within_rows(loc, val, seed)
+    if seed % 11 == 7:
+        val = np.round(val * float(r.choice([1e6, 1e8, 1e9])))
     kw = dict(problem=prob, cardinality_check=False, max_iter=int(r.choice([10**8, 10**8, 10**8, 3000, 211, 17])),
               eps_start=float(r.choice([0.0, 0.0, 1.0, 0.01])))
     gpu = dict(tail_threshold=[None, 0, 3, 17, 40, 200, 512][seed % 7], tiled_min_k=[None, None, 1, -1][seed % 4],
@@ -40,6 +46,10 @@ for seed in range(first, first + count):
     if gpu["tiled_min_k"] == 1:
         gpu["engine"] = 1  # build the tile-major copy whatever the size
         gpu["tiled_shape"] = [None, 4, 8, 9, 7][(seed // 4) % 5]  # launch shape (4: the column split, merge fused into the scan)
+    if seed % 7 == 3 and seed % 3 != 2:
+        gpu["force_f64"] = True  # fp32-exact values in the 12 B/edge layout: the engine's fp64 record formats
+    # the fp32 filter of the wave-per-row kernel's big rounds (read per create), forced whatever the table's size
+    os.environ["MISSLAP_F32_FILTER"] = "1" if seed % 4 == 1 else "-1"
     gpu = {k: v for k, v in gpu.items() if v is not None}
     o = orc.from_sparse(loc, val.copy(), **kw)
     osol = o.solve()
