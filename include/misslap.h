@@ -360,6 +360,26 @@ int misslap_trim_caches(int64_t *freed_bytes);
  * time: 4 GB per solve in flight); one that must not lose HBM to the library lowers them. */
 int misslap_set_cache_limits(int64_t max_total_bytes, int64_t max_block_bytes, int32_t max_blocks);
 
+/* ---- many independent problems at a time (round 5; no counterpart in the reference, whose own harness solves its
+ * problems in a loop: benchmarking.py:84-142).  During ~90 % of a solve one problem occupies ONE of the GPU's 256 compute
+ * units, and a GPU fed from many queues retires only ~90 000 launches per second over all of them, so solves issued from
+ * many host threads stall at 6-8x the single-solve throughput.  misslap_solve_batch solves the n handles in LOCKSTEP:
+ * groups of `group_size` problems (0 = default, 12) share one HIP stream and every launch of the solve loop that several of
+ * them issue at the same point is ONE launch (csrc/host_batch.hpp).  Each handle goes through exactly the sequence of
+ * kernels misslap_solve would have launched for it: person_to_object_out[k] / meta_out[k] are what misslap_solve(handles[k])
+ * returns, bit for bit.  The handles must be unsolved, unsharded, unprofiled, on one device, and of ONE shape (n_rows x
+ * n_cols; the entries may differ).  meta_out: an array of n structs with struct_size set (may be NULL, like the output
+ * pointers); *info (may be NULL) says how many launches went out for how many recorded. */
+typedef struct misslap_batch_info {
+    int32_t groups;            /* streams / host threads used */
+    int32_t reserved;
+    int64_t calls_recorded;    /* launches + asynchronous copies / fills the n solve loops asked for */
+    int64_t launches_issued;   /* ... and what went onto the streams after merging */
+    double wall_ms;
+} misslap_batch_info;
+int misslap_solve_batch(misslap_solver *const *handles, int32_t n, int32_t *const *person_to_object_out,
+                        misslap_meta *meta_out, int32_t group_size, misslap_batch_info *info);
+
 const char *misslap_last_error(void);
 int misslap_abi_version(void);
 

@@ -51,6 +51,11 @@ class Meta(C.Structure):
     ]
 
 
+class BatchInfo(C.Structure):
+    _fields_ = [("groups", C.c_int32), ("reserved", C.c_int32), ("calls_recorded", C.c_int64),
+                ("launches_issued", C.c_int64), ("wall_ms", C.c_double)]
+
+
 def new_meta():
     m = Meta()
     m.struct_size = C.sizeof(Meta)
@@ -100,6 +105,8 @@ SYMBOLS = {
     "misslap_destroy": (C.c_int, [_VP]),
     "misslap_dims": (C.c_int, [_VP, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "misslap_solve": (C.c_int, [_VP, _VP, C.POINTER(Meta)]),
+    "misslap_solve_batch": (C.c_int, [C.POINTER(_VP), C.c_int32, C.POINTER(_VP), C.POINTER(Meta), C.c_int32,
+                                      C.POINTER(BatchInfo)]),
     "misslap_round_bid": (C.c_int, [_VP]),
     "misslap_round_tiebreak": (C.c_int, [_VP]),
     "misslap_round_apply": (C.c_int, [_VP]),

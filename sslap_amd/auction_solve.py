@@ -171,6 +171,27 @@ class AuctionSolver:
         self._fill_meta(meta)
         return sol
 
+    @staticmethod
+    def solve_batch(solvers, group_size=0):
+        """Solve many independent problems of ONE shape in lockstep (misslap_solve_batch: the problems of a group share a
+        HIP stream and every launch of the solve loop that several of them issue at the same point is one launch).  Every
+        solver ends up exactly as after its own `.solve()` -- same assignment, same meta, bit for bit.  Returns
+        (list of person_to_object arrays, info dict: groups, calls_recorded, launches_issued, wall_ms)."""
+        lib = _lib.load()
+        n = len(solvers)
+        sols = [np.empty(s.num_rows, dtype=np.int32) for s in solvers]
+        handles = (C.c_void_p * n)(*[s._h for s in solvers])
+        outs = (C.c_void_p * n)(*[a.ctypes.data for a in sols])
+        metas = (_lib.Meta * n)()
+        for m in metas:
+            m.struct_size = C.sizeof(_lib.Meta)
+        info = _lib.BatchInfo()
+        _lib.check(lib.misslap_solve_batch(handles, n, outs, metas, int(group_size), C.byref(info)))
+        for s, m in zip(solvers, metas):
+            s._fill_meta(m)
+        return sols, dict(groups=int(info.groups), calls_recorded=int(info.calls_recorded),
+                          launches_issued=int(info.launches_issued), wall_ms=float(info.wall_ms))
+
     def solve_sharded(self, comm=None):
         """The same solve over the ranks of a communicator (sslap_amd.dist.Comm): persons of the big rounds sharded,
         per-object arg-max exchanged on the solver's stream inside the library (misslap_solve_sharded)."""

@@ -8,7 +8,8 @@ CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libmisslap.so")
 LIB_DIAG = os.path.join(PKG, "libmisslap_diag.so")  # diagnostics build (-DMISSLAP_DIAG), tools/ only
 SOURCES = ["misslap.hip", "device_common.hpp", "kernels_round.hpp", "kernels_tail.hpp", "kernels_check.hpp", "kernels_debug.hpp", "kernels_tiled.hpp", "host_comm.hpp", "kernels_matching.hpp",
-           "kernels_ingest.hpp", "host_matching.hpp", "abi_v1.hpp", os.path.join("..", "..", "include", "misslap.h")]
+           "kernels_ingest.hpp", "host_matching.hpp", "abi_v1.hpp", "host_base.hpp", "host_batch.hpp", "host_cache.hpp", "host_rounds.hpp", "host_create.hpp",
+           "abi_matching.hpp", "abi_util.hpp", "abi_comm.hpp", "abi_batch.hpp", "abi_diag.hpp", os.path.join("..", "..", "include", "misslap.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-honor-nans", "-std=c++17", "-shared", "-fPIC",
          "-fvisibility=hidden", "-Wall", "-Wextra"]
 

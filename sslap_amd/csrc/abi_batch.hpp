@@ -1,0 +1,188 @@
+// abi_batch.hpp -- C ABI: misslap_solve_batch, many independent problems in lockstep (the mechanism: host_batch.hpp).
+// (part of the single translation unit misslap.hip; included in the order given there)
+#pragma once
+
+namespace {
+
+constexpr size_t kBatchFiberStack = 512 * 1024;
+
+// what a fiber runs: the ordinary solve of its handle (the loop of host_comm.hpp without a communicator, then
+// misslap_finish), with every launch recorded instead of issued
+void batch_fiber_main(unsigned lo, unsigned hi) {
+    BatchFiber *f = reinterpret_cast<BatchFiber *>(((uintptr_t)hi << 32) | (uintptr_t)lo);
+    f->rc = misslap_solve_sharded(f->h, nullptr, f->sol, f->meta);
+    if (f->rc) f->err = g_err;
+    f->state = BatchFiber::kDone;
+    swapcontext(&f->ctx, &f->grp->sched);  // (never resumed)
+}
+
+// issue what the fibers of the group have recorded: the heads of all pending lists at a time, equal kernels as one launch
+void batch_flush(BatchGroup &g) {
+    std::vector<size_t> at(g.fibers.size(), 0);
+    std::vector<BatchCall *> heads, same;
+    for (;;) {
+        heads.clear();
+        for (size_t k = 0; k < g.fibers.size(); ++k) {
+            BatchFiber &f = *g.fibers[k];
+            if (at[k] < f.pending.size()) heads.push_back(&f.pending[at[k]++]);
+        }
+        if (heads.empty()) break;
+        g.launches_merged += (long long)heads.size();
+        std::vector<bool> done(heads.size(), false);
+        for (size_t a = 0; a < heads.size(); ++a) {
+            if (done[a]) continue;
+            BatchCall *c = heads[a];
+            if (!c->merge) {
+                c->single(g.stream);
+                g.launches_issued += 1;
+                continue;
+            }
+            same.clear();
+            for (size_t b = a; b < heads.size(); ++b)
+                if (!done[b] && heads[b]->merge == c->merge && heads[b]->block.x == c->block.x) {
+                    same.push_back(heads[b]);
+                    done[b] = true;
+                }
+            c->merge(g.stream, same.data(), (int)same.size());
+            g.launches_issued += 1;
+        }
+    }
+    for (auto &f : g.fibers) f->pending.clear();
+}
+
+// one group: its handles' solves on fibers of this thread, one stream
+int batch_run_group(BatchGroup &g, int device) {
+    if (hipSetDevice(device) != hipSuccess) return fail(MISSLAP_ERR_HIP, "hipSetDevice failed");
+    if (hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking) != hipSuccess) return fail(MISSLAP_ERR_HIP, "hipStreamCreate failed");
+    for (auto &fp : g.fibers) {
+        BatchFiber &f = *fp;
+        f.grp = &g;
+        f.stack.reset(new char[kBatchFiberStack]);
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = f.stack.get();
+        f.ctx.uc_stack.ss_size = kBatchFiberStack;
+        f.ctx.uc_link = &g.sched;
+        const uintptr_t p = reinterpret_cast<uintptr_t>(&f);
+        makecontext(&f.ctx, reinterpret_cast<void (*)()>(batch_fiber_main), 2, (unsigned)(p & 0xffffffffu), (unsigned)(p >> 32));
+        f.own_stream = f.h->stream;
+        f.own_own_stream = f.h->own_stream;
+        f.h->stream = g.stream;  // (everything of the handle's earlier life on its own stream has completed: create drains it)
+        f.h->batch = &f;
+        f.state = BatchFiber::kRunnable;
+    }
+    const double t_end = now_ms() + 3600e3;
+    int rc = MISSLAP_OK;
+    for (;;) {
+        bool all_done = true, recorded = false;
+        for (auto &fp : g.fibers) {
+            BatchFiber &f = *fp;
+            if (f.state == BatchFiber::kDone || f.state == BatchFiber::kWantsSync) {
+                all_done = all_done && f.state == BatchFiber::kDone;
+                continue;
+            }
+            all_done = false;
+            swapcontext(&g.sched, &f.ctx);  // runs the fiber until it needs the device (or ends)
+            recorded = recorded || !f.pending.empty();
+        }
+        bool want_sync = false;
+        for (auto &fp : g.fibers) {
+            want_sync = want_sync || fp->state == BatchFiber::kWantsSync;
+            recorded = recorded || !fp->pending.empty();
+        }
+        if (recorded) batch_flush(g);
+        if (want_sync) {
+            if (hipStreamSynchronize(g.stream) != hipSuccess) {
+                rc = fail(MISSLAP_ERR_HIP, "hipStreamSynchronize failed inside a batched solve: %s", hipGetErrorString(hipGetLastError()));
+                break;
+            }
+            for (auto &fp : g.fibers)
+                if (fp->state == BatchFiber::kWantsSync) fp->state = BatchFiber::kRunnable;
+        }
+        if (all_done) break;
+        if (!recorded && !want_sync) {  // everybody is waiting for a status word
+            __builtin_ia32_pause();
+            if (now_ms() > t_end) {
+                rc = fail(MISSLAP_ERR_STATE, "batched solve timed out");
+                break;
+            }
+        }
+    }
+    (void)hipStreamSynchronize(g.stream);
+    for (auto &fp : g.fibers) {
+        BatchFiber &f = *fp;
+        f.h->batch = nullptr;
+        f.h->stream = f.own_stream;
+        f.h->own_stream = f.own_own_stream;
+        if (!rc && f.state != BatchFiber::kDone) rc = fail(MISSLAP_ERR_STATE, "a batched solve did not finish");
+        if (!rc && f.rc) rc = fail(f.rc, "%s", f.err.c_str());
+    }
+    (void)hipStreamDestroy(g.stream);
+    g.stream = nullptr;
+    return rc;
+}
+
+}  // namespace
+
+MISSLAP_API int misslap_solve_batch(misslap_solver *const *handles, int32_t n, int32_t *const *person_to_object_out,
+                                    misslap_meta *meta_out, int32_t group_size, misslap_batch_info *info) {
+    if (!handles || n <= 0) return fail(MISSLAP_ERR_INVALID, "bad argument");
+    if (group_size <= 0) group_size = 12;  // (what one kernel-argument block carries of the widest launch, host_batch.hpp)
+    const int device = handles[0]->device;
+    for (int k = 0; k < n; ++k) {
+        const misslap_solver *h = handles[k];
+        if (!h) return fail(MISSLAP_ERR_INVALID, "null handle in the batch");
+        if (h->device != device) return fail(MISSLAP_ERR_INVALID, "the handles of a batch live on one device");
+        if (h->world != 1) return fail(MISSLAP_ERR_INVALID, "sharded handles cannot be batched");
+        if (h->profile) return fail(MISSLAP_ERR_INVALID, "profiled handles (options.profile) cannot be batched");
+        if (h->live_off) return fail(MISSLAP_ERR_STATE, "a batched solve needs the live status words (MISSLAP_LIVE_STATUS=0 is set, or they failed)");
+        if (h->n_rows != handles[0]->n_rows || h->n_cols != handles[0]->n_cols)
+            return fail(MISSLAP_ERR_INVALID, "the problems of a batch have the same shape (%d x %d here, %d x %d in handle %d): merged "
+                        "launches run on the largest grid", handles[0]->n_rows, handles[0]->n_cols, h->n_rows, h->n_cols, k);
+        for (int j = 0; j < k; ++j)
+            if (handles[j] == h) return fail(MISSLAP_ERR_INVALID, "handle %d appears twice in the batch", k);
+        if (meta_out && h->abi >= 2 && (meta_out[k].struct_size < (int32_t)offsetof(misslap_meta, edges_scanned) || meta_out[k].struct_size > 65536))
+            return fail(MISSLAP_ERR_INVALID, "misslap_meta[%d].struct_size = %d: set it to sizeof(misslap_meta) before the call", k, meta_out[k].struct_size);
+    }
+    const double t0 = now_ms();
+    const int n_groups = (n + group_size - 1) / group_size;
+    std::vector<std::unique_ptr<BatchGroup>> groups;
+    for (int gi = 0; gi < n_groups; ++gi) {
+        groups.emplace_back(new BatchGroup());
+        for (int k = gi * group_size; k < std::min(n, (gi + 1) * group_size); ++k) {
+            std::unique_ptr<BatchFiber> f(new BatchFiber());
+            f->h = handles[k];
+            f->sol = person_to_object_out ? person_to_object_out[k] : nullptr;
+            f->meta = meta_out ? &meta_out[k] : nullptr;
+            groups.back()->fibers.push_back(std::move(f));
+        }
+    }
+    // one host thread and one stream per group: the groups overlap on the GPU (their tail kernels are one workgroup per
+    // problem), the problems of a group share every launch
+    std::vector<int> rcs((size_t)n_groups, MISSLAP_OK);
+    std::vector<std::string> errs((size_t)n_groups);
+    if (n_groups == 1) {
+        rcs[0] = batch_run_group(*groups[0], device);
+        if (rcs[0]) errs[0] = g_err;
+    } else {
+        std::vector<std::thread> th;
+        for (int gi = 0; gi < n_groups; ++gi)
+            th.emplace_back([&, gi] {
+                rcs[(size_t)gi] = batch_run_group(*groups[(size_t)gi], device);
+                if (rcs[(size_t)gi]) errs[(size_t)gi] = g_err;  // (thread-local: carried back by hand)
+            });
+        for (auto &t : th) t.join();
+    }
+    if (info) {
+        info->groups = n_groups;
+        info->calls_recorded = 0;
+        info->launches_issued = 0;
+        for (auto &g : groups) {
+            info->calls_recorded += g->launches_merged;
+            info->launches_issued += g->launches_issued;
+        }
+        info->wall_ms = now_ms() - t0;
+    }
+    for (int gi = 0; gi < n_groups; ++gi)
+        if (rcs[(size_t)gi]) return fail(rcs[(size_t)gi], "%s", errs[(size_t)gi].c_str());
+    return MISSLAP_OK;
+}

@@ -134,7 +134,7 @@ MISSLAP_API int misslap_solve_sharded(misslap_solver *h, misslap_comm *comm, int
     int rc = drive_sharded(&o, comm, fail);
     h->sharded_rounds = comm ? comm->sharded_rounds : 0;
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(stream_sync(h));
     h->solve_ms += now_ms() - t0;
     return misslap_finish(h, person_to_object_out, meta);
 }

@@ -157,7 +157,11 @@ int block_alloc(void **p, size_t bytes, size_t *got);
 void block_free(int device, void *p, size_t bytes);
 }  // namespace
 
+namespace {
+struct BatchFiber;  // host_batch.hpp
+}
 struct misslap_solver {
+    BatchFiber *batch = nullptr;  // inside misslap_solve_batch: the fiber this handle's solve loop runs on (its launches are recorded)
     int abi = MISSLAP_ABI_VERSION;  // 1: created with version-1 options (88 bytes) -> version-1 misslap_meta layout
     int n_cus = 256;                // compute units of the device (one k_bid_tiled workgroup per CU)
     // Candidate lines are exact only while prices never fall (device_common.hpp).  A price update is fl(fl(c - w) + eps)

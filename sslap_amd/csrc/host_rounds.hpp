@@ -93,8 +93,8 @@ int read_ctl(misslap_solver *h) {
             return fail(MISSLAP_ERR_STATE, "device-side invariant violated (error bits 0x%x)", h->h_ctl->err);
         return MISSLAP_OK;
     }
-    HIP_TRY(hipMemcpyAsync(h->h_ctl, h->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(stream_memcpy(h, h->h_ctl, h->ctl, sizeof(Ctl), hipMemcpyDeviceToHost));
+    HIP_TRY(stream_sync(h));
     h->ctl_fresh = 2;
     h->K_ub = h->h_ctl->K;
     h->K_exact = true;
@@ -119,7 +119,10 @@ bool live_poll(misslap_solver *h, unsigned want, bool exact, int *K, int *err, l
             *nits = (long long)((c & 0xffffffffull) | ((d & 0xffffffffull) << 32));
             return true;
         }
-        if (spins < 4000) {
+        if (h->batch) {  // (a fiber of a batch: let the other problems run; the scheduler comes back to this poll)
+            batch_yield(h, BatchFiber::kPolling);
+            if ((spins & 255) == 255 && now_ms() > t_end) return false;
+        } else if (spins < 4000) {
             __builtin_ia32_pause();
         } else {
             std::this_thread::yield();  // (a tail kernel runs for milliseconds: do not burn a core another solve needs)
@@ -133,7 +136,7 @@ bool live_poll(misslap_solver *h, unsigned want, bool exact, int *K, int *err, l
 // posts the status is enqueued behind it
 void ensure_posted(misslap_solver *h) {
     if (h->live_valid || h->live_off) return;
-    hipLaunchKernelGGL(k_post_status, dim3(1), dim3(1), 0, h->stream, h->ctl, h->live_dev, ++h->ticket);
+    MISSLAP_LAUNCH(h, k_post_status, (F_k_post_status), 1, dim3(1), dim3(1), (const Ctl *)h->ctl, h->live_dev, ++h->ticket);
     h->live_valid = true;
 }
 int read_status(misslap_solver *h) {
@@ -171,6 +174,7 @@ int status_enqueue(misslap_solver *h, int slot) {
         return MISSLAP_OK;
     }
     h->ctl_fresh = false;
+    if (h->batch) return fail(MISSLAP_ERR_STATE, "a batched solve needs the live status words");
     HIP_TRY(hipMemcpyAsync(&h->h_stat[slot], h->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipEventRecord(h->stat_ev[slot], h->stream));
     return MISSLAP_OK;
@@ -230,10 +234,10 @@ int launch_bid_tiled(misslap_solver *h) {
         int *pos_of = h->nmatch, *order_person = h->hole_list, *order_pos = h->mover_list, *sums = h->cnt;
         const int nchunks = (h->n_rows + kScanChunk - 1) / kScanChunk;
         // (each returns at once when the scan itself will: a round enqueued on a stale upper bound of K)
-        hipLaunchKernelGGL(k_order_prepare, dim3(std::max(nchunks, blocks_for(h->K_ub, 1024))), dim3(1024), 0, h->stream, h->ctl, h->U,
-                           pos_of, h->p2o, h->n_rows, nchunks, sums, h->thr, h->tiled_min_K);
-        hipLaunchKernelGGL(k_order_scatter, dim3(nchunks), dim3(1024), 0, h->stream, h->ctl, h->p2o, h->n_rows, sums, pos_of,
-                           order_person, order_pos, h->thr, h->tiled_min_K);
+        MISSLAP_LAUNCH_PLAIN(h, k_order_prepare, dim3(std::max(nchunks, blocks_for(h->K_ub, 1024))), dim3(1024), 0, h->ctl, h->U,
+                             pos_of, h->p2o, h->n_rows, nchunks, sums, h->thr, h->tiled_min_K);
+        MISSLAP_LAUNCH_PLAIN(h, k_order_scatter, dim3(nchunks), dim3(1024), 0, h->ctl, h->p2o, h->n_rows, sums, pos_of,
+                             order_person, order_pos, h->thr, h->tiled_min_K);
         ta.order_person = order_person;
         ta.order_pos = order_pos;
     }
@@ -252,7 +256,10 @@ int launch_bid_tiled(misslap_solver *h) {
     if (h->tiled_fmt == 0) {
         switch (h->tiled_shape) {
 #define X(I, TH, R, B, D, TC, LD, GL, CS) \
-    case I: MISSLAP_LAUNCH_TIMED(pr, (k_bid_tiled<TH, R, B, D, TC, LD, 0, GL, CS>), g, dim3(TH), (unsigned)lds, h->stream, a, ta); break;
+    case I:                                                                                                            \
+        if (h->batch) MISSLAP_LAUNCH_PLAIN(h, (k_bid_tiled<TH, R, B, D, TC, LD, 0, GL, CS>), g, dim3(TH), lds, a, ta);        \
+        else MISSLAP_LAUNCH_TIMED(pr, (k_bid_tiled<TH, R, B, D, TC, LD, 0, GL, CS>), g, dim3(TH), (unsigned)lds, h->stream, a, ta); \
+        break;
             MISSLAP_FOR_TILED_SHAPES(X)
 #undef X
             default: return fail(MISSLAP_ERR_STATE, "bad tiled shape");
@@ -261,7 +268,10 @@ int launch_bid_tiled(misslap_solver *h) {
         const int key = h->tiled_fmt * 100 + shp[6];
         switch (key) {
 #define X(FMT, GL) \
-    case FMT * 100 + GL: MISSLAP_LAUNCH_TIMED(pr, (MISSLAP_BID_KERNEL_FMT(GL, FMT)), g, dim3(1024), (unsigned)lds, h->stream, a, ta); break;
+    case FMT * 100 + GL:                                                                                               \
+        if (h->batch) MISSLAP_LAUNCH_PLAIN(h, (MISSLAP_BID_KERNEL_FMT(GL, FMT)), g, dim3(1024), lds, a, ta);                  \
+        else MISSLAP_LAUNCH_TIMED(pr, (MISSLAP_BID_KERNEL_FMT(GL, FMT)), g, dim3(1024), (unsigned)lds, h->stream, a, ta);     \
+        break;
             MISSLAP_FOR_FMT_LANES(X)
 #undef X
             default: return fail(MISSLAP_ERR_STATE, "no full-scan instance for format %d with %d lanes per person", h->tiled_fmt, shp[6]);
@@ -325,14 +335,20 @@ int launch_bid(misslap_solver *h) {
     // big rounds of a handle whose price table does not fit an XCD's L2: the lean scans go through the fp32 filter
     // (wave_bid_filter); the mirror is rebuilt from the prices in front of the launch (12 bytes per object)
     if (h->price32 && !h->round_small && variant != 2 && (long long)h->K_ub * 8 >= h->n_rows) {
-        HIP_TRY(hipMemsetAsync(h->pmax_bits, 0, sizeof(int), h->stream));
-        hipLaunchKernelGGL(k_price_mirror, dim3(std::min(blocks_for(h->n_cols, 1024 * 4), h->n_cus)), dim3(1024), 0, h->stream, h->ctl, h->price,
-                           h->price32, h->n_cols, h->pmax_bits, h->thr, a.gather_max_K);
+        HIP_TRY(stream_memset(h, h->pmax_bits, 0, sizeof(int)));
+        MISSLAP_LAUNCH(h, k_price_mirror, (F_k_price_mirror), 1024, dim3(std::min(blocks_for(h->n_cols, 1024 * 4), h->n_cus)), dim3(1024),
+                       (const Ctl *)h->ctl, (const double *)h->price, h->price32, h->n_cols, h->pmax_bits, h->thr, a.gather_max_K);
         a.price32 = h->price32;
     }
 #define MISSLAP_LAUNCH_BID(E, ED)                                                                                   \
     do {                                                                                                            \
-        if (fused) MISSLAP_LAUNCH_TIMED(pr, (k_round_fused<E>), g, b, 0, h->stream, a, ED);                         \
+        if (h->batch) {  /* (no profiling inside a batch) */                                                        \
+            if (fused) MISSLAP_LAUNCH(h, (k_round_fused<E>), (F_k_round_fused<E>), 1024, g, b, a, ED);              \
+            else if (h->round_small) MISSLAP_LAUNCH(h, (k_bid<E, RecSource, 2>), (F_k_bid<E, RecSource, 2>), kBidBlock, g, b, a, ED); \
+            else if (variant == 0) MISSLAP_LAUNCH(h, (k_bid<E, PriceSource, 0>), (F_k_bid<E, PriceSource, 0>), kBidBlock, g, b, a, ED); \
+            else if (variant == 1) MISSLAP_LAUNCH(h, (k_bid<E, PriceSource, 1>), (F_k_bid<E, PriceSource, 1>), kBidBlock, g, b, a, ED); \
+            else MISSLAP_LAUNCH(h, (k_bid<E, PriceSource, 2>), (F_k_bid<E, PriceSource, 2>), kBidBlock, g, b, a, ED); \
+        } else if (fused) MISSLAP_LAUNCH_TIMED(pr, (k_round_fused<E>), g, b, 0, h->stream, a, ED);                  \
         else if (h->round_small) MISSLAP_LAUNCH_TIMED(pr, (k_bid<E, RecSource, 2>), g, b, 0, h->stream, a, ED);     \
         else if (variant == 0) MISSLAP_LAUNCH_TIMED(pr, (k_bid<E, PriceSource, 0>), g, b, 0, h->stream, a, ED);     \
         else if (variant == 1) MISSLAP_LAUNCH_TIMED(pr, (k_bid<E, PriceSource, 1>), g, b, 0, h->stream, a, ED);     \
@@ -358,8 +374,8 @@ int launch_tiebreak(misslap_solver *h) {
     if (h->round_small) return MISSLAP_OK;  // k_round_small (launch_apply) resolves the ties itself
     RoundArgs a = round_args(h);
     const long long share = h->K_ub;
-    hipLaunchKernelGGL(k_tiebreak, dim3(blocks_for(share, 256)), dim3(256), 0, h->stream, a,
-                       h->round_ordered ? h->mover_list : nullptr, h->tiled_min_K, h->take_edges_n, h->take_edges_out);
+    MISSLAP_LAUNCH(h, k_tiebreak, (F_k_tiebreak), 256, dim3(blocks_for(share, 256)), dim3(256), a,
+                   (const int *)(h->round_ordered ? h->mover_list : nullptr), h->tiled_min_K, h->take_edges_n, h->take_edges_out);
     h->take_edges_n = 0;
     h->take_edges_out = nullptr;
     HIP_TRY(hipGetLastError());
@@ -382,7 +398,7 @@ int launch_apply(misslap_solver *h) {
     if (h->round_small) {
         h->round_small = false;
         h->K_exact = false;
-        hipLaunchKernelGGL(k_round_small, dim3(1), dim3(1024), 0, h->stream, a);
+        MISSLAP_LAUNCH(h, k_round_small, (F_k_round_small), 1024, dim3(1), dim3(1024), a);
         HIP_TRY(hipGetLastError());
         return MISSLAP_OK;
     }
@@ -390,16 +406,16 @@ int launch_apply(misslap_solver *h) {
     h->round_ordered = false;
     // by the bidders where they are few against the objects (every rank holds every bid only in unsharded rounds)
     if ((h->world == 1 || h->K_ub < h->shard_min_K) && (long long)h->K_ub * h->apply_bidders_ratio <= h->n_cols)
-        hipLaunchKernelGGL(k_apply_bidders, dim3(blocks_for(h->K_ub, 256)), dim3(256), 0, h->stream, a);
+        MISSLAP_LAUNCH(h, k_apply_bidders, (F_k_apply_bidders), 256, dim3(blocks_for(h->K_ub, 256)), dim3(256), a);
     else
-        hipLaunchKernelGGL(k_apply, dim3(blocks_for(h->n_cols, 256)), dim3(256), 0, h->stream, a);
+        MISSLAP_LAUNCH(h, k_apply, (F_k_apply), 256, dim3(blocks_for(h->n_cols, 256)), dim3(256), a);
     if (h->K_ub <= kCompactSmallMax) {
-        hipLaunchKernelGGL(k_compact_small, dim3(1), dim3(1024), 0, h->stream, a);
+        MISSLAP_LAUNCH(h, k_compact_small, (F_k_compact_small), 1024, dim3(1), dim3(1024), a);
     } else {
         const int cb = blocks_for(h->K_ub, kChunk);
-        hipLaunchKernelGGL(k_compact_count, dim3(cb), dim3(256), 0, h->stream, a);
-        hipLaunchKernelGGL(k_compact_scatter, dim3(cb), dim3(256), 0, h->stream, a);
-        hipLaunchKernelGGL(k_compact_fill, dim3(blocks_for(h->K_ub, 256)), dim3(256), 0, h->stream, a);
+        MISSLAP_LAUNCH(h, k_compact_count, (F_k_compact_count), 256, dim3(cb), dim3(256), a);
+        MISSLAP_LAUNCH(h, k_compact_scatter, (F_k_compact_scatter), 256, dim3(cb), dim3(256), a);
+        MISSLAP_LAUNCH(h, k_compact_fill, (F_k_compact_fill), 256, dim3(blocks_for(h->K_ub, 256)), dim3(256), a);
     }
     HIP_TRY(hipGetLastError());
     return MISSLAP_OK;
@@ -460,25 +476,32 @@ int launch_tail(misslap_solver *h) {
     // sixteen wavefronts (kernels_tail.hpp); then -- lines only -- the rounds with 3..kTeamMax bidders, one list slot
     // per wavefront; then the rest: with lines the two-wavefront duo / chain instance, without them the 512-thread
     // instance that holds every mode
+    // (inside a batch all three instances are launched whatever K: an instance that finds K outside its range returns
+    // at once, and the problems of a group then issue the same sequence of kernels, i.e. share every launch)
+    const bool in_batch = h->batch != nullptr;
 #define MISSLAP_LAUNCH_TAIL(E, ED)                                                                                       \
     do {                                                                                                                 \
         if (lines && h->line_maintenance)                                                                                \
-            hipLaunchKernelGGL(k_refresh_lines<E>, dim3(blocks_for((h->n_rows + 1) / 2, kBidBlock / kWave)),             \
-                               dim3(kBidBlock), 0, h->stream, round_args(h), ED, kCandMaintenanceMin, long_max, min_alive_long); \
+            MISSLAP_LAUNCH(h, k_refresh_lines<E>, (F_k_refresh_lines<E>), kBidBlock,                                     \
+                           dim3(blocks_for((h->n_rows + 1) / 2, kBidBlock / kWave)), dim3(kBidBlock), round_args(h), ED, \
+                           (int)kCandMaintenanceMin, long_max, min_alive_long);                                          \
         if (lines && h->line_maintenance && h->long_rows) {                                                              \
             if (h->max_row_len <= 256 * kLongPer)                                                                        \
-                hipLaunchKernelGGL((k_refresh_long<E, 256>), dim3(blocks_for(h->n_rows, 1)), dim3(256), 0, h->stream,    \
-                                   round_args(h), ED);                                                                   \
+                MISSLAP_LAUNCH(h, (k_refresh_long<E, 256>), (F_k_refresh_long<E, 256>), 256, dim3(blocks_for(h->n_rows, 1)), \
+                               dim3(256), round_args(h), ED);                                                            \
             else                                                                                                         \
-                hipLaunchKernelGGL((k_refresh_long<E, 512>), dim3(blocks_for(h->n_rows, 1)), dim3(512), 0, h->stream,    \
-                                   round_args(h), ED);                                                                   \
+                MISSLAP_LAUNCH(h, (k_refresh_long<E, 512>), (F_k_refresh_long<E, 512>), 512, dim3(blocks_for(h->n_rows, 1)), \
+                               dim3(512), round_args(h), ED);                                                            \
         }                                                                                                                \
-        if (h->K_ub > kTeamMax)                                                                                          \
-            hipLaunchKernelGGL((k_tail<E, 2 * kTailMax>), dim3(1), dim3(2 * kTailMax), 0, h->stream, a, ED);             \
-        if (h->K_ub > 2 && lines)                                                                                        \
-            hipLaunchKernelGGL((k_tail<E, 2 * kTailMax, true>), dim3(1), dim3(2 * kTailMax), 0, h->stream, a, ED);       \
-        if (lines) hipLaunchKernelGGL((k_tail<E, 2 * kWave>), dim3(1), dim3(2 * kWave), 0, h->stream, a, ED);            \
-        else hipLaunchKernelGGL((k_tail<E, kTailMax>), dim3(1), dim3(kTailMax), 0, h->stream, a, ED);                    \
+        if (h->K_ub > kTeamMax || in_batch)                                                                              \
+            MISSLAP_LAUNCH(h, (k_tail<E, 2 * kTailMax>), (F_k_tail<E, 2 * kTailMax, false>), 2 * kTailMax, dim3(1),      \
+                           dim3(2 * kTailMax), a, ED);                                                                   \
+        if ((h->K_ub > 2 || in_batch) && lines)                                                                          \
+            MISSLAP_LAUNCH(h, (k_tail<E, 2 * kTailMax, true>), (F_k_tail<E, 2 * kTailMax, true>), 2 * kTailMax, dim3(1), \
+                           dim3(2 * kTailMax), a, ED);                                                                   \
+        if (lines) MISSLAP_LAUNCH(h, (k_tail<E, 2 * kWave>), (F_k_tail<E, 2 * kWave, false>), 2 * kWave, dim3(1),        \
+                                  dim3(2 * kWave), a, ED);                                                               \
+        else MISSLAP_LAUNCH(h, (k_tail<E, kTailMax>), (F_k_tail<E, kTailMax, false>), kTailMax, dim3(1), dim3(kTailMax), a, ED); \
     } while (0)
     if (h->f32) MISSLAP_LAUNCH_TAIL(EdgesF32, e32);
     else MISSLAP_LAUNCH_TAIL(EdgesF64, e64);
@@ -486,9 +509,10 @@ int launch_tail(misslap_solver *h) {
     if (pr) HIP_TRY(hipEventRecord(pr->stop, h->stream));
     // the tail keeps only the price records current: rebuild price / o2p / p2o from them
     h->live_valid = !h->live_off && h->live_dev != nullptr;
-    hipLaunchKernelGGL(k_sync_from_rec, dim3(blocks_for(h->n_cols, 256)), dim3(256), 0, h->stream, h->ctl, h->rec, h->price,
-                       h->o2p, h->p2o, h->U, h->n_cols, (h->cand != nullptr && !h->lines_dropped) ? 1 : 0,
-                       h->live_valid ? h->live_dev : nullptr, ++h->ticket);
+    MISSLAP_LAUNCH(h, k_sync_from_rec, (F_k_sync_from_rec), 256, dim3(blocks_for(h->n_cols, 256)), dim3(256), h->ctl,
+                   (const PriceRec *)h->rec, h->price, h->o2p, h->p2o, (const int *)h->U, h->n_cols,
+                   (h->cand != nullptr && !h->lines_dropped) ? 1 : 0, h->live_valid ? h->live_dev : (unsigned long long *)nullptr,
+                   ++h->ticket);
     HIP_TRY(hipGetLastError());
     h->phase_fresh = false;
     if (h->tail_nits0 < 0) h->tail_nits0 = h->h_ctl->nits;  // (the status read in front of this launch)
@@ -518,12 +542,12 @@ int launch_rows_gather(misslap_solver *h, float eps, const FinalOut &fo, int n_r
     if (n_blocks) *n_blocks = grid;
     if (h->f32) {
         EdgesF32 ed{h->edges32};
-        hipLaunchKernelGGL(k_ece<EdgesF32>, dim3(grid), dim3(256), 0, h->stream, h->ctl, ed, h->row_ptr, h->price,
-                           h->p2o, n_rows, eps, fo);
+        MISSLAP_LAUNCH(h, k_ece<EdgesF32>, (F_k_ece<EdgesF32>), 256, dim3(grid), dim3(256), h->ctl, ed, (const int *)h->row_ptr,
+                       (const double *)h->price, (const int *)h->p2o, n_rows, eps, fo);
     } else {
         EdgesF64 ed{h->col, h->val64};
-        hipLaunchKernelGGL(k_ece<EdgesF64>, dim3(grid), dim3(256), 0, h->stream, h->ctl, ed, h->row_ptr, h->price,
-                           h->p2o, n_rows, eps, fo);
+        MISSLAP_LAUNCH(h, k_ece<EdgesF64>, (F_k_ece<EdgesF64>), 256, dim3(grid), dim3(256), h->ctl, ed, (const int *)h->row_ptr,
+                       (const double *)h->price, (const int *)h->p2o, n_rows, eps, fo);
     }
     HIP_TRY(hipGetLastError());
     return MISSLAP_OK;
@@ -547,14 +571,14 @@ int launch_rows_all(misslap_solver *h, float eps, const FinalOut &fo, int *n_blo
     if (h->tiled_fmt == 0) {
         switch (gl) {
 #define X(GL) \
-    case GL: hipLaunchKernelGGL((MISSLAP_CHECK_KERNEL(GL)), dim3((unsigned)grid), dim3(1024), (unsigned)lds, h->stream, a, ta); break;
+    case GL: MISSLAP_LAUNCH_PLAIN(h, (MISSLAP_CHECK_KERNEL(GL)), dim3((unsigned)grid), dim3(1024), lds, a, ta); break;
             MISSLAP_FOR_CHECK_LANES(X)
 #undef X
         }
     } else {
         switch (h->tiled_fmt * 100 + gl) {
 #define X(FMT, GL) \
-    case FMT * 100 + GL: hipLaunchKernelGGL((MISSLAP_CHECK_KERNEL_FMT(GL, FMT)), dim3((unsigned)grid), dim3(1024), (unsigned)lds, h->stream, a, ta); break;
+    case FMT * 100 + GL: MISSLAP_LAUNCH_PLAIN(h, (MISSLAP_CHECK_KERNEL_FMT(GL, FMT)), dim3((unsigned)grid), dim3(1024), lds, a, ta); break;
             MISSLAP_FOR_FMT_LANES(X)
 #undef X
         }
@@ -575,14 +599,14 @@ int run_ece(misslap_solver *h, float eps, int *ok) {
     h->ctl_fresh = false;
     // (the flag is clear behind the state initialisation and behind every k_reset_phase: one runtime fill kernel less
     // per phase; a second test on the same state -- misslap_check_ece -- clears it itself)
-    if (!h->ece_flag_clear) HIP_TRY(hipMemsetAsync(&h->ctl->ece_fail, 0, sizeof(int), h->stream));
+    if (!h->ece_flag_clear) HIP_TRY(stream_memset(h, &h->ctl->ece_fail, 0, sizeof(int)));
     h->ece_flag_clear = false;
     const FinalOut fo{0, h->maximize, h->o2p, h->contrib, h->nmatch, h->n_rows, h->n_cols, nullptr};
     const int sample = std::min(h->n_rows, kEceSampleRows);
     if ((rc = launch_rows_gather(h, eps, fo, sample))) return rc;
     if (sample < h->n_rows && (rc = launch_rows_all(h, eps, fo))) return rc;
     if (!h->live_off) {  // the verdict through the live words: no copy of the control block, no stream drain
-        hipLaunchKernelGGL(k_post_ece, dim3(1), dim3(1), 0, h->stream, h->ctl, h->live_dev, ++h->ticket);
+        MISSLAP_LAUNCH(h, k_post_ece, (F_k_post_ece), 1, dim3(1), dim3(1), (const Ctl *)h->ctl, h->live_dev, ++h->ticket);
         h->live_valid = true;
         int K = 0, err = 0;
         long long nits = 0;
@@ -593,8 +617,9 @@ int run_ece(misslap_solver *h, float eps, int *ok) {
             unsigned long long v = *w;
             const double t_end = now_ms() + 2000.0;
             for (unsigned spins = 0; (unsigned)(v >> 32) != h->ticket; ++spins) {
-                __builtin_ia32_pause();
-                if ((spins & 4095) == 4095 && now_ms() > t_end) break;
+                if (h->batch) batch_yield(h, BatchFiber::kPolling);
+                else __builtin_ia32_pause();
+                if ((spins & (h->batch ? 63 : 4095)) == (h->batch ? 63u : 4095u) && now_ms() > t_end) break;
                 v = *w;
             }
             if ((unsigned)(v >> 32) == h->ticket) {

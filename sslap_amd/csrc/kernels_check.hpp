@@ -142,7 +142,7 @@ __device__ __forceinline__ void flush_final_wg(const FinalOut &fo, FinalAcc acc,
 // Branch-free: every load is unconditional (clamped index), a masked-off element has value -inf and matches nothing.
 // fo.fin = 0 (eCE only): every wavefront stops as soon as any row has failed.
 template <class E>
-__global__ __launch_bounds__(256) void k_ece(Ctl *ctl, E ed, const int *row_ptr, const double *price,
+__device__ __forceinline__ void k_ece_body(Ctl *ctl, E ed, const int *row_ptr, const double *price,
                                              const int *p2o, int n_rows, float eps_f, FinalOut fo) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const double eps = (double)eps_f;
@@ -186,6 +186,14 @@ __global__ __launch_bounds__(256) void k_ece(Ctl *ctl, E ed, const int *row_ptr,
     __shared__ double s_fin[8 * 4];
     if (fo.fin) flush_final_wg(fo, acc, s_fin);  // (uniform over the launch)
 }
+template <class E>
+__global__ __launch_bounds__(256) void k_ece(Ctl *ctl, E ed, const int *row_ptr, const double *price,
+                                             const int *p2o, int n_rows, float eps_f, FinalOut fo) { k_ece_body<E>(ctl, ed, row_ptr, price, p2o, n_rows, eps_f, fo); }
+template <class E>
+struct F_k_ece {  // (the body as a callable: what a batched launch runs per problem, csrc/host_batch.hpp)
+    static __device__ __forceinline__ void run(Ctl *ctl, E ed, const int *row_ptr, const double *price, const int *p2o, int n_rows, float eps_f, FinalOut fo) { k_ece_body<E>(ctl, ed, row_ptr, price, p2o, n_rows, eps_f, fo); }
+};
+
 
 __global__ void k_final_reset(Ctl *ctl) { ctl->ece_fail = 0; }
 

@@ -237,7 +237,7 @@ __device__ __forceinline__ void tally_flush(const RoundArgs &a, const BidTally &
 }
 
 template <class E, class Src, int kLines>
-__global__ __launch_bounds__(kBidBlock) void k_bid(RoundArgs a, E ed) {
+__device__ __forceinline__ void k_bid_body(RoundArgs a, E ed) {
     static_assert(kLines == 2 || !SrcOf<Src>::kOwners, "the lean scan does not carry the owners k_round_small needs");
     const int wave = threadIdx.x >> 6;
     const int wpb = kBidBlock / kWave;
@@ -253,10 +253,17 @@ __global__ __launch_bounds__(kBidBlock) void k_bid(RoundArgs a, E ed) {
     bid_positions<E, Src, kLines, false>(a, ed, lo, hi, first, gridDim.x * wpb, i_first, tl);
     tally_flush<kBidBlock / kWave>(a, tl, head.K);
 }
+template <class E, class Src, int kLines>
+__global__ __launch_bounds__(kBidBlock) void k_bid(RoundArgs a, E ed) { k_bid_body<E, Src, kLines>(a, ed); }
+template <class E, class Src, int kLines>
+struct F_k_bid {  // (the body as a callable: what a batched launch runs per problem, csrc/host_batch.hpp)
+    static __device__ __forceinline__ void run(RoundArgs a, E ed) { k_bid_body<E, Src, kLines>(a, ed); }
+};
+
 
 // The fp32 mirror of the prices for wave_bid_filter, and the largest price (bit pattern: prices are >= 0, so the patterns
 // order like integers; *pmax_bits is zeroed by the host in front of the launch).  Only in a live round that k_bid serves.
-__global__ __launch_bounds__(1024) void k_price_mirror(const Ctl *ctl, const double *price, float *price32, int n_cols,
+__device__ __forceinline__ void k_price_mirror_body(const Ctl *ctl, const double *price, float *price32, int n_cols,
                                                        int *pmax_bits, int thr, int gather_max_K) {
     if (!round_live(ctl, thr) || (gather_max_K > 0 && ctl->K >= gather_max_K)) return;
     __shared__ int s_w[16];
@@ -275,6 +282,12 @@ __global__ __launch_bounds__(1024) void k_price_mirror(const Ctl *ctl, const dou
         if (b > 0) atomicMax(pmax_bits, b);
     }
 }
+__global__ __launch_bounds__(1024) void k_price_mirror(const Ctl *ctl, const double *price, float *price32, int n_cols,
+                                                       int *pmax_bits, int thr, int gather_max_K) { k_price_mirror_body(ctl, price, price32, n_cols, pmax_bits, thr, gather_max_K); }
+struct F_k_price_mirror {  // (the body as a callable: what a batched launch runs per problem, csrc/host_batch.hpp)
+    static __device__ __forceinline__ void run(const Ctl *ctl, const double *price, float *price32, int n_cols, int *pmax_bits, int thr, int gather_max_K) { k_price_mirror_body(ctl, price, price32, n_cols, pmax_bits, thr, gather_max_K); }
+};
+
 
 // Line maintenance ahead of the tail kernels (once per eps-phase, when K has fallen to the tail threshold).  The grid
 // rounds refresh the lines of the persons who BID in them; a person who won its object in one of the big rounds (which
@@ -286,7 +299,7 @@ __global__ __launch_bounds__(1024) void k_price_mirror(const Ctl *ctl, const dou
 // long_max > 0: the long-row builder runs behind this pass and takes rows of up to so many edges; their lines are
 // rebuilt below min_alive_long live candidates.
 template <class E>
-__global__ __launch_bounds__(kBidBlock) void k_refresh_lines(RoundArgs a, E ed, int min_alive, int long_max, int min_alive_long) {
+__device__ __forceinline__ void k_refresh_lines_body(RoundArgs a, E ed, int min_alive, int long_max, int min_alive_long) {
     if (!E::kCand || a.cand == nullptr) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wpb = kBidBlock / kWave;
@@ -324,6 +337,13 @@ __global__ __launch_bounds__(kBidBlock) void k_refresh_lines(RoundArgs a, E ed, 
     }
     if (lane == 0 && err) atomicOr(&a.ctl->err, err);
 }
+template <class E>
+__global__ __launch_bounds__(kBidBlock) void k_refresh_lines(RoundArgs a, E ed, int min_alive, int long_max, int min_alive_long) { k_refresh_lines_body<E>(a, ed, min_alive, long_max, min_alive_long); }
+template <class E>
+struct F_k_refresh_lines {  // (the body as a callable: what a batched launch runs per problem, csrc/host_batch.hpp)
+    static __device__ __forceinline__ void run(RoundArgs a, E ed, int min_alive, int long_max, int min_alive_long) { k_refresh_lines_body<E>(a, ed, min_alive, long_max, min_alive_long); }
+};
+
 
 // The same maintenance for LONG rows (kCandRowMax < row length <= kCandLongMax: the dense `mat=` entry of the reference,
 // rows of thousands of edges).  A full scan of such a row keeps nothing in registers that a line could be built from,
@@ -336,7 +356,7 @@ constexpr int kLongPer = 32;                   // values per thread
 constexpr int kCandLongMax = 512 * kLongPer;  // 16384: the longest row that keeps a line (512-thread instance; 1024
                                               // threads leave 128 registers per thread, which spills the row's values)
 template <class E, int kLongThreads>          // 256 threads: rows <= 8192 edges; 512 threads: rows <= 16384
-__global__ __launch_bounds__(kLongThreads) void k_refresh_long(RoundArgs a, E ed) {
+__device__ __forceinline__ void k_refresh_long_body(RoundArgs a, E ed) {
     if (!E::kCand || a.cand == nullptr) return;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     __shared__ int s_cnt[2], s_n, s_g[kCandMax + 2], s_col[kCandMax + 2];
@@ -468,6 +488,13 @@ __global__ __launch_bounds__(kLongThreads) void k_refresh_long(RoundArgs a, E ed
         __syncthreads();
     }
 }
+template <class E, int kLongThreads>
+__global__ __launch_bounds__(kLongThreads) void k_refresh_long(RoundArgs a, E ed) { k_refresh_long_body<E, kLongThreads>(a, ed); }
+template <class E, int kLongThreads>
+struct F_k_refresh_long {  // (the body as a callable: what a batched launch runs per problem, csrc/host_batch.hpp)
+    static __device__ __forceinline__ void run(RoundArgs a, E ed) { k_refresh_long_body<E, kLongThreads>(a, ed); }
+};
+
 
 // order_pos: the bidders of this rank's shard were taken in person order (k_bid_tiled, partial rounds): shard slot
 // -> list position; nullptr = the shard is a range of list positions
@@ -475,7 +502,7 @@ __global__ __launch_bounds__(kLongThreads) void k_refresh_long(RoundArgs a, E ed
 // take_n workgroups scanned (RoundArgs::wg_stats), like k_take_launch_edges, without a launch of its own
 // order_min_K: the person-ordered scan (and the kernels that prepare order_pos) ran only if K >= order_min_K -- a round
 // enqueued on a stale upper bound of K may have been bid by k_bid instead, in list order
-__global__ __launch_bounds__(256) void k_tiebreak(RoundArgs a, const int *order_pos, int order_min_K, int take_n, unsigned long long *take_out) {
+__device__ __forceinline__ void k_tiebreak_body(RoundArgs a, const int *order_pos, int order_min_K, int take_n, unsigned long long *take_out) {
     const Ctl *ctl = a.ctl;
     if (!round_live(ctl, a.thr)) return;
     if (ctl->K < order_min_K) order_pos = nullptr;
@@ -505,6 +532,11 @@ __global__ __launch_bounds__(256) void k_tiebreak(RoundArgs a, const int *order_
         if (a.bid_key[n] == a.best_key[j]) atomicMin(&a.best_pos[j], n);
     }
 }
+__global__ __launch_bounds__(256) void k_tiebreak(RoundArgs a, const int *order_pos, int order_min_K, int take_n, unsigned long long *take_out) { k_tiebreak_body(a, order_pos, order_min_K, take_n, take_out); }
+struct F_k_tiebreak {  // (the body as a callable: what a batched launch runs per problem, csrc/host_batch.hpp)
+    static __device__ __forceinline__ void run(RoundArgs a, const int *order_pos, int order_min_K, int take_n, unsigned long long *take_out) { k_tiebreak_body(a, order_pos, order_min_K, take_n, take_out); }
+};
+
 
 // ASSIGN (auction_.pyx:388-427).  All writes of one round are disjoint: winners are distinct unassigned persons,
 // evicted owners are distinct assigned persons, and a winner's slot in U is its own.
@@ -593,7 +625,7 @@ __device__ __forceinline__ void count_holes(Ctl *ctl, int holes) {  // one atomi
     }
 }
 // One thread per object: instead of the reference's O(M) sequential walk (:394).
-__global__ __launch_bounds__(256) void k_apply(RoundArgs a) {
+__device__ __forceinline__ void k_apply_body(RoundArgs a) {
     Ctl *ctl = a.ctl;
     if (!round_live(ctl, a.thr)) return;
     int holes = 0;
@@ -603,11 +635,16 @@ __global__ __launch_bounds__(256) void k_apply(RoundArgs a) {
     }
     count_holes(ctl, holes);
 }
+__global__ __launch_bounds__(256) void k_apply(RoundArgs a) { k_apply_body(a); }
+struct F_k_apply {  // (the body as a callable: what a batched launch runs per problem, csrc/host_batch.hpp)
+    static __device__ __forceinline__ void run(RoundArgs a) { k_apply_body(a); }
+};
+
 // One thread per BIDDER, for rounds with far fewer bidders than objects (every list position below K has bid in this
 // round, so bid_obj[n] is this round's -- on every rank only in rounds that are not sharded): position n has won the
 // object it bid on iff k_tiebreak left n in best_pos.  A loser that reads best_pos after the winner has reset it sees
 // "none", which is not its position either.
-__global__ __launch_bounds__(256) void k_apply_bidders(RoundArgs a) {
+__device__ __forceinline__ void k_apply_bidders_body(RoundArgs a) {
     Ctl *ctl = a.ctl;
     if (!round_live(ctl, a.thr)) return;
     const int K = ctl->K;
@@ -618,10 +655,15 @@ __global__ __launch_bounds__(256) void k_apply_bidders(RoundArgs a) {
     }
     count_holes(ctl, holes);
 }
+__global__ __launch_bounds__(256) void k_apply_bidders(RoundArgs a) { k_apply_bidders_body(a); }
+struct F_k_apply_bidders {  // (the body as a callable: what a batched launch runs per problem, csrc/host_batch.hpp)
+    static __device__ __forceinline__ void run(RoundArgs a) { k_apply_bidders_body(a); }
+};
+
 
 // push_all_left: the k-th empty slot in [0, K') receives the k-th person found in [K', K).
 constexpr int kChunk = 1024;  // U positions per block (256 threads x 4)
-__global__ __launch_bounds__(256) void k_compact_count(RoundArgs a) {
+__device__ __forceinline__ void k_compact_count_body(RoundArgs a) {
     const Ctl *ctl = a.ctl;
     if (!round_live(ctl, a.thr)) return;
     const int K = ctl->K, Kn = K - ctl->nholes;
@@ -655,8 +697,13 @@ __global__ __launch_bounds__(256) void k_compact_count(RoundArgs a) {
         __syncthreads();
     }
 }
+__global__ __launch_bounds__(256) void k_compact_count(RoundArgs a) { k_compact_count_body(a); }
+struct F_k_compact_count {  // (the body as a callable: what a batched launch runs per problem, csrc/host_batch.hpp)
+    static __device__ __forceinline__ void run(RoundArgs a) { k_compact_count_body(a); }
+};
 
-__global__ __launch_bounds__(256) void k_compact_scatter(RoundArgs a) {
+
+__device__ __forceinline__ void k_compact_scatter_body(RoundArgs a) {
     Ctl *ctl = a.ctl;
     if (!round_live(ctl, a.thr)) return;
     const int K = ctl->K, Kn = K - ctl->nholes;
@@ -718,11 +765,16 @@ __global__ __launch_bounds__(256) void k_compact_scatter(RoundArgs a) {
         if (b == nchunks - 1 && threadIdx.x == 0) ctl->nleft = offl;  // total left holes (== movers)
     }
 }
+__global__ __launch_bounds__(256) void k_compact_scatter(RoundArgs a) { k_compact_scatter_body(a); }
+struct F_k_compact_scatter {  // (the body as a callable: what a batched launch runs per problem, csrc/host_batch.hpp)
+    static __device__ __forceinline__ void run(RoundArgs a) { k_compact_scatter_body(a); }
+};
+
 
 // ... and the round's end (K += evicted - assigned :429, nits += 1 :273; a launch of one thread until round 4): every
 // workgroup reads the control block when it starts and counts itself in on Ctl::arrive when it is done; the one that
 // arrives last knows that nobody reads the old K any more and writes the new one.
-__global__ __launch_bounds__(256) void k_compact_fill(RoundArgs a) {
+__device__ __forceinline__ void k_compact_fill_body(RoundArgs a) {
     Ctl *ctl = a.ctl;
     const CtlHead head(ctl);
     if (!head.live(a.thr, false)) {  // (uniform over the launch)
@@ -748,6 +800,11 @@ __global__ __launch_bounds__(256) void k_compact_fill(RoundArgs a) {
         post_live_status(a.live, a.ticket, Kn, head.err, head.nits + 1);
     }
 }
+__global__ __launch_bounds__(256) void k_compact_fill(RoundArgs a) { k_compact_fill_body(a); }
+struct F_k_compact_fill {  // (the body as a callable: what a batched launch runs per problem, csrc/host_batch.hpp)
+    static __device__ __forceinline__ void run(RoundArgs a) { k_compact_fill_body(a); }
+};
+
 
 // push_all_left + round end in ONE launch for moderate K: a single 1024-thread workgroup walks U[0,K) in
 // chunks (block scan with a running carry), writes the two lists, fills, and closes the round.  Replaces four
@@ -838,7 +895,7 @@ __device__ __forceinline__ void compact_small_body(const RoundArgs &a, Ctl *ctl,
     }
 }
 
-__global__ __launch_bounds__(1024) void k_compact_small(RoundArgs a) {
+__device__ __forceinline__ void k_compact_small_body(RoundArgs a) {
     Ctl *ctl = a.ctl;
     const CtlHead head(ctl);
     if (!head.live(a.thr, false)) {  // (the round was not live: its ticket is posted all the same -- the host waits for it)
@@ -847,6 +904,11 @@ __global__ __launch_bounds__(1024) void k_compact_small(RoundArgs a) {
     }
     compact_small_body(a, ctl, head.K, ctl->nholes, head.err);
 }
+__global__ __launch_bounds__(1024) void k_compact_small(RoundArgs a) { k_compact_small_body(a); }
+struct F_k_compact_small {  // (the body as a callable: what a batched launch runs per problem, csrc/host_batch.hpp)
+    static __device__ __forceinline__ void run(RoundArgs a) { k_compact_small_body(a); }
+};
+
 
 // RESOLVE + ASSIGN + push_all_left + round end of a round with few bidders in ONE launch (a single 1024-thread
 // workgroup; the host uses it while K_ub <= kRoundSmallMax, the round is not sharded over GPUs and the bids were
@@ -994,7 +1056,7 @@ __device__ __forceinline__ void round_small_body(const RoundArgs &a, Ctl *ctl, c
     }
 }
 
-__global__ __launch_bounds__(1024) void k_round_small(RoundArgs a) {
+__device__ __forceinline__ void k_round_small_body(RoundArgs a) {
     const int t = threadIdx.x;
     // Everything a position needs comes from its bidder (k_bid<E, RecSource>) in two loads, requested before the
     // control block is read (positions at or beyond K hold stale bids, masked below) and kept in registers.
@@ -1015,6 +1077,11 @@ __global__ __launch_bounds__(1024) void k_round_small(RoundArgs a) {
     }
     round_small_body(a, ctl, head, br, key);
 }
+__global__ __launch_bounds__(1024) void k_round_small(RoundArgs a) { k_round_small_body(a); }
+struct F_k_round_small {  // (the body as a callable: what a batched launch runs per problem, csrc/host_batch.hpp)
+    static __device__ __forceinline__ void run(RoundArgs a) { k_round_small_body(a); }
+};
+
 
 // A whole round with few bidders in ONE launch: the bids of k_bid<E, RecSource, 2> by 1024-thread workgroups (one
 // wavefront per list position), and the rest of the round (round_small_body) by whichever workgroup finishes its bids
@@ -1026,7 +1093,7 @@ __global__ __launch_bounds__(1024) void k_round_small(RoundArgs a) {
 // Saves one launch boundary per round (~5 us of ~10.5; 1 400 - 2 100 such rounds per C3 solve), and one launch in four
 // of a solve is what bounds several solves in flight on one GPU.
 template <class E>
-__global__ __launch_bounds__(1024) void k_round_fused(RoundArgs a, E ed) {
+__device__ __forceinline__ void k_round_fused_body(RoundArgs a, E ed) {
     const int t = threadIdx.x, wave = t >> 6;
     constexpr int wpb = 1024 / kWave;
     const int first = blockIdx.x * wpb + wave;
@@ -1064,21 +1131,38 @@ __global__ __launch_bounds__(1024) void k_round_fused(RoundArgs a, E ed) {
     }
     round_small_body(a, ctl, head, br, key);
 }
+template <class E>
+__global__ __launch_bounds__(1024) void k_round_fused(RoundArgs a, E ed) { k_round_fused_body<E>(a, ed); }
+template <class E>
+struct F_k_round_fused {  // (the body as a callable: what a batched launch runs per problem, csrc/host_batch.hpp)
+    static __device__ __forceinline__ void run(RoundArgs a, E ed) { k_round_fused_body<E>(a, ed); }
+};
+
 
 // The status of everything enqueued so far, posted by a launch of its own: behind a batch of small rounds, whose
 // closing kernel (k_round_small, a few microseconds each, thousands per solve) does not pay for four stores to host
 // memory every round.
-__global__ void k_post_status(const Ctl *ctl, unsigned long long *live, unsigned ticket) {
+__device__ __forceinline__ void k_post_status_body(const Ctl *ctl, unsigned long long *live, unsigned ticket) {
     post_live_status(live, ticket, ctl->K, ctl->err, ctl->nits);
 }
+__global__ void k_post_status(const Ctl *ctl, unsigned long long *live, unsigned ticket) { k_post_status_body(ctl, live, ticket); }
+struct F_k_post_status {  // (the body as a callable: what a batched launch runs per problem, csrc/host_batch.hpp)
+    static __device__ __forceinline__ void run(const Ctl *ctl, unsigned long long *live, unsigned ticket) { k_post_status_body(ctl, live, ticket); }
+};
+
 // ... and, behind the eCE pass of a phase end, its verdict in a fifth word
-__global__ void k_post_ece(const Ctl *ctl, unsigned long long *live, unsigned ticket) {
+__device__ __forceinline__ void k_post_ece_body(const Ctl *ctl, unsigned long long *live, unsigned ticket) {
     post_live_status(live, ticket, ctl->K, ctl->err, ctl->nits);
     __hip_atomic_store(&live[4], ((unsigned long long)ticket << 32) | (unsigned)ctl->ece_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+__global__ void k_post_ece(const Ctl *ctl, unsigned long long *live, unsigned ticket) { k_post_ece_body(ctl, live, ticket); }
+struct F_k_post_ece {  // (the body as a callable: what a batched launch runs per problem, csrc/host_batch.hpp)
+    static __device__ __forceinline__ void run(const Ctl *ctl, unsigned long long *live, unsigned ticket) { k_post_ece_body(ctl, live, ticket); }
+};
+
 
 // eps-phase restart (auction_.pyx:286-290): forget assignments, keep prices.
-__global__ __launch_bounds__(256) void k_reset_phase(Ctl *ctl, int *p2o, int *o2p, PriceRec *rec, int *U,
+__device__ __forceinline__ void k_reset_phase_body(Ctl *ctl, int *p2o, int *o2p, PriceRec *rec, int *U,
                                                      int n_rows, int n_cols) {
     const int stride = gridDim.x * blockDim.x;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1098,5 +1182,11 @@ __global__ __launch_bounds__(256) void k_reset_phase(Ctl *ctl, int *p2o, int *o2
         ctl->ece_fail = 0;  // (the eCE test at the end of this phase finds its flag clear: no fill launch in front of it)
     }
 }
+__global__ __launch_bounds__(256) void k_reset_phase(Ctl *ctl, int *p2o, int *o2p, PriceRec *rec, int *U,
+                                                     int n_rows, int n_cols) { k_reset_phase_body(ctl, p2o, o2p, rec, U, n_rows, n_cols); }
+struct F_k_reset_phase {  // (the body as a callable: what a batched launch runs per problem, csrc/host_batch.hpp)
+    static __device__ __forceinline__ void run(Ctl *ctl, int *p2o, int *o2p, PriceRec *rec, int *U, int n_rows, int n_cols) { k_reset_phase_body(ctl, p2o, o2p, rec, U, n_rows, n_cols); }
+};
+
 
 }  // namespace misslap

@@ -77,7 +77,7 @@ __device__ __forceinline__ int apply_winner(const TailArgs &a, int person, int p
 // After the tail kernels: price[j], o2p[j] from the records, and p2o as the inverse of o2p.  p2o needs no clearing pass:
 // every person is either the owner of exactly one record (written below) or unassigned, and the unassigned persons are
 // the list U[0, K) -- K <= the tail threshold of them.
-__global__ __launch_bounds__(256) void k_sync_from_rec(Ctl *ctl, const PriceRec *rec, double *price, int *o2p, int *p2o,
+__device__ __forceinline__ void k_sync_from_rec_body(Ctl *ctl, const PriceRec *rec, double *price, int *o2p, int *p2o,
                                                        const int *U, int n_cols, int lines, unsigned long long *live,
                                                        unsigned ticket) {
     const int K = ctl->K;
@@ -101,6 +101,13 @@ __global__ __launch_bounds__(256) void k_sync_from_rec(Ctl *ctl, const PriceRec 
         if (r.owner >= 0) p2o[r.owner] = j;
     }
 }
+__global__ __launch_bounds__(256) void k_sync_from_rec(Ctl *ctl, const PriceRec *rec, double *price, int *o2p, int *p2o,
+                                                       const int *U, int n_cols, int lines, unsigned long long *live,
+                                                       unsigned ticket) { k_sync_from_rec_body(ctl, rec, price, o2p, p2o, U, n_cols, lines, live, ticket); }
+struct F_k_sync_from_rec {  // (the body as a callable: what a batched launch runs per problem, csrc/host_batch.hpp)
+    static __device__ __forceinline__ void run(Ctl *ctl, const PriceRec *rec, double *price, int *o2p, int *p2o, const int *U, int n_cols, int lines, unsigned long long *live, unsigned ticket) { k_sync_from_rec_body(ctl, rec, price, o2p, p2o, U, n_cols, lines, live, ticket); }
+};
+
 
 // per-wavefront statistics, flushed once when the kernel ends
 struct TailStats {
@@ -854,8 +861,8 @@ __device__ __forceinline__ void tail_team1_mode(const TailArgs &a, const E &ed, 
 // kThreads = 128 ("duo / chain only", handles with lines): the rounds with K <= 2 and nothing else -- two wavefronts
 // for duo mode, wavefront 0 alone for the chain; the instance that carries every mode needs 185 VGPRs and spills 14
 // SGPRs, each spill a v_writelane / v_readlane pair inside a chain that is bound by its instruction count.
-template <class E, int kThreads, bool kTeamOnly = false>
-__global__ __launch_bounds__(kThreads) void k_tail(TailArgs a, E ed) {
+template <class E, int kThreads, bool kTeamOnly>
+__device__ __forceinline__ void k_tail_body(TailArgs a, E ed) {
     static_assert(!kTeamOnly || (kThreads == 2 * kTailMax && kThreads / kWave == kTeamMax), "one slot per wavefront");
     constexpr bool kBlockOnly = kThreads > kTailMax && !kTeamOnly;
     constexpr bool kDuoOnly = kThreads == 2 * kWave;
@@ -1283,5 +1290,12 @@ __global__ __launch_bounds__(kThreads) void k_tail(TailArgs a, E ed) {
         ctl->tail_rounds += nits - nits0;
     }
 }
+template <class E, int kThreads, bool kTeamOnly = false>
+__global__ __launch_bounds__(kThreads) void k_tail(TailArgs a, E ed) { k_tail_body<E, kThreads, kTeamOnly>(a, ed); }
+template <class E, int kThreads, bool kTeamOnly>
+struct F_k_tail {  // (the body as a callable: what a batched launch runs per problem, csrc/host_batch.hpp)
+    static __device__ __forceinline__ void run(TailArgs a, E ed) { k_tail_body<E, kThreads, kTeamOnly>(a, ed); }
+};
+
 
 }  // namespace misslap

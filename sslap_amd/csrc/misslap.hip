@@ -42,6 +42,7 @@ using namespace misslap;
 
 #define MISSLAP_API extern "C" __attribute__((visibility("default")))
 #include "host_base.hpp"
+#include "host_batch.hpp"
 #include "host_cache.hpp"
 #include "host_rounds.hpp"
 #include "host_create.hpp"
@@ -272,8 +273,8 @@ MISSLAP_API int misslap_phase_end(misslap_solver *h, int32_t *finished) {
             h->finished = true;
         } else {
             h->eps = h->eps * h->theta;  // :283 (fp32 product)
-            hipLaunchKernelGGL(k_reset_phase, dim3(blocks_for(h->n_rows > h->n_cols ? h->n_rows : h->n_cols, 256)),
-                               dim3(256), 0, h->stream, h->ctl, h->p2o, h->o2p, h->rec, h->U, h->n_rows, h->n_cols);
+            MISSLAP_LAUNCH(h, k_reset_phase, (F_k_reset_phase), 256, dim3(blocks_for(h->n_rows > h->n_cols ? h->n_rows : h->n_cols, 256)),
+                           dim3(256), h->ctl, h->p2o, h->o2p, h->rec, h->U, h->n_rows, h->n_cols);
             HIP_TRY(hipGetLastError());
             h->live_valid = false;  // (K was changed by a launch without a ticket; the mirror below is current)
             h->nreductions += 1;  // :292
@@ -300,28 +301,27 @@ MISSLAP_API int misslap_finish(misslap_solver *h, int32_t *person_to_object_out,
     h->ctl_fresh = false;
     // ONE pass over the rows for meta['eCE'] / soln_found (:297, :300), the objective (:302, :489-523) and the validity
     // flags of the assignment (benchmarking.py:56-64): all three look for the stored entry (i, sol[i])
-    hipLaunchKernelGGL(k_final_reset, dim3(1), dim3(1), 0, h->stream, h->ctl);
+    MISSLAP_LAUNCH_PLAIN(h, k_final_reset, dim3(1), dim3(1), 0, h->ctl);
     const FinalOut fo{1, h->maximize, h->o2p, h->contrib, h->nmatch, h->n_rows, h->n_cols, h->fin_slots};
     int n_slots = 0;
     // (a workgroup without rows returns before it writes its slot)
-    HIP_TRY(hipMemsetAsync(h->fin_slots, 0, sizeof(FinSlot) * (size_t)h->fin_slots_n, h->stream));
+    HIP_TRY(stream_memset(h, h->fin_slots, 0, sizeof(FinSlot) * (size_t)h->fin_slots_n));
     if ((rc = launch_rows_all(h, h->target_eps, fo, &n_slots))) return rc;
     h->ece_flag_clear = false;  // the final pass leaves its verdict in Ctl::ece_fail: the next test must clear it
     if (h->f32) {
         EdgesF32 ed{h->edges32};
-        hipLaunchKernelGGL(k_obj_sum<EdgesF32>, dim3(1), dim3(1024), 0, h->stream, h->ctl, ed, h->row_ptr, h->p2o,
-                           h->n_rows, h->maximize, h->contrib, h->nmatch, h->fin_slots, n_slots);
+        MISSLAP_LAUNCH_PLAIN(h, k_obj_sum<EdgesF32>, dim3(1), dim3(1024), 0, h->ctl, ed, h->row_ptr, h->p2o,
+                             h->n_rows, h->maximize, h->contrib, h->nmatch, h->fin_slots, n_slots);
     } else {
         EdgesF64 ed{h->col, h->val64};
-        hipLaunchKernelGGL(k_obj_sum<EdgesF64>, dim3(1), dim3(1024), 0, h->stream, h->ctl, ed, h->row_ptr, h->p2o,
-                           h->n_rows, h->maximize, h->contrib, h->nmatch, h->fin_slots, n_slots);
+        MISSLAP_LAUNCH_PLAIN(h, k_obj_sum<EdgesF64>, dim3(1), dim3(1024), 0, h->ctl, ed, h->row_ptr, h->p2o,
+                             h->n_rows, h->maximize, h->contrib, h->nmatch, h->fin_slots, n_slots);
     }
     HIP_TRY(hipGetLastError());
     if (person_to_object_out)
-        HIP_TRY(hipMemcpyAsync(person_to_object_out, h->p2o, sizeof(int) * (size_t)h->n_rows, hipMemcpyDeviceToHost,
-                               h->stream));
+        HIP_TRY(stream_memcpy(h, person_to_object_out, h->p2o, sizeof(int) * (size_t)h->n_rows, hipMemcpyDeviceToHost));
     // the bid kernels' statistics (a slot per workgroup, RoundArgs::wg_stats) -> the control block
-    hipLaunchKernelGGL(k_collect_stats, dim3(1), dim3(1024), 0, h->stream, h->ctl, h->wg_stats, h->wg_stats_slots);
+    MISSLAP_LAUNCH_PLAIN(h, k_collect_stats, dim3(1), dim3(1024), 0, h->ctl, h->wg_stats, h->wg_stats_slots);
     HIP_TRY(hipGetLastError());
     h->ctl_fresh = false;
     if ((rc = read_ctl(h))) return rc;
@@ -484,6 +484,7 @@ MISSLAP_API int misslap_solve(misslap_solver *h, int32_t *person_to_object_out, 
 }
 // (the sharded solve is defined below: misslap_solve calls it)
 #include "abi_comm.hpp"
+#include "abi_batch.hpp"
 
 MISSLAP_API int misslap_get_state(misslap_solver *h, double *prices, int32_t *unassigned, int32_t *person_to_object,
                                   int32_t *object_to_person) {
