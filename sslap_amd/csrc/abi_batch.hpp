@@ -16,15 +16,20 @@ void batch_fiber_main(unsigned lo, unsigned hi) {
     swapcontext(&f->ctx, &f->grp->sched);  // (never resumed)
 }
 
-// issue what the fibers of the group have recorded: the heads of all pending lists at a time, equal kernels as one launch
-void batch_flush(BatchGroup &g) {
-    std::vector<size_t> at(g.fibers.size(), 0);
+// issue what the fibers of the group have recorded: the heads of all pending lists at a time, equal kernels as one
+// launch.  A held head (the start of a tail sequence) stops its list unless `release` says that everybody is there.
+void batch_flush(BatchGroup &g, bool release) {
     std::vector<BatchCall *> heads, same;
     for (;;) {
         heads.clear();
-        for (size_t k = 0; k < g.fibers.size(); ++k) {
-            BatchFiber &f = *g.fibers[k];
-            if (at[k] < f.pending.size()) heads.push_back(&f.pending[at[k]++]);
+        for (auto &fp : g.fibers) {
+            BatchFiber &f = *fp;
+            if (f.at >= f.pending.size()) continue;
+            BatchCall &c = f.pending[f.at];
+            if (c.hold && !release) continue;
+            c.hold = false;
+            heads.push_back(&c);
+            f.at += 1;
         }
         if (heads.empty()) break;
         g.launches_merged += (long long)heads.size();
@@ -47,7 +52,11 @@ void batch_flush(BatchGroup &g) {
             g.launches_issued += 1;
         }
     }
-    for (auto &f : g.fibers) f->pending.clear();
+    for (auto &fp : g.fibers)
+        if (fp->at == fp->pending.size()) {
+            fp->pending.clear();
+            fp->at = 0;
+        }
 }
 
 // one group: its handles' solves on fibers of this thread, one stream
@@ -70,41 +79,49 @@ int batch_run_group(BatchGroup &g, int device) {
         f.h->batch = &f;
         f.state = BatchFiber::kRunnable;
     }
+    // How long the problems that HAVE their next launches wait for the ones still polling for a status (passes over the
+    // fibers, a few microseconds each): launches recorded together merge, and the stream is in order anyway -- what a
+    // polling problem waits for is queued in front of whatever the others would add
+    constexpr int kPatience = 64;
     const double t_end = now_ms() + 3600e3;
-    int rc = MISSLAP_OK;
+    int rc = MISSLAP_OK, idle = 0;
     for (;;) {
-        bool all_done = true, recorded = false;
+        bool active = false;
         for (auto &fp : g.fibers) {
             BatchFiber &f = *fp;
-            if (f.state == BatchFiber::kDone || f.state == BatchFiber::kWantsSync) {
-                all_done = all_done && f.state == BatchFiber::kDone;
-                continue;
-            }
-            all_done = false;
+            if (f.state == BatchFiber::kDone) continue;
+            active = true;
+            if (f.state == BatchFiber::kWantsSync) continue;
             swapcontext(&g.sched, &f.ctx);  // runs the fiber until it needs the device (or ends)
-            recorded = recorded || !f.pending.empty();
         }
-        bool want_sync = false;
+        if (!active) break;
+        int n_ready = 0, n_hold = 0, n_wait = 0, n_sync = 0;
         for (auto &fp : g.fibers) {
-            want_sync = want_sync || fp->state == BatchFiber::kWantsSync;
-            recorded = recorded || !fp->pending.empty();
+            const BatchFiber &f = *fp;
+            if (f.state == BatchFiber::kDone && f.at >= f.pending.size()) continue;
+            if (f.at < f.pending.size()) (f.pending[f.at].hold ? n_hold : n_ready) += 1;
+            else if (f.state == BatchFiber::kWantsSync) n_sync += 1;
+            else n_wait += 1;
         }
-        if (recorded) batch_flush(g);
-        if (want_sync) {
+        const bool release = n_hold > 0 && n_ready == 0 && n_wait == 0 && n_sync == 0;
+        if (release || (n_ready > 0 && (n_wait == 0 || ++idle > kPatience))) {
+            batch_flush(g, release);
+            idle = 0;
+            continue;  // (fibers whose calls just went out may have asked for a drained stream: next pass)
+        }
+        if (n_sync > 0 && n_ready == 0) {
             if (hipStreamSynchronize(g.stream) != hipSuccess) {
                 rc = fail(MISSLAP_ERR_HIP, "hipStreamSynchronize failed inside a batched solve: %s", hipGetErrorString(hipGetLastError()));
                 break;
             }
             for (auto &fp : g.fibers)
-                if (fp->state == BatchFiber::kWantsSync) fp->state = BatchFiber::kRunnable;
+                if (fp->state == BatchFiber::kWantsSync && fp->at >= fp->pending.size()) fp->state = BatchFiber::kRunnable;
+            continue;
         }
-        if (all_done) break;
-        if (!recorded && !want_sync) {  // everybody is waiting for a status word
-            __builtin_ia32_pause();
-            if (now_ms() > t_end) {
-                rc = fail(MISSLAP_ERR_STATE, "batched solve timed out");
-                break;
-            }
+        __builtin_ia32_pause();  // everybody is waiting for a status word (or for the patience above)
+        if (now_ms() > t_end) {
+            rc = fail(MISSLAP_ERR_STATE, "batched solve timed out");
+            break;
         }
     }
     (void)hipStreamSynchronize(g.stream);

@@ -76,6 +76,10 @@ struct BatchCall {
     // calls[0 .. n) as one batched launch per kMax of them.  nullptr: `single` goes onto the stream by itself
     void (*merge)(hipStream_t, BatchCall *const *calls, int n) = nullptr;
     std::function<void(hipStream_t)> single;
+    // the first call of a handle's tail sequence: it stays in the list until EVERY unfinished problem of the group has
+    // reached its own (batch_flush).  The tail kernels run for milliseconds on one workgroup each: issued as the problems
+    // get there, one after the other on the group's in-order stream, they would serialise; issued together they overlap
+    bool hold = false;
     dim3 grid, block;
     alignas(16) unsigned char args[kBatchArgBytes];
 };
@@ -93,6 +97,8 @@ struct BatchFiber {
     int32_t *sol = nullptr;
     misslap_meta *meta = nullptr;
     std::vector<BatchCall> pending;
+    size_t at = 0;           // pending[at ..) have not been issued yet
+    bool hold_next = false;  // the next recorded call is the head of a tail sequence
     hipStream_t own_stream = nullptr;  // the handle's stream outside the batch
     bool own_own_stream = false;
 };
@@ -128,12 +134,16 @@ void batch_record(misslap_solver *h, dim3 g, dim3 b, const A &...a) {
     c.merge = &batch_merge<F, kBounds, A...>;
     c.grid = g;
     c.block = b;
+    c.hold = f->hold_next;
+    f->hold_next = false;
     new (c.args) ArgPack<A...>(a...);
 }
 inline void batch_record_plain(misslap_solver *h, std::function<void(hipStream_t)> fn) {
     BatchFiber *f = h->batch;
     f->pending.emplace_back();
     f->pending.back().single = std::move(fn);
+    f->pending.back().hold = f->hold_next;
+    f->hold_next = false;
 }
 // the fiber gives the thread back to its group's scheduler
 inline void batch_yield(misslap_solver *h, BatchFiber::State why) {

@@ -479,6 +479,7 @@ int launch_tail(misslap_solver *h) {
     // (inside a batch all three instances are launched whatever K: an instance that finds K outside its range returns
     // at once, and the problems of a group then issue the same sequence of kernels, i.e. share every launch)
     const bool in_batch = h->batch != nullptr;
+    if (in_batch) h->batch->hold_next = true;  // ... and the sequence waits for the other problems of the group (host_batch.hpp)
 #define MISSLAP_LAUNCH_TAIL(E, ED)                                                                                       \
     do {                                                                                                                 \
         if (lines && h->line_maintenance)                                                                                \

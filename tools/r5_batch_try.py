@@ -34,4 +34,7 @@ good &= run(3000, 3000, 0.01, 8, 0)
 good &= run(3000, 4000, 0.01, 8, 3, thr=0)
 good &= run(6000, 40000, 0.001, 6, 0, tiled_min_k=1, engine=1)
 good &= run(20000, 20000, 0.002, 24, 12)
+good &= run(20000, 20000, 0.002, 24, 6)
+good &= run(50000, 50000, 0.005, 24, 12)
+good &= run(50000, 50000, 0.005, 24, 8)
 print("ALL OK" if good else "MISMATCH")
