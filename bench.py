@@ -226,6 +226,32 @@ def run_concurrent(B, steps, make_solver, edges_per_solve, want_sha, digest):
             "hw_queues_env": os.environ.get("GPU_MAX_HW_QUEUES")}
 
 
+def run_batch(B, group, steps, make_solver, edges_per_solve, want_sha, digest):
+    """B independent solves in LOCKSTEP (misslap_solve_batch: the problems of a group share one HIP stream and every launch
+    of the solve loop that several of them issue at the same point is one launch) -- the library's answer to "many LAPs on
+    one GPU" where --concurrent (B host threads, B streams) stalls on the device's launch rate."""
+    from sslap_amd import solve_batch
+    walls, creates, infos, shas = [], [], [], []
+    for _ in range(steps + 1):  # (one untimed warm-up batch: streams, fibers, the block cache)
+        t0 = time.perf_counter()
+        solvers = [make_solver() for _ in range(B)]
+        t1 = time.perf_counter()
+        sols, info = solve_batch(solvers, group)
+        t2 = time.perf_counter()
+        walls.append(t2 - t1)
+        creates.append(t1 - t0)
+        infos.append(info)
+        shas = [digest(x) for x in sols]
+        del solvers
+    wall = sum(walls[1:]) / steps
+    n = B
+    return {"B": B, "group_size": group or 12, "groups": infos[-1]["groups"], "wall_ms": round(1e3 * wall, 3),
+            "ms_per_solve": round(1e3 * wall / n, 3), "aggregate_medges_s": round(edges_per_solve * n / wall / 1e6, 2),
+            "create_ms_for_all": round(1e3 * sum(creates[1:]) / steps, 3),
+            "calls_recorded": infos[-1]["calls_recorded"], "launches_issued": infos[-1]["launches_issued"],
+            "all_sha256_equal_reference_run": all(d == want_sha for d in shas) and len(shas) == n}
+
+
 def source_digest():
     """sha256 over the kernel sources the library is built from: ties a committed PMC measurement to the code it was
     taken on (the GPU box has no .git, so a commit hash alone could not be checked there)."""
@@ -273,6 +299,10 @@ def main():
     ap.add_argument("--concurrent", type=int, default=0,
                     help="N = 1 only: after the timed single-solve steps, B independent solves at a time from B host "
                          "threads (B handles, B streams); reported beside the single-solve `value`, never instead of it")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="N = 1 only: after the timed single-solve steps, B copies of the workload solved in lockstep by "
+                         "misslap_solve_batch; reported beside the single-solve `value`, never instead of it")
+    ap.add_argument("--batch-group", type=int, default=0, help="problems per stream of --batch (0 = the library's default, 12)")
     ap.add_argument("--mode", choices=("sharded", "replicas"), default="sharded",
                     help="N > 1: 'sharded' = ONE problem, persons of the big rounds sharded over the ranks, RCCL "
                          "exchange (strong scaling; the default); 'replicas' = N independent problems, one per GPU, "
@@ -282,6 +312,8 @@ def main():
     backend = os.environ.get("MISSLAP_DIST_BACKEND", "nccl")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and backend != "threads":
         launch_ranks(args.gpus, sys.argv[1:])  # does not return
+    if args.batch > 1:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # (a queue per group of the batched solve)
     if args.concurrent > 1:
         # hardware queues for the concurrent streams (the runtime's default is 4 per process: streams beyond that
         # share a queue and their kernels serialise -- C3, 16 at a time: 2.8x the single-solve throughput with 4 queues,
@@ -547,6 +579,19 @@ def run_rank(args, rank, world, local_rank, ranks, comm, shared, backend):
             conc["block_cache_GiB"] = cache_gb
             conc["single_solve_ms_per_step"] = round(1e3 * dt / args.steps, 3)
             conc["throughput_vs_single"] = round(conc["aggregate_medges_s"] / (edges_all / dt / 1e6), 2)
+        batch = None
+        if args.batch > 1 and world == 1:
+            opts_b = dict(gpu_opts, profile=False)
+            cache_gb = 4 * args.batch
+            _lib.check(_lib.load().misslap_set_cache_limits(cache_gb << 30, 8 << 30, 4096))
+            batch = run_batch(args.batch, args.batch_group, max(1, args.steps),
+                              lambda: AuctionSolver.from_device_pointers(d_loc.data_ptr(), d_val.data_ptr(), nnz,
+                                                                         problem="max", max_iter=10**8, **opts_b),
+                              gpu["edges_scanned"], synth.sol_digest(sol), synth.sol_digest)
+            batch["single_solve_ms_per_step"] = round(1e3 * dt / args.steps, 3)
+            batch["single_solve_ms"] = round(sum(g["solve_ms"] for _, g in runs) / len(runs), 3)
+            # solves per second of the batch against ONE solve at a time (both without the CSR build)
+            batch["throughput_vs_single_solve"] = round(batch["single_solve_ms"] / batch["ms_per_solve"], 2)
         out = {
             "metric": "Medges/s (bid-phase CSR nnz/s) + solve ms, N=200k d=0.1% sparse LAP",
             "value": round(edges_all / dt / 1e6, 2),
@@ -645,6 +690,7 @@ def run_rank(args, rank, world, local_rank, ranks, comm, shared, backend):
             "exchanges_per_solve": 2 * rank_list[0]["sharded_rounds_per_solve"],
             "sol_sha256_equal_on_all_ranks": len({r["sol_sha256"] for r in rank_list}) == 1,
             "concurrent": conc,
+            "batch": batch,
         }
         if world == 1 and not args.no_cpu:
             whole = not args.cpu_sample_only and args.config != "C5"  # (C5: ~20 min of oracle time)
