@@ -48,7 +48,7 @@ void batch_flush(BatchGroup &g, bool release) {
                     same.push_back(heads[b]);
                     done[b] = true;
                 }
-            c->merge(g.stream, same.data(), (int)same.size());
+            c->merge(g, same.data(), (int)same.size());
             g.launches_issued += 1;
         }
     }
@@ -135,6 +135,9 @@ int batch_run_group(BatchGroup &g, int device) {
     }
     (void)hipStreamDestroy(g.stream);
     g.stream = nullptr;
+    if (g.h_ring) (void)hipHostFree(g.h_ring);
+    if (g.d_ring) (void)hipFree(g.d_ring);
+    g.h_ring = g.d_ring = nullptr;
     return rc;
 }
 

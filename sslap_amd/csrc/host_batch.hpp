@@ -64,6 +64,12 @@ template <class F, int kBounds, class... A>
 __global__ __launch_bounds__(kBounds) void k_batched(BatchSlots<A...> p) {
     if ((int)blockIdx.y < p.n) pack_call<F>(p.s[blockIdx.y]);
 }
+// ... the same for more problems than a kernel-argument block carries: their arguments staged in device memory (a ring of
+// the group, filled by an asynchronous copy on the same stream right in front of the launch)
+template <class F, int kBounds, class... A>
+__global__ __launch_bounds__(kBounds) void k_batched_ptr(const ArgPack<A...> *slots, int n) {
+    if ((int)blockIdx.y < n) pack_call<F>(slots[blockIdx.y]);
+}
 
 }  // namespace misslap
 
@@ -71,10 +77,11 @@ namespace {
 
 constexpr size_t kBatchArgBytes = 640;  // the largest by-value argument pack of a mergeable launch
 
+struct BatchGroup;
 struct BatchCall {
     // the identity of a mergeable launch (same pointer = same kernel body, bounds and argument types); launches
     // calls[0 .. n) as one batched launch per kMax of them.  nullptr: `single` goes onto the stream by itself
-    void (*merge)(hipStream_t, BatchCall *const *calls, int n) = nullptr;
+    void (*merge)(BatchGroup &, BatchCall *const *calls, int n) = nullptr;
     std::function<void(hipStream_t)> single;
     // the first call of a handle's tail sequence: it stays in the list until EVERY unfinished problem of the group has
     // reached its own (batch_flush).  The tail kernels run for milliseconds on one workgroup each: issued as the problems
@@ -85,6 +92,7 @@ struct BatchCall {
 };
 
 struct BatchGroup;
+struct BatchCall;
 struct BatchFiber {
     enum State { kRunnable, kPolling, kWantsSync, kDone };
     misslap_solver *h = nullptr;
@@ -107,21 +115,50 @@ struct BatchGroup {
     ucontext_t sched;
     std::vector<std::unique_ptr<BatchFiber>> fibers;
     long long launches_merged = 0, launches_issued = 0;  // calls recorded / launches that went out
+    // argument ring for launches over more problems than a kernel-argument block carries (k_batched_ptr): a pinned host
+    // buffer the packs are written to, and its device twin they are copied to on the stream in front of the launch.  A
+    // region is reused only after the stream has been drained (once per kBatchRingBytes of arguments)
+    char *h_ring = nullptr, *d_ring = nullptr;
+    size_t ring_at = 0;
 };
+constexpr size_t kBatchRingBytes = (size_t)32 << 20;
+// n packs of `bytes` each -> device memory, ordered on the group's stream; returns the device address (nullptr: failed)
+inline const void *batch_stage_args(BatchGroup &g, BatchCall *const *calls, int n, size_t bytes) {
+    const size_t need = ((size_t)n * bytes + 255) & ~(size_t)255;
+    if (!g.h_ring) {
+        if (hipHostMalloc((void **)&g.h_ring, kBatchRingBytes) != hipSuccess || hipMalloc((void **)&g.d_ring, kBatchRingBytes) != hipSuccess) return nullptr;
+    }
+    if (need > kBatchRingBytes) return nullptr;
+    if (g.ring_at + need > kBatchRingBytes) {
+        if (hipStreamSynchronize(g.stream) != hipSuccess) return nullptr;  // every earlier copy and launch has read its region
+        g.ring_at = 0;
+    }
+    char *hp = g.h_ring + g.ring_at, *dp = g.d_ring + g.ring_at;
+    for (int k = 0; k < n; ++k) std::memcpy(hp + (size_t)k * bytes, calls[k]->args, bytes);
+    if (hipMemcpyAsync(dp, hp, (size_t)n * bytes, hipMemcpyHostToDevice, g.stream) != hipSuccess) return nullptr;
+    g.ring_at += need;
+    return dp;
+}
 
 // ---- recording (called from the launch sites through MISSLAP_LAUNCH*) -------------------------------------------------
 template <class F, int kBounds, class... A>
-void batch_merge(hipStream_t st, BatchCall *const *calls, int n) {
+void batch_merge(BatchGroup &g, BatchCall *const *calls, int n) {
     using Slots = BatchSlots<A...>;
-    for (int k0 = 0; k0 < n; k0 += Slots::kMax) {
+    unsigned gx = 1;
+    for (int k = 0; k < n; ++k) gx = std::max(gx, calls[k]->grid.x);
+    if (n > Slots::kMax) {  // through the device ring: ONE launch whatever n
+        const void *d = batch_stage_args(g, calls, n, sizeof(ArgPack<A...>));
+        if (d) {
+            hipLaunchKernelGGL((k_batched_ptr<F, kBounds, A...>), dim3(gx, (unsigned)n), calls[0]->block, 0, g.stream,
+                               static_cast<const ArgPack<A...> *>(d), n);
+            return;
+        }
+    }
+    for (int k0 = 0; k0 < n; k0 += Slots::kMax) {  // (n <= kMax: the arguments travel in the kernel-argument block)
         Slots p;
         p.n = std::min(Slots::kMax, n - k0);
-        unsigned gx = 1;
-        for (int k = 0; k < p.n; ++k) {
-            std::memcpy(static_cast<void *>(&p.s[k]), calls[k0 + k]->args, sizeof(ArgPack<A...>));
-            gx = std::max(gx, calls[k0 + k]->grid.x);
-        }
-        hipLaunchKernelGGL((k_batched<F, kBounds, A...>), dim3(gx, (unsigned)p.n), calls[k0]->block, 0, st, p);
+        for (int k = 0; k < p.n; ++k) std::memcpy(static_cast<void *>(&p.s[k]), calls[k0 + k]->args, sizeof(ArgPack<A...>));
+        hipLaunchKernelGGL((k_batched<F, kBounds, A...>), dim3(gx, (unsigned)p.n), calls[k0]->block, 0, g.stream, p);
     }
 }
 template <class F, int kBounds, class... A>
