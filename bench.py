@@ -249,6 +249,7 @@ def run_batch(B, group, steps, make_solver, edges_per_solve, want_sha, digest):
             "ms_per_solve": round(1e3 * wall / n, 3), "aggregate_medges_s": round(edges_per_solve * n / wall / 1e6, 2),
             "create_ms_for_all": round(1e3 * sum(creates[1:]) / steps, 3),
             "calls_recorded": infos[-1]["calls_recorded"], "launches_issued": infos[-1]["launches_issued"],
+            "host_ms_summed_over_groups": infos[-1]["host_ms"],
             "all_sha256_equal_reference_run": all(d == want_sha for d in shas) and len(shas) == n}
 
 

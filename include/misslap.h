@@ -376,6 +376,9 @@ typedef struct misslap_batch_info {
     int64_t calls_recorded;    /* launches + asynchronous copies / fills the n solve loops asked for */
     int64_t launches_issued;   /* ... and what went onto the streams after merging */
     double wall_ms;
+    /* where the host threads of the groups spent their time (summed over groups): running the problems' solve loops up to
+     * their next wait, merging + issuing launches, waiting for the device (polling status words / draining the stream) */
+    double host_ms_fibers, host_ms_flush, host_ms_wait;
 } misslap_batch_info;
 int misslap_solve_batch(misslap_solver *const *handles, int32_t n, int32_t *const *person_to_object_out,
                         misslap_meta *meta_out, int32_t group_size, misslap_batch_info *info);

@@ -53,7 +53,8 @@ class Meta(C.Structure):
 
 class BatchInfo(C.Structure):
     _fields_ = [("groups", C.c_int32), ("reserved", C.c_int32), ("calls_recorded", C.c_int64),
-                ("launches_issued", C.c_int64), ("wall_ms", C.c_double)]
+                ("launches_issued", C.c_int64), ("wall_ms", C.c_double), ("host_ms_fibers", C.c_double),
+                ("host_ms_flush", C.c_double), ("host_ms_wait", C.c_double)]
 
 
 def new_meta():

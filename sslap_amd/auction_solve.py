@@ -190,7 +190,9 @@ class AuctionSolver:
         for s, m in zip(solvers, metas):
             s._fill_meta(m)
         return sols, dict(groups=int(info.groups), calls_recorded=int(info.calls_recorded),
-                          launches_issued=int(info.launches_issued), wall_ms=float(info.wall_ms))
+                          launches_issued=int(info.launches_issued), wall_ms=float(info.wall_ms),
+                          host_ms=dict(fibers=round(float(info.host_ms_fibers), 3), flush=round(float(info.host_ms_flush), 3),
+                                       wait=round(float(info.host_ms_wait), 3)))
 
     def solve_sharded(self, comm=None):
         """The same solve over the ranks of a communicator (sslap_amd.dist.Comm): persons of the big rounds sharded,

@@ -85,15 +85,24 @@ int batch_run_group(BatchGroup &g, int device) {
     constexpr int kPatience = 64;
     const double t_end = now_ms() + 3600e3;
     int rc = MISSLAP_OK, idle = 0;
+    double t_mark = now_ms();
+    auto lap = [&](double &acc) {
+        const double t = now_ms();
+        acc += t - t_mark;
+        t_mark = t;
+    };
     for (;;) {
-        bool active = false;
+        bool active = false, progressed = false;
         for (auto &fp : g.fibers) {
             BatchFiber &f = *fp;
             if (f.state == BatchFiber::kDone) continue;
             active = true;
             if (f.state == BatchFiber::kWantsSync) continue;
+            const size_t before = f.pending.size();
             swapcontext(&g.sched, &f.ctx);  // runs the fiber until it needs the device (or ends)
+            progressed = progressed || f.pending.size() != before || f.state != BatchFiber::kPolling;
         }
+        lap(progressed ? g.ms_fibers : g.ms_wait);
         if (!active) break;
         int n_ready = 0, n_hold = 0, n_wait = 0, n_sync = 0;
         for (auto &fp : g.fibers) {
@@ -106,6 +115,7 @@ int batch_run_group(BatchGroup &g, int device) {
         const bool release = n_hold > 0 && n_ready == 0 && n_wait == 0 && n_sync == 0;
         if (release || (n_ready > 0 && (n_wait == 0 || ++idle > kPatience))) {
             batch_flush(g, release);
+            lap(g.ms_flush);
             idle = 0;
             continue;  // (fibers whose calls just went out may have asked for a drained stream: next pass)
         }
@@ -116,6 +126,7 @@ int batch_run_group(BatchGroup &g, int device) {
             }
             for (auto &fp : g.fibers)
                 if (fp->state == BatchFiber::kWantsSync && fp->at >= fp->pending.size()) fp->state = BatchFiber::kRunnable;
+            lap(g.ms_wait);
             continue;
         }
         __builtin_ia32_pause();  // everybody is waiting for a status word (or for the patience above)
@@ -201,6 +212,12 @@ MISSLAP_API int misslap_solve_batch(misslap_solver *const *handles, int32_t n, i
             info->launches_issued += g->launches_issued;
         }
         info->wall_ms = now_ms() - t0;
+        info->host_ms_fibers = info->host_ms_flush = info->host_ms_wait = 0.0;
+        for (auto &g : groups) {
+            info->host_ms_fibers += g->ms_fibers;
+            info->host_ms_flush += g->ms_flush;
+            info->host_ms_wait += g->ms_wait;
+        }
     }
     for (int gi = 0; gi < n_groups; ++gi)
         if (rcs[(size_t)gi]) return fail(rcs[(size_t)gi], "%s", errs[(size_t)gi].c_str());

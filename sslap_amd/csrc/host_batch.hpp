@@ -115,6 +115,7 @@ struct BatchGroup {
     ucontext_t sched;
     std::vector<std::unique_ptr<BatchFiber>> fibers;
     long long launches_merged = 0, launches_issued = 0;  // calls recorded / launches that went out
+    double ms_fibers = 0, ms_flush = 0, ms_wait = 0;     // where this group's host thread spent its time
     // argument ring for launches over more problems than a kernel-argument block carries (k_batched_ptr): a pinned host
     // buffer the packs are written to, and its device twin they are copied to on the stream in front of the launch.  A
     // region is reused only after the stream has been drained (once per kBatchRingBytes of arguments)
