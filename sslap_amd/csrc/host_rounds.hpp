@@ -234,10 +234,10 @@ int launch_bid_tiled(misslap_solver *h) {
         int *pos_of = h->nmatch, *order_person = h->hole_list, *order_pos = h->mover_list, *sums = h->cnt;
         const int nchunks = (h->n_rows + kScanChunk - 1) / kScanChunk;
         // (each returns at once when the scan itself will: a round enqueued on a stale upper bound of K)
-        MISSLAP_LAUNCH_PLAIN(h, k_order_prepare, dim3(std::max(nchunks, blocks_for(h->K_ub, 1024))), dim3(1024), 0, h->ctl, h->U,
-                             pos_of, h->p2o, h->n_rows, nchunks, sums, h->thr, h->tiled_min_K);
-        MISSLAP_LAUNCH_PLAIN(h, k_order_scatter, dim3(nchunks), dim3(1024), 0, h->ctl, h->p2o, h->n_rows, sums, pos_of,
-                             order_person, order_pos, h->thr, h->tiled_min_K);
+        MISSLAP_LAUNCH(h, k_order_prepare, (F_k_order_prepare), 1024, dim3(std::max(nchunks, blocks_for(h->K_ub, 1024))), dim3(1024),
+                       (const Ctl *)h->ctl, (const int *)h->U, pos_of, (const int *)h->p2o, h->n_rows, nchunks, sums, h->thr, h->tiled_min_K);
+        MISSLAP_LAUNCH(h, k_order_scatter, (F_k_order_scatter), 1024, dim3(nchunks), dim3(1024), (const Ctl *)h->ctl, (const int *)h->p2o,
+                       h->n_rows, (const int *)sums, (const int *)pos_of, order_person, order_pos, h->thr, h->tiled_min_K);
         ta.order_person = order_person;
         ta.order_pos = order_pos;
     }

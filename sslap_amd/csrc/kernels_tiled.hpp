@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) void k_tile_scatter(E ed, const int *row_ptr, 
 // chunks in front of theirs themselves (at most a few hundred) instead of waiting for a scan launch.
 // (thr / min_K: the scan these kernels prepare runs only in a live round with K >= min_K -- otherwise nothing to do)
 __device__ __forceinline__ bool order_needed(const Ctl *ctl, int thr, int min_K) { return round_live(ctl, thr) && ctl->K >= min_K; }
-__global__ __launch_bounds__(1024) void k_order_prepare(const Ctl *ctl, const int *U, int *pos_of, const int *p2o, int n_rows,
+__device__ __forceinline__ void k_order_prepare_body(const Ctl *ctl, const int *U, int *pos_of, const int *p2o, int n_rows,
                                                         int nchunks, int *sums, int thr, int min_K) {
     if (!order_needed(ctl, thr, min_K)) return;
     const int K = ctl->K;
@@ -375,7 +375,13 @@ __global__ __launch_bounds__(1024) void k_order_prepare(const Ctl *ctl, const in
         sums[blockIdx.x] = t;
     }
 }
-__global__ __launch_bounds__(1024) void k_order_scatter(const Ctl *ctl, const int *p2o, int n_rows, const int *sums, const int *pos_of,
+__global__ __launch_bounds__(1024) void k_order_prepare(const Ctl *ctl, const int *U, int *pos_of, const int *p2o, int n_rows,
+                                                        int nchunks, int *sums, int thr, int min_K) { k_order_prepare_body(ctl, U, pos_of, p2o, n_rows, nchunks, sums, thr, min_K); }
+struct F_k_order_prepare {  // (the body as a callable: what a batched launch runs per problem, csrc/host_batch.hpp)
+    static __device__ __forceinline__ void run(const Ctl *ctl, const int *U, int *pos_of, const int *p2o, int n_rows, int nchunks, int *sums, int thr, int min_K) { k_order_prepare_body(ctl, U, pos_of, p2o, n_rows, nchunks, sums, thr, min_K); }
+};
+
+__device__ __forceinline__ void k_order_scatter_body(const Ctl *ctl, const int *p2o, int n_rows, const int *sums, const int *pos_of,
                                                         int *order_person, int *order_pos, int thr, int min_K) {
     if (!order_needed(ctl, thr, min_K)) return;
     __shared__ int s_w[16];
@@ -410,6 +416,12 @@ __global__ __launch_bounds__(1024) void k_order_scatter(const Ctl *ctl, const in
         carry += tot;
     }
 }
+__global__ __launch_bounds__(1024) void k_order_scatter(const Ctl *ctl, const int *p2o, int n_rows, const int *sums, const int *pos_of,
+                                                        int *order_person, int *order_pos, int thr, int min_K) { k_order_scatter_body(ctl, p2o, n_rows, sums, pos_of, order_person, order_pos, thr, min_K); }
+struct F_k_order_scatter {  // (the body as a callable: what a batched launch runs per problem, csrc/host_batch.hpp)
+    static __device__ __forceinline__ void run(const Ctl *ctl, const int *p2o, int n_rows, const int *sums, const int *pos_of, int *order_person, int *order_pos, int thr, int min_K) { k_order_scatter_body(ctl, p2o, n_rows, sums, pos_of, order_person, order_pos, thr, min_K); }
+};
+
 
 // ---- the kernel -------------------------------------------------------------------------------------------
 __device__ __forceinline__ double group8_max_f64(double v) {

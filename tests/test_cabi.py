@@ -203,3 +203,9 @@ def test_rccl_binding_matches_the_installed_header():
                      r"ncclRedOp_t op,\s*ncclComm_t comm,\s*hipStream_t stream\)", hdr)
     assert re.search(r"ncclCommInitRank\(ncclComm_t\*\s*comm,\s*int nranks,\s*ncclUniqueId commId,\s*int rank\)", hdr)
     assert re.search(r"ncclCommCount\(const ncclComm_t comm,\s*int\*\s*count\)", hdr)
+
+
+def test_solve_batch_rejects_bad_arguments_without_a_gpu():
+    lib = _lib.load()
+    assert lib.misslap_solve_batch(None, 0, None, None, 0, None) == _lib.ERR_INVALID
+    assert lib.misslap_solve_batch(None, 3, None, None, 0, None) == _lib.ERR_INVALID

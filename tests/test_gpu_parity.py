@@ -1398,6 +1398,88 @@ def test_f32_filter_scan_round_by_round(spec, prob, f64, cand, gpu_lib, monkeypa
         assert g.gpu["edges_scanned"] == o.extra["edges_scanned"], r
 
 
+_BATCH_CASES = [
+    # (label, spec, problem, number of problems, group size, options of every handle)
+    ("small_ints", dict(kind="sparse", n=300, m=300, density=0.05, ints=4), "max", 7, 0, dict()),
+    ("rect_grid_only", dict(kind="sparse", n=3000, m=4000, density=0.01), "min", 9, 4, dict(tail_threshold=0)),
+    ("mid_default", dict(kind="sparse", n=12000, m=12000, density=0.004), "max", 13, 0, dict()),
+    ("mid_tail16", dict(kind="sparse", n=5000, m=5000, density=0.01), "max", 6, 2, dict(tail_threshold=16)),
+    ("engine", dict(kind="sparse", n=6000, m=40000, density=0.001), "max", 5, 0, dict(tiled_min_k=1, engine=1)),
+    ("engine_f64_shuffled", dict(kind="shuffled", n=5000, m=25000, density=0.004, ints=5), "min", 4, 3,
+     dict(tiled_min_k=1, engine=1, force_f64=True)),
+    ("f64_values", dict(kind="f64", n=2500, density=0.01), "max", 5, 0, dict()),
+    ("dense_long_rows", dict(kind="dense", n=600, m=600), "max", 4, 0, dict()),
+    ("max_iter_cut", dict(kind="sparse", n=3000, m=3000, density=0.01), "max", 5, 0, dict(max_iter=57)),
+    ("no_lines", dict(kind="sparse", n=3000, m=3000, density=0.01), "max", 5, 0, dict(cand=False)),
+    ("one_problem", dict(kind="sparse", n=2000, m=2000, density=0.01), "max", 1, 0, dict()),
+    ("many_groups", dict(kind="sparse", n=1500, m=1500, density=0.02), "max", 40, 6, dict()),
+]
+
+
+@pytest.mark.parametrize("label,spec,prob,count,group,kw", _BATCH_CASES, ids=[c[0] for c in _BATCH_CASES])
+def test_batched_solve_equals_the_single_solves(label, spec, prob, count, group, kw, gpu_lib):
+    """misslap_solve_batch: many problems of one shape in lockstep -- the problems of a group share a HIP stream, and every
+    launch of the solve loop that several of them issue at the same point is ONE launch (csrc/host_batch.hpp).  Each handle
+    must end up exactly where its own misslap_solve leaves it: assignment, every meta key, fp64 objective, edge and bid
+    counts, validity flags -- for different problems (seeds) of the shape, through every engine and stage of the loop."""
+    from sslap_amd import solve_batch
+    kw = dict(kw)
+    max_iter = kw.pop("max_iter", 10**8)
+    probs = [cases.synth_inputs(dict(spec, seed=31 + 7 * k)) for k in range(count)]
+    mk = lambda loc, val: from_sparse(loc, val.copy(), problem=prob, cardinality_check=False, max_iter=max_iter, **kw)  # noqa: E731
+    singles = []
+    for loc, val in probs:
+        s = mk(loc, val)
+        sol = s.solve()
+        singles.append((sol, dict(s.meta), dict(s.gpu)))
+    solvers = [mk(loc, val) for loc, val in probs]
+    sols, info = solve_batch(solvers, group)
+    assert info["groups"] == -(-count // (group or 12)) and info["launches_issued"] <= info["calls_recorded"]
+    if count >= 4 and (group or 12) >= 3:
+        assert info["launches_issued"] < info["calls_recorded"]  # launches WERE shared
+    for k in range(count):
+        sol1, meta1, gpu1 = singles[k]
+        assert np.array_equal(sols[k], sol1), (label, k)
+        for key in cases.META_KEYS:
+            assert solvers[k].meta[key] == meta1[key], (label, k, key)
+        for key in ("obj_f64", "edges_scanned", "bids_made", "grid_rounds", "tail_rounds", "cand_hits", "complete_assignment",
+                    "valid_assignment", "tiled_active", "tiled_format", "eps_phases", "phases_with_lines"):
+            assert solvers[k].gpu[key] == gpu1[key], (label, k, key)
+    ref = orc.auction_solve(loc=probs[0][0], val=probs[0][1].copy(), problem=prob, cardinality_check=False, max_iter=max_iter)
+    assert np.array_equal(sols[0], ref["sol"]) and solvers[0].meta["its"] == ref["meta"]["its"]
+    # a handle is an ordinary handle again afterwards (its own stream, no recording)
+    assert solvers[0].status().finished == 1
+
+
+def test_batched_solve_argument_checks(gpu_lib):
+    from sslap_amd import solve_batch
+    a = from_sparse(*synth.gen_sparse(500, 500, 0.03, seed=1), problem="max", cardinality_check=False)
+    b = from_sparse(*synth.gen_sparse(600, 600, 0.03, seed=2), problem="max", cardinality_check=False)
+    with pytest.raises(ValueError, match="same shape"):
+        solve_batch([a, b])
+    with pytest.raises(ValueError, match="appears twice"):
+        solve_batch([a, a])
+    c = from_sparse(*synth.gen_sparse(500, 500, 0.03, seed=3), problem="max", cardinality_check=False, profile=1)
+    with pytest.raises(ValueError, match="profiled"):
+        solve_batch([a, c])
+    sols, _ = solve_batch([a])  # (the refused calls left the handles untouched)
+    o = orc.from_sparse(*synth.gen_sparse(500, 500, 0.03, seed=1), problem="max", cardinality_check=False)
+    assert np.array_equal(sols[0], o.solve())
+
+
+def test_batched_solve_of_sixteen_c1_equals_the_fixture(golden_large, gpu_lib):
+    """BASELINE config C1 sixteen times over (the reference's harness solves its problems in a loop,
+    benchmarking.py:84-142): every assignment equals the reference fixture."""
+    from sslap_amd import solve_batch
+    g = golden_large["cases"]["C1"]
+    loc, val = _config_arrays("C1")[:2]
+    solvers = [from_sparse(loc, val.copy(), problem="max", cardinality_check=False, max_iter=10**8) for _ in range(16)]
+    sols, info = solve_batch(solvers)
+    assert all(synth.sol_digest(x) == g["sol_sha256"] for x in sols)
+    assert all(s.meta["its"] == g["meta"]["its"] and s.gpu["obj_f64"] == g["obj_f64"] for s in solvers)
+    assert info["launches_issued"] * 4 < info["calls_recorded"]
+
+
 def test_no_kernel_depends_on_what_a_device_block_held_before(gpu_lib):
     """Device blocks come back from a cache, so whatever a kernel reads without anybody having written it is the
     previous handle's data -- or, in a fresh process, zeros, which hides the bug.  A fresh interpreter with
