@@ -163,3 +163,21 @@ def test_bench_line_of_the_many_rank_run_is_well_formed_on_one_gpu(backend, n, c
     assert d["value"] > 0 and d["roofline"]["frac"] <= 1.0 and d["cpu_baseline"] is None
     # unique work: the ranks' shares of the sharded rounds + the replicated rounds once = the single-GPU edge count
     assert round(d["value"] * d["ms_per_step"] * 1e3) == pytest.approx(g["edges_scanned"], rel=1e-3)
+
+
+@pytest.mark.gpu
+def test_bench_batch_leg_reports_beside_the_single_solve_value(gpu_lib):
+    """`python bench.py --batch B`: B copies of the workload solved in lockstep (misslap_solve_batch) AFTER the timed
+    single-solve steps; `value` stays the single-solve figure, the batch is reported beside it with every assignment's
+    sha256 checked against the single solve's (= the fixture's)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu", "--config", "C1",
+                        "--batch", "12", "--batch-group", "4"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "large_cases.json")))["cases"]["C1"]
+    b = d["batch"]
+    assert d["sol_sha256"] == g["sol_sha256"] and b["all_sha256_equal_reference_run"] is True
+    assert b["B"] == 12 and b["groups"] == 3 and 0 < b["launches_issued"] < b["calls_recorded"]
+    assert b["throughput_vs_single_solve"] > 1.0 and d["value"] > 0 and d["n_gpus"] == 1
