@@ -9,5 +9,5 @@ from .auction_solve import AuctionSolver, auction_solve, from_matrix, from_spars
 from .check_feasible import hopcroft_solve
 
 __version__ = "0.1.0"
-solve_batch = AuctionSolver.solve_batch  # many problems of one shape in lockstep on one GPU (include/misslap.h: misslap_solve_batch)
+solve_batch = AuctionSolver.solve_batch  # many problems with the same number of persons in lockstep on one GPU (include/misslap.h: misslap_solve_batch)
 __all__ = ["auction_solve", "hopcroft_solve", "from_matrix", "from_sparse", "AuctionSolver", "solve_batch"]

@@ -173,7 +173,7 @@ class AuctionSolver:
 
     @staticmethod
     def solve_batch(solvers, group_size=0):
-        """Solve many independent problems of ONE shape in lockstep (misslap_solve_batch: the problems of a group share a
+        """Solve many independent problems with the same number of persons (rows) in lockstep (misslap_solve_batch: the problems of a group share a
         HIP stream and every launch of the solve loop that several of them issue at the same point is one launch).  Every
         solver ends up exactly as after its own `.solve()` -- same assignment, same meta, bit for bit.  Returns
         (list of person_to_object arrays, info dict: groups, calls_recorded, launches_issued, wall_ms)."""

@@ -166,9 +166,12 @@ MISSLAP_API int misslap_solve_batch(misslap_solver *const *handles, int32_t n, i
         if (h->world != 1) return fail(MISSLAP_ERR_INVALID, "sharded handles cannot be batched");
         if (h->profile) return fail(MISSLAP_ERR_INVALID, "profiled handles (options.profile) cannot be batched");
         if (h->live_off) return fail(MISSLAP_ERR_STATE, "a batched solve needs the live status words (MISSLAP_LIVE_STATUS=0 is set, or they failed)");
-        if (h->n_rows != handles[0]->n_rows || h->n_cols != handles[0]->n_cols)
-            return fail(MISSLAP_ERR_INVALID, "the problems of a batch have the same shape (%d x %d here, %d x %d in handle %d): merged "
-                        "launches run on the largest grid", handles[0]->n_rows, handles[0]->n_cols, h->n_rows, h->n_cols, k);
+        // (merged launches run on the largest of their grids; what is sized by the number of PERSONS -- chunk counters,
+        // per-workgroup result slots -- is indexed by workgroup, so that number is the same for every problem of a batch;
+        // everything sized by the objects is walked with grid-stride loops)
+        if (h->n_rows != handles[0]->n_rows)
+            return fail(MISSLAP_ERR_INVALID, "the problems of a batch have the same number of persons (%d here, %d in handle %d): merged "
+                        "launches run on the largest grid", handles[0]->n_rows, h->n_rows, k);
         for (int j = 0; j < k; ++j)
             if (handles[j] == h) return fail(MISSLAP_ERR_INVALID, "handle %d appears twice in the batch", k);
         if (meta_out && h->abi >= 2 && (meta_out[k].struct_size < (int32_t)offsetof(misslap_meta, edges_scanned) || meta_out[k].struct_size > 65536))

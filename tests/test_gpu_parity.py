@@ -1455,7 +1455,7 @@ def test_batched_solve_argument_checks(gpu_lib):
     from sslap_amd import solve_batch
     a = from_sparse(*synth.gen_sparse(500, 500, 0.03, seed=1), problem="max", cardinality_check=False)
     b = from_sparse(*synth.gen_sparse(600, 600, 0.03, seed=2), problem="max", cardinality_check=False)
-    with pytest.raises(ValueError, match="same shape"):
+    with pytest.raises(ValueError, match="same number of persons"):
         solve_batch([a, b])
     with pytest.raises(ValueError, match="appears twice"):
         solve_batch([a, a])
