@@ -1442,7 +1442,9 @@ def test_batched_solve_equals_the_single_solves(label, spec, prob, count, group,
         assert np.array_equal(sols[k], sol1), (label, k)
         for key in cases.META_KEYS:
             assert solvers[k].meta[key] == meta1[key], (label, k, key)
-        for key in ("obj_f64", "edges_scanned", "bids_made", "grid_rounds", "tail_rounds", "cand_hits", "complete_assignment",
+        # (not cand_hits: WHICH rounds rebuild candidate lines depends on when the host saw which K -- an upper bound by
+        # design -- so the number of bids a line answers may differ from run to run; what is bid, and the row lengths counted, never do)
+        for key in ("obj_f64", "edges_scanned", "bids_made", "grid_rounds", "tail_rounds", "complete_assignment",
                     "valid_assignment", "tiled_active", "tiled_format", "eps_phases", "phases_with_lines"):
             assert solvers[k].gpu[key] == gpu1[key], (label, k, key)
     ref = orc.auction_solve(loc=probs[0][0], val=probs[0][1].copy(), problem=prob, cardinality_check=False, max_iter=max_iter)

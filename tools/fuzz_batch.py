@@ -47,16 +47,21 @@ for seed in range(first, first + count):
     solvers = [from_sparse(loc, val.copy(), **kw, **gpu) for loc, val in probs]
     sols, info = solve_batch(solvers, group)
     ok = True
+    why = []
     for k in range(B):
         sol1, meta1, gpu1 = singles[k]
-        ok = ok and np.array_equal(sols[k], sol1) and all(solvers[k].meta[key] == meta1[key] for key in cases.META_KEYS)
-        ok = ok and all(solvers[k].gpu[key] == gpu1[key] for key in ("obj_f64", "edges_scanned", "bids_made", "grid_rounds", "tail_rounds",
-                                                                    "cand_hits", "complete_assignment", "valid_assignment"))
+        if not np.array_equal(sols[k], sol1):
+            why.append((k, "sol"))
+        why += [(k, key, solvers[k].meta[key], meta1[key]) for key in cases.META_KEYS if solvers[k].meta[key] != meta1[key]]
+        # (counters that do not depend on WHEN the host saw which K: which rounds rebuild candidate lines does, so cand_hits is not compared)
+        why += [(k, key, solvers[k].gpu[key], gpu1[key]) for key in ("obj_f64", "edges_scanned", "bids_made", "grid_rounds", "tail_rounds",
+                                                                      "complete_assignment", "valid_assignment") if solvers[k].gpu[key] != gpu1[key]]
+    ok = not why
     o = orc.from_sparse(probs[0][0], probs[0][1].copy(), **kw)
     ok = ok and np.array_equal(sols[0], o.solve())
     if not ok:
         bad += 1
-        print("MISMATCH", seed, n, m, density, ints, B, group, kw, gpu, flush=True)
+        print("MISMATCH", seed, n, m, density, ints, B, group, kw, gpu, why[:6], flush=True)
     elif seed % 10 == 0:
         print("ok", seed, n, m, B, group, info["calls_recorded"], "->", info["launches_issued"], flush=True)
 print("done", count, "batches,", bad, "mismatches", flush=True)
