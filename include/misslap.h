@@ -368,8 +368,8 @@ int misslap_set_cache_limits(int64_t max_total_bytes, int64_t max_block_bytes, i
  * them issue at the same point is ONE launch (csrc/host_batch.hpp).  Each handle goes through exactly the sequence of
  * kernels misslap_solve would have launched for it: person_to_object_out[k] / meta_out[k] are what misslap_solve(handles[k])
  * returns, bit for bit.  The handles must be unsolved, unsharded, unprofiled, on one device, and have the same number of
- * persons (rows; objects and entries may differ).  meta_out: an array of n structs with struct_size set (may be NULL, like the output
- * pointers); *info (may be NULL) says how many launches went out for how many recorded. */
+ * persons (rows; objects and entries may differ).  meta_out: n pointers to structs with struct_size set (the array and
+ * any of its entries may be NULL, like the output pointers); *info (may be NULL) says how many launches went out for how many recorded. */
 typedef struct misslap_batch_info {
     int32_t groups;            /* streams / host threads used */
     int32_t reserved;
@@ -381,7 +381,7 @@ typedef struct misslap_batch_info {
     double host_ms_fibers, host_ms_flush, host_ms_wait;
 } misslap_batch_info;
 int misslap_solve_batch(misslap_solver *const *handles, int32_t n, int32_t *const *person_to_object_out,
-                        misslap_meta *meta_out, int32_t group_size, misslap_batch_info *info);
+                        misslap_meta *const *meta_out, int32_t group_size, misslap_batch_info *info);
 
 const char *misslap_last_error(void);
 int misslap_abi_version(void);

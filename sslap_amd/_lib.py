@@ -106,7 +106,7 @@ SYMBOLS = {
     "misslap_destroy": (C.c_int, [_VP]),
     "misslap_dims": (C.c_int, [_VP, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "misslap_solve": (C.c_int, [_VP, _VP, C.POINTER(Meta)]),
-    "misslap_solve_batch": (C.c_int, [C.POINTER(_VP), C.c_int32, C.POINTER(_VP), C.POINTER(Meta), C.c_int32,
+    "misslap_solve_batch": (C.c_int, [C.POINTER(_VP), C.c_int32, C.POINTER(_VP), C.POINTER(C.POINTER(Meta)), C.c_int32,
                                       C.POINTER(BatchInfo)]),
     "misslap_round_bid": (C.c_int, [_VP]),
     "misslap_round_tiebreak": (C.c_int, [_VP]),

@@ -186,7 +186,8 @@ class AuctionSolver:
         for m in metas:
             m.struct_size = C.sizeof(_lib.Meta)
         info = _lib.BatchInfo()
-        _lib.check(lib.misslap_solve_batch(handles, n, outs, metas, int(group_size), C.byref(info)))
+        meta_ptrs = (C.POINTER(_lib.Meta) * n)(*[C.pointer(m) for m in metas])
+        _lib.check(lib.misslap_solve_batch(handles, n, outs, meta_ptrs, int(group_size), C.byref(info)))
         for s, m in zip(solvers, metas):
             s._fill_meta(m)
         return sols, dict(groups=int(info.groups), calls_recorded=int(info.calls_recorded),

@@ -155,7 +155,7 @@ int batch_run_group(BatchGroup &g, int device) {
 }  // namespace
 
 MISSLAP_API int misslap_solve_batch(misslap_solver *const *handles, int32_t n, int32_t *const *person_to_object_out,
-                                    misslap_meta *meta_out, int32_t group_size, misslap_batch_info *info) {
+                                    misslap_meta *const *meta_out, int32_t group_size, misslap_batch_info *info) {
     if (!handles || n <= 0) return fail(MISSLAP_ERR_INVALID, "bad argument");
     if (group_size <= 0) group_size = 12;  // (what one kernel-argument block carries of the widest launch, host_batch.hpp)
     const int device = handles[0]->device;
@@ -174,8 +174,10 @@ MISSLAP_API int misslap_solve_batch(misslap_solver *const *handles, int32_t n, i
                         "launches run on the largest grid", handles[0]->n_rows, h->n_rows, k);
         for (int j = 0; j < k; ++j)
             if (handles[j] == h) return fail(MISSLAP_ERR_INVALID, "handle %d appears twice in the batch", k);
-        if (meta_out && h->abi >= 2 && (meta_out[k].struct_size < (int32_t)offsetof(misslap_meta, edges_scanned) || meta_out[k].struct_size > 65536))
-            return fail(MISSLAP_ERR_INVALID, "misslap_meta[%d].struct_size = %d: set it to sizeof(misslap_meta) before the call", k, meta_out[k].struct_size);
+        // (an array of POINTERS: the caller's misslap_meta may be shorter or longer than this build's, struct_size says)
+        if (meta_out && meta_out[k] && h->abi >= 2 &&
+            (meta_out[k]->struct_size < (int32_t)offsetof(misslap_meta, edges_scanned) || meta_out[k]->struct_size > 65536))
+            return fail(MISSLAP_ERR_INVALID, "meta_out[%d]->struct_size = %d: set it to sizeof(misslap_meta) before the call", k, meta_out[k]->struct_size);
     }
     const double t0 = now_ms();
     const int n_groups = (n + group_size - 1) / group_size;
@@ -186,7 +188,7 @@ MISSLAP_API int misslap_solve_batch(misslap_solver *const *handles, int32_t n, i
             std::unique_ptr<BatchFiber> f(new BatchFiber());
             f->h = handles[k];
             f->sol = person_to_object_out ? person_to_object_out[k] : nullptr;
-            f->meta = meta_out ? &meta_out[k] : nullptr;
+            f->meta = meta_out ? meta_out[k] : nullptr;
             groups.back()->fibers.push_back(std::move(f));
         }
     }

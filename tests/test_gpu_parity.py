@@ -1129,7 +1129,7 @@ def test_integration_md_sharded_binding_stub_works(gpu_lib):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     text = open(os.path.join(root, "INTEGRATION.md")).read()
     blocks = re.findall(r"```python\n(# sslap/misslap_binding.py.*?)```", text, re.S)
-    assert len(blocks) == 2
+    assert len(blocks) == 3  # single GPU, sharded, many problems at a time
     ns = {}
     for code in blocks:
         exec(compile(code.replace('C.CDLL("libmisslap.so")', f'C.CDLL({_lib.LIB_PATH!r})'), "INTEGRATION.md", "exec"), ns)
@@ -1137,6 +1137,12 @@ def test_integration_md_sharded_binding_stub_works(gpu_lib):
     sol = ns["solve_sharded"](loc, val.copy(), 0, 1, 0, lambda uid: uid, problem="max")
     ref = orc.auction_solve(loc=loc, val=val.copy(), problem="max", cardinality_check=False)
     assert np.array_equal(sol, ref["sol"])
+    # ... and the binding of the batched solve (misslap_solve_batch), executed verbatim as well
+    probs = [synth.gen_sparse(900, 900, 0.03, seed=40 + k) for k in range(5)]
+    solvers = [ns["_from_sparse"](l, v.copy(), problem="max", cardinality_check=False) for l, v in probs]
+    sols = ns["solve_many"](solvers)
+    for (l, v), got in zip(probs, sols):
+        assert np.array_equal(got, orc.auction_solve(loc=l, val=v.copy(), problem="max", cardinality_check=False)["sol"])
 
 
 def _drive_to_phase_end(g):
