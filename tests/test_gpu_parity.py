@@ -596,7 +596,8 @@ def test_plain_c_client_of_the_c_abi(tmp_path, gpu_lib):
         env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
         subprocess.check_call([exe, inp, out], env=env, timeout=120)
         lines = open(out).read().split("\n")
-        its, nred, nass, obj, card, n, m = lines[0].split()
+        its, nred, nass, obj, card, n, m, batch_ok = lines[0].split()
+        assert batch_ok == "1"  # three more handles through misslap_solve_batch: the same answer, short metas respected
         sol = np.array([int(x) for x in lines[1:1 + int(n)]], dtype=np.int32)
         ref = orc.auction_solve(loc=loc, val=val.copy(), problem=prob, cardinality_check=False, max_iter=10**8)
         assert np.array_equal(sol, ref["sol"])
