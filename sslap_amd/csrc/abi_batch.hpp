@@ -66,10 +66,20 @@ int batch_run_group(BatchGroup &g, int device) {
     for (auto &fp : g.fibers) {
         BatchFiber &f = *fp;
         f.grp = &g;
-        f.stack.reset(new char[kBatchFiberStack]);
+        if (!f.stack.alloc(kBatchFiberStack)) {
+            (void)hipStreamDestroy(g.stream);
+            g.stream = nullptr;
+            for (auto &fq : g.fibers)  // (the ones already set up)
+                if (fq->h->batch == fq.get()) {
+                    fq->h->batch = nullptr;
+                    fq->h->stream = fq->own_stream;
+                    fq->h->own_stream = fq->own_own_stream;
+                }
+            return fail(MISSLAP_ERR_STATE, "no memory for the stack of a batched solve (%zu bytes)", kBatchFiberStack);
+        }
         getcontext(&f.ctx);
-        f.ctx.uc_stack.ss_sp = f.stack.get();
-        f.ctx.uc_stack.ss_size = kBatchFiberStack;
+        f.ctx.uc_stack.ss_sp = f.stack.base();
+        f.ctx.uc_stack.ss_size = f.stack.size();
         f.ctx.uc_link = &g.sched;
         const uintptr_t p = reinterpret_cast<uintptr_t>(&f);
         makecontext(&f.ctx, reinterpret_cast<void (*)()>(batch_fiber_main), 2, (unsigned)(p & 0xffffffffu), (unsigned)(p >> 32));

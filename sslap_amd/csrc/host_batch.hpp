@@ -21,6 +21,7 @@
 // Per-handle order on the stream is the recording order, so every handle sees exactly the sequence of kernels it would
 // have launched alone: the results are bit-identical by construction (and by test: tests/test_gpu_parity.py).
 #pragma once
+#include <sys/mman.h>
 #include <ucontext.h>
 
 #include <functional>
@@ -93,12 +94,37 @@ struct BatchCall {
 
 struct BatchGroup;
 struct BatchCall;
+// A fiber's stack: its own mapping with an inaccessible page below it, so that running out of it is a fault at the
+// guard page and not a silent write into whatever the heap had next to it.
+struct FiberStack {
+    void *map = nullptr;
+    size_t map_bytes = 0;
+    static constexpr size_t kGuard = 16384;
+    bool alloc(size_t bytes) {
+        map_bytes = bytes + kGuard;
+        map = mmap(nullptr, map_bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_STACK, -1, 0);
+        if (map == MAP_FAILED) {
+            map = nullptr;
+            return false;
+        }
+        return mprotect(map, kGuard, PROT_NONE) == 0;  // (stacks grow downwards: the low end)
+    }
+    char *base() const { return static_cast<char *>(map) + kGuard; }
+    size_t size() const { return map_bytes - kGuard; }
+    FiberStack() = default;
+    FiberStack(const FiberStack &) = delete;
+    FiberStack &operator=(const FiberStack &) = delete;
+    ~FiberStack() {
+        if (map) munmap(map, map_bytes);
+    }
+};
+
 struct BatchFiber {
     enum State { kRunnable, kPolling, kWantsSync, kDone };
     misslap_solver *h = nullptr;
     BatchGroup *grp = nullptr;
     ucontext_t ctx;
-    std::unique_ptr<char[]> stack;
+    FiberStack stack;
     State state = kRunnable;
     int rc = MISSLAP_OK;
     std::string err;

@@ -213,9 +213,13 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
                 return e && e[0] == '1';
             }();
             if ((rc = count_and_scan(false))) return rc;
-            bool carry = carry_env;
+            // A row that stores an entry more than once (legal: the last one is the choice, auction_.pyx:467-471) is
+            // ascending but not strictly: it takes the stored-index formats too -- formats 0 / 1 order equal values by
+            // the COLUMN (k_bid_tiled, kKeyCol), which must then be unique within a row.
+            bool carry = carry_env || (unsorted & 2) != 0;
             bool usable = true;
-            if (unsorted) {
+            if (carry) usable = st.max_row_len <= 65536;
+            if (unsorted & 1) {
                 // Rows whose columns are not ascending (legal in the reference: cumulative_idxs, auction_.pyx:33-48, only
                 // needs the ROWS sorted, and the bid loop takes the stored order, :343-357).  The copy only needs the edges
                 // grouped by tile; what the in-row tie rule (:351) needs -- the stored index -- travels with every edge

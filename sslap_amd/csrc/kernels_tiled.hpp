@@ -95,7 +95,7 @@ __host__ __device__ __forceinline__ int tile_idx(int person, int t, int T, int r
 // ---- ingest: tile-major copy of the edges ---------------------------------------------------------------
 // pass 1, one wavefront per person: L(i, t) = number of edges of row i with column < t * kTileCols
 // (binary search, one tile boundary per lane); cnt[idx(i,t)] = L(i,t+1) - L(i,t); also the
-// column-order check.
+// column-order check (*unsorted: bit 0 = some row's columns do not ascend, bit 1 = some row repeats a column).
 // cnt = the count rounded up to an even number (every segment starts 16-byte aligned, so that a lane can
 // take two edges with one dwordx4 load); len = the real count.
 // (the columns of the row-major CSR: `cols[cs * g]` -- cs = 2 for the interleaved 8 B/edge layout, 1 for the 12 B/edge one)
@@ -105,9 +105,13 @@ __global__ __launch_bounds__(256) void k_tile_count(const int *cols, int cs, con
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int i = blockIdx.x * 4 + wave; i < n_rows; i += gridDim.x * 4) {
         const int s = row_ptr[i], e = row_ptr[i + 1];
-        int bad = 0;
-        for (int g = s + 1 + lane; g < e; g += kWave) bad |= (cols[(size_t)cs * g] < cols[(size_t)cs * (g - 1)]);
-        if (__ballot(bad) && lane == 0) atomicOr(unsorted, 1);
+        int bad = 0;  // bit 0: a column below its predecessor; bit 1: a column equal to it (an entry stored more than once)
+        for (int g = s + 1 + lane; g < e; g += kWave) {
+            const int c = cols[(size_t)cs * g], cp = cols[(size_t)cs * (g - 1)];
+            bad |= (c < cp ? 1 : 0) | (c == cp ? 2 : 0);
+        }
+        for (int off = 32; off >= 1; off >>= 1) bad |= __shfl_xor(bad, off);
+        if (bad && lane == 0) atomicOr(unsorted, bad);
         for (int t0 = 0; t0 <= T; t0 += kWave) {
             const int t = t0 + lane;
             int lo = 0;
@@ -616,7 +620,16 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
     const bool full = MODE == 1 || (ctl->K == a.n_rows && !ta.order_person);  // uniform
     int person[kTileRows];
     double sv[kTileRows], sw[kTileRows];
-    int sg[kTileRows];  // position of the lane's best element ...
+    // Formats 0 / 1 hold rows whose columns ascend STRICTLY (the ingest sends rows with a repeated column to the
+    // stored-index formats): the column of an edge is then as good a key for the tie rule as its position -- unique
+    // within the row and monotone in the stored index -- and it travels with the best element anyway (scol).  The tile
+    // loop of a bid scan therefore does not track positions at all (two instructions per element less); sg takes the
+    // columns over behind the loop, and the overflow entries and the merges order equal values by it as before.
+#ifndef MISSLAP_TILED_KEYCOL
+#define MISSLAP_TILED_KEYCOL 1  // (0: positions in every format -- A/B builds)
+#endif
+    constexpr bool kKeyCol = MISSLAP_TILED_KEYCOL && MODE == 0 && kCS == 1 && !F::kG;
+    int sg[kTileRows];  // position of the lane's best element (kKeyCol: its column, from behind the tile loop on) ...
     // ... and its column and cost.  They are NOT updated per element (two more selects in the inner loop): after a step
     // that moved sg the winner is picked from the step's registers (see `note_best`).  Re-reading them at the end through
     // the position -- two random 4-byte reads per bidder into the tile-major arrays -- pulled 51 MB of lines per full
@@ -637,7 +650,7 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
         sv[j] = ninf;
         sw[j] = ninf;
         sg[j] = -1;
-        scol[j] = 0;
+        scol[j] = kKeyCol ? -1 : 0;  // (kKeyCol: "no element yet", like sg)
         scost[j] = VT(0);
         wtile[j] = -1;
         wslot8[j] = 0;
@@ -929,7 +942,7 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
                                                 (F::kG ? ((v > sv[j]) | ((v == sv[j]) & (q > sg[j]))) : (v >= sv[j]));  // :351
                                 sw[j] = __builtin_fmax(sw[j], __builtin_fmin(v, sv[j]));      // :353 / :357-358
                                 sv[j] = __builtin_fmax(sv[j], v);
-                                sg[j] = ge ? q : sg[j];
+                                if (!kKeyCol) sg[j] = ge ? q : sg[j];
                                 if (kCS == 1 && ABL == 0) {
                                     scost[j] = ge ? vb : scost[j];
                                     sslot = ge ? (int)(h ? e_cur.c[jj][d] >> 16 : e_cur.c[jj][d] & 0xffffu) : sslot;
@@ -1020,6 +1033,10 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
     // overflow edges (see k_ovf_count): lane gl of a person's group takes entries gl, gl + kGL, ... of its list; the price
     // comes from memory (the table the tiles were filled from), the update is the same with the tie rule spelled out
     // -- these edges are met out of stored order, so among equal values the later stored POSITION must win (:351)
+    if (kKeyCol) {
+#pragma unroll
+        for (int j = 0; j < kTileRows; ++j) sg[j] = scol[j];  // from here on the key of the tie rule is the column
+    }
     if (ABL == 0 && !loader) {
         if (t == 0 && ta.ovf_cap != 2 * kGL * kTileDepth) atomicOr(&a.ctl->err, kErrLdsBase);
         // (four persons at a time: with eight persons per lane group the lists of all of them together would not fit
@@ -1055,7 +1072,7 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
                 for (int jj = 0; jj < kOB; ++jj) en[jj] = ta.ovf[oi[jj] < oe[jj] ? oi[jj] : 0];
 #pragma unroll
                 for (int jj = 0; jj < kOB; ++jj) {
-                    q[jj] = en[jj].x;
+                    q[jj] = kKeyCol ? en[jj].y : en[jj].x;  // the key that orders equal values: position (kKeyCol: column)
                     if constexpr (F::kF64) vb[jj] = __hiloint2double(en[jj].w, en[jj].z);
                     else vb[jj] = en[jj].z;
                     pr[jj] = a.price[en[jj].y];

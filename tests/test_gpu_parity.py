@@ -1205,11 +1205,38 @@ def test_ece_pass_equals_the_reference_loop_at_every_phase_end(label, spec, prob
     # ... and the fused final pass: eCE, objective, validity flags from ONE scan
     sol = g.finish()
     assert g.gpu["tiled_active"] == int(label.startswith("tiled"))
+    if label == "tiled_dups":  # a repeated column: the tie rule needs the stored index (formats 0 / 1 order ties by column)
+        assert g.gpu["tiled_format"] == 2
     ref = orc.auction_solve(loc=loc, val=val.copy(), problem=prob, cardinality_check=False, max_iter=10**7)
     assert np.array_equal(sol, ref["sol"]) and g.meta["eCE"] == ref["meta"]["eCE"] == 1
     assert g.meta["soln_found"] == ref["meta"]["soln_found"] and g.gpu["obj_f64"] == ref["extra"]["obj_f64"]
     n = int(loc[:, 0].max()) + 1  # benchmarking.py:56-64 with size = number of rows
     assert g.gpu["complete_assignment"] == (np.unique(sol).size == n, True, bool((sol < n).all())) and g.gpu["valid_assignment"]
+
+
+@pytest.mark.parametrize("f64", [False, True])
+@pytest.mark.parametrize("shape", [None, 8, 9])
+def test_repeated_entries_on_the_engine_round_by_round(shape, f64, gpu_lib):
+    """Rows that store an entry more than once (ascending columns, not strictly; equal AND different values under the
+    same column, integer costs: ties everywhere): formats 0 / 1 of the tile-major copy order equal values by column,
+    which needs unique columns, so the ingest must send such input to the stored-index formats -- full state vs the
+    oracle, engine forced for every grid round."""
+    spec = dict(kind="dups", n=4000, density=0.004, ints=4, adjacent=True)
+    loc, val = cases.synth_inputs(spec)
+    kw = dict(tiled_shape=shape) if shape else {}
+    for r in [1, 2, 3, 5, 8, 13, 30, 80]:
+        o = orc.from_sparse(loc, val.copy(), problem="max", max_iter=r, cardinality_check=False)
+        o.solve()
+        so = o.state()
+        g = from_sparse(loc, val.copy(), problem="max", max_iter=r, cardinality_check=False, tail_threshold=0,
+                        tiled_min_k=1, engine=1, force_f64=f64, **kw)
+        g.solve()
+        assert g.gpu["tiled_active"] == 1 and g.gpu["tiled_format"] == (3 if f64 else 2)
+        sg = g.state()
+        assert sg["its"] == so["its"] and sg["K"] == so["K"], r
+        assert np.array_equal(sg["U"], so["U"]), r
+        assert np.array_equal(sg["p"].view(np.uint64), so["p"].view(np.uint64)), r
+        assert np.array_equal(sg["p2o"], so["p2o"]) and np.array_equal(sg["o2p"], so["o2p"]), r
 
 
 @pytest.mark.parametrize("thr", [None, 0, 16])

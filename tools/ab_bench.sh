@@ -1,8 +1,8 @@
 #!/bin/bash
-# A/B of library builds through bench.py (C3, 3 steps, no CPU leg): bash tools/ab_bench.sh <outdir> <lib name>...
+# A/B of library builds through bench.py (C3 or $CFG, 3 steps, no CPU leg): [CFG=C2] bash tools/ab_bench.sh <outdir> <lib name>...
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/$1; shift; mkdir -p "$O"
 for n in "$@"; do
-  MISSLAP_LIB=$R/build_ab/lib_$n.so timeout -k 10 240 python3 $R/bench.py --no-cpu --steps 3 > "$O/$n.json" 2> "$O/$n.err"; rc=$?
+  MISSLAP_LIB=$R/build_ab/lib_$n.so timeout -k 10 240 python3 $R/bench.py --no-cpu --steps 3 --config ${CFG:-C3} > "$O/$n.json" 2> "$O/$n.err"; rc=$?
   python3 - "$O/$n.json" "$n" <<'PY'
 import json, sys
 try:
