@@ -31,7 +31,7 @@ for seed in range(first, first + count):
         loc, val = synth.shuffle_within_rows(loc, val, seed)
     kw = dict(problem=prob, cardinality_check=False, max_iter=int(r.choice([10**8, 10**8, 10**8, 900, 37])),
               eps_start=float(r.choice([0.0, 0.0, 1.0])))
-    gpu = dict(tail_threshold=[None, 0, 17, 200][seed % 4], tiled_min_k=[None, 1, -1][seed % 3],
+    gpu = dict(tail_threshold=[None, 0, 17, 200][seed % 4], tiled_min_k=[None, 1, -1][seed % 3], shard_min_k=[-1, None, -1][(seed // 3) % 3],
                rounds_per_sync=[None, 1, 4][(seed // 2) % 3], cand=[None, None, False][(seed // 3) % 3])
     if gpu["tiled_min_k"] == 1:
         gpu["engine"] = 1
