@@ -10,9 +10,14 @@ MISSLAP_API int misslap_debug_time_bid(misslap_solver *h, int32_t mode, int32_t 
     if (!h || !ms_avg || reps <= 0) return fail(MISSLAP_ERR_INVALID, "bad argument");
     if (!h->f32) return fail(MISSLAP_ERR_STATE, "ablation kernels are instantiated for the 8 B/edge layout only");
     HIP_TRY(hipSetDevice(h->device));
-    if (mode >= 10) {  // LDS-tiled kernel, shape 0: 10 complete, 11 no fill, 12 no arithmetic, 13 no edge loads
-        if (!h->tiled_ok || (h->tiled_shape != 3 && mode != 10))  // the ablations are instantiated for shape 3
-            return fail(MISSLAP_ERR_STATE, "tiled ablations need tiled_shape 3");
+    // mode | 0x100: COLD -- 1 GiB of other data is written between the launches and every launch is timed on its own (a
+    // full scan's 260 MB of edges + tables fit the 256 MB of MALL: back to back they never come from HBM)
+    const bool cold = (mode & 0x100) != 0;
+    mode &= 0xff;
+    if (mode >= 10) {  // LDS-tiled kernel: 10 complete, 11 no fill, 12 no arithmetic, 13 no edge loads ... (shape 3: one
+                       // loader); 20 / 21 / 22 / 27: complete / no fill / no arithmetic / half fill in the PRODUCTION shape 0
+        if (!h->tiled_ok || (mode < 20 && h->tiled_shape != 3 && mode != 10) || (mode >= 20 && h->tiled_shape != 0))
+            return fail(MISSLAP_ERR_STATE, "tiled ablations 11-17 need tiled_shape 3, 20-27 tiled_shape 0");
         const hipFuncAttribute at = hipFuncAttributeMaxDynamicSharedMemorySize;
         const int ldsb = (int)tiled_lds_bytes(kTiledShapes[h->tiled_shape][4]);
         HIP_TRY(hipFuncSetAttribute((const void *)k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 1, 1>, at, ldsb));
@@ -21,6 +26,10 @@ MISSLAP_API int misslap_debug_time_bid(misslap_solver *h, int32_t mode, int32_t 
         HIP_TRY(hipFuncSetAttribute((const void *)k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 1, 4>, at, ldsb));
         HIP_TRY(hipFuncSetAttribute((const void *)k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 1, 5>, at, ldsb));
         HIP_TRY(hipFuncSetAttribute((const void *)k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 1, 6>, at, ldsb));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 1, 7>, at, ldsb));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 3, 1>, at, ldsb));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 3, 2>, at, ldsb));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 3, 7>, at, ldsb));
         RoundArgs a = round_args(h);
         a.launch_edges = nullptr;
         TiledArgs ta{h->tiled, h->tcol, h->seg4, h->T, 1, h->n_tiled,
@@ -44,16 +53,40 @@ MISSLAP_API int misslap_debug_time_bid(misslap_solver *h, int32_t mode, int32_t 
                 case 14: hipLaunchKernelGGL((k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 1, 4>), g, b, ldsb, h->stream, a, ta); break;
                 case 15: hipLaunchKernelGGL((k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 1, 5>), g, b, ldsb, h->stream, a, ta); break;
                 case 16: hipLaunchKernelGGL((k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 1, 6>), g, b, ldsb, h->stream, a, ta); break;
+                case 17: hipLaunchKernelGGL((k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 1, 7>), g, b, ldsb, h->stream, a, ta); break;
+                case 20: hipLaunchKernelGGL((k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 3, 0>), g, b, ldsb, h->stream, a, ta); break;
+                case 21: hipLaunchKernelGGL((k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 3, 1>), g, b, ldsb, h->stream, a, ta); break;
+                case 22: hipLaunchKernelGGL((k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 3, 2>), g, b, ldsb, h->stream, a, ta); break;
+                case 27: hipLaunchKernelGGL((k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 3, 7>), g, b, ldsb, h->stream, a, ta); break;
                 default: hipLaunchKernelGGL((k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 1, 3>), g, b, ldsb, h->stream, a, ta); break;
             }
         };
         launch_t();
-        HIP_TRY(hipEventRecord(t0, h->stream));
-        for (int r = 0; r < reps; ++r) launch_t();
-        HIP_TRY(hipEventRecord(t1, h->stream));
-        HIP_TRY(hipEventSynchronize(t1));
+        HIP_TRY(hipGetLastError());
         float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, t0, t1));
+        if (cold) {
+            void *flush = nullptr;
+            const size_t flush_bytes = (size_t)1 << 30;
+            HIP_TRY(hipMalloc(&flush, flush_bytes));
+            for (int r = 0; r < reps; ++r) {
+                HIP_TRY(hipMemsetAsync(flush, r, flush_bytes, h->stream));
+                HIP_TRY(hipEventRecord(t0, h->stream));
+                launch_t();
+                HIP_TRY(hipEventRecord(t1, h->stream));
+                HIP_TRY(hipEventSynchronize(t1));
+                float one = 0.f;
+                HIP_TRY(hipEventElapsedTime(&one, t0, t1));
+                ms += one;
+            }
+            (void)hipFree(flush);
+        } else {
+            HIP_TRY(hipEventRecord(t0, h->stream));
+            for (int r = 0; r < reps; ++r) launch_t();
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(t1, h->stream));
+            HIP_TRY(hipEventSynchronize(t1));
+            HIP_TRY(hipEventElapsedTime(&ms, t0, t1));
+        }
         *ms_avg = ms / (float)reps;
         (void)hipEventDestroy(t0);
         (void)hipEventDestroy(t1);

@@ -628,7 +628,7 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
 #ifndef MISSLAP_TILED_KEYCOL
 #define MISSLAP_TILED_KEYCOL 1  // (0: positions in every format -- A/B builds)
 #endif
-    constexpr bool kKeyCol = MISSLAP_TILED_KEYCOL && MODE == 0 && kCS == 1 && !F::kG;
+    constexpr bool kKeyCol = MISSLAP_TILED_KEYCOL && MODE == 0 && kCS == 1 && !F::kG && ABL == 0;  // (the ablations carry no column)
     int sg[kTileRows];  // position of the lane's best element (kKeyCol: its column, from behind the tile loop on) ...
     // ... and its column and cost.  They are NOT updated per element (two more selects in the inner loop): after a step
     // that moved sg the winner is picked from the step's registers (see `note_best`).  Re-reading them at the end through
@@ -682,7 +682,7 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
         double *dst = s_price + (kDouble ? (tile & 1) : 0) * kBufDoubles;
 #pragma unroll 4
         for (int piece = first; piece < kPieces; piece += stride)
-            if (ABL != 1)
+            if (ABL != 1 && !(ABL == 7 && (piece & 1)))  // (7: every other piece -- what half the fill bytes would be worth)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc + piece * 128),
                                                  (__attribute__((address_space(3))) void *)(dst + piece * 128), 16, 0,
                                                  0);
@@ -1227,7 +1227,7 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
     for (int j = 0; j < kTileRows; ++j) {
         const int pj = max(person[j], 0);
         if constexpr (kCS == 1) {  // `mine` is the lane that met the best edge
-            bcol[j] = scol[j];
+            bcol[j] = ABL == 0 ? scol[j] : pj % a.n_cols;  // (ablations carry no column: spread the atomics like real bids)
             bcost[j] = scost[j];
         } else {         // any workgroup of the slice may hold it: through its position (unconditional loads, used under `mine`)
             bcol[j] = ta.tcol[max(G[j], 0)];
@@ -1263,7 +1263,7 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
     if (lane == 0) {
         s_e[t >> 6] = edges;
         s_n[t >> 6] = nb;
-        if (err) atomicOr(&a.ctl->err, err);
+        if (err && ABL == 0) atomicOr(&a.ctl->err, err);  // (an ablation's bids are garbage: 3 328 atomics on one word would be its timing)
     }
     __syncthreads();
     if (t == 0) {

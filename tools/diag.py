@@ -18,10 +18,22 @@ names = {0: "complete", 1: "no_gather", 2: "no_reduce", 3: "stream_only"}
 if "--tiled-ablate" in sys.argv:
     s3 = AuctionSolver.from_device_pointers(dl.data_ptr(), dv.data_ptr(), nnz, problem="max", max_iter=10**8, tiled_shape=3)
     for mode, nm in ((10, "complete"), (11, "no_fill"), (12, "no_lookup_no_arith"), (15, "lookup_no_arith"), (16, "arith_no_lookup"),
-                     (13, "no_edge_loads"), (14, "no_barriers"), (10, "complete2")):
+                     (13, "no_edge_loads"), (14, "no_barriers"), (17, "half_fill"), (10, "complete2")):
         ms = C.c_float()
         _lib.check(_lib.load_diag().misslap_debug_time_bid(s3._h, mode, 20, C.byref(ms)))
         out["tiled_" + nm + "_us"] = round(ms.value * 1e3, 1)
+    # the production shape (three loader wavefronts), back to back and COLD (1 GiB written between the launches: a scan's
+    # 260 MB fit the MALL, back to back they never come from HBM)
+    for cold, tag in ((0, "hot"), (0x100, "cold")):
+        for mode, nm in ((20, "complete"), (21, "no_fill"), (22, "no_lookup_no_arith"), (27, "half_fill"), (20, "complete2")):
+            ms = C.c_float()
+            _lib.check(_lib.load_diag().misslap_debug_time_bid(s._h, mode | cold, 20, C.byref(ms)))
+            out[f"shape0_{tag}_{nm}_us"] = round(ms.value * 1e3, 1)
+        if tag == "hot":
+            for mode, nm in ((10, "complete"), (17, "half_fill"), (12, "no_lookup_no_arith")):
+                ms = C.c_float()
+                _lib.check(_lib.load_diag().misslap_debug_time_bid(s3._h, mode | 0x100, 20, C.byref(ms)))
+                out[f"shape3_cold_{nm}_us"] = round(ms.value * 1e3, 1)
     print(json.dumps(out, indent=1))
     sys.exit(0)
 for mode in (0, 1, 2, 3, 0):
