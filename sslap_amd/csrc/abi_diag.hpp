@@ -6,6 +6,17 @@
 // Diagnostics: average duration (ms) of `reps` launches of an ablated full-scan bid kernel over the
 // current unassigned list (K == n_rows right after create).  mode: 0 complete, 1 no price gather,
 // 2 no cross-lane reduction, 3 edge stream only.  Results are discarded; solver state is untouched.
+namespace {
+__global__ __launch_bounds__(256) void k_flush_read(const uint4 *src, size_t n16, unsigned *sink) {  // plain loads: the lines stay cached, clean
+    unsigned acc = 0;
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n16; k += (size_t)gridDim.x * 256) {
+        const uint4 v = src[k];
+        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (acc == 0x9e3779b9u) *sink = acc;
+}
+}  // namespace
+
 MISSLAP_API int misslap_debug_time_bid(misslap_solver *h, int32_t mode, int32_t reps, float *ms_avg) {
     if (!h || !ms_avg || reps <= 0) return fail(MISSLAP_ERR_INVALID, "bad argument");
     if (!h->f32) return fail(MISSLAP_ERR_STATE, "ablation kernels are instantiated for the 8 B/edge layout only");
@@ -65,11 +76,16 @@ MISSLAP_API int misslap_debug_time_bid(misslap_solver *h, int32_t mode, int32_t 
         HIP_TRY(hipGetLastError());
         float ms = 0.f;
         if (cold) {
+            // (evicted by READS of other data: a memset would leave 256 MB of dirty lines whose write-back the timed scan
+            // would pay for)
             void *flush = nullptr;
             const size_t flush_bytes = (size_t)1 << 30;
-            HIP_TRY(hipMalloc(&flush, flush_bytes));
+            HIP_TRY(hipMalloc(&flush, flush_bytes + 64));
+            HIP_TRY(hipMemsetAsync(flush, 0, flush_bytes + 64, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
             for (int r = 0; r < reps; ++r) {
-                HIP_TRY(hipMemsetAsync(flush, r, flush_bytes, h->stream));
+                hipLaunchKernelGGL(k_flush_read, dim3(2048), dim3(256), 0, h->stream, (const uint4 *)flush, flush_bytes / 16,
+                                   (unsigned *)((char *)flush + flush_bytes));
                 HIP_TRY(hipEventRecord(t0, h->stream));
                 launch_t();
                 HIP_TRY(hipEventRecord(t1, h->stream));
