@@ -512,7 +512,7 @@ def run_rank(args, rank, world, local_rank, ranks, comm, shared, backend):
             tj = json.load(open(tpath))
             traffic_meta = dict(traffic_commit=tj.get("commit"), traffic_source_sha256=tj.get("source_sha256"),
                                 traffic_file=os.path.relpath(tpath, ROOT))
-            # (the bid instance of the full-scan engine: template arguments <..., MODE, kFmt> with MODE = 0; MODE 1 is the
+            # (the bid instance of the full-scan engine: template argument 10 of <..., MODE, kFmt, kP32> is MODE = 0; MODE 1 is the
             # eCE pass.  The gather engine: the instance with the most bytes, i.e. the one that does the full scans)
             def is_bid_instance(k):
                 if (rk_name + "<") not in k:
@@ -520,7 +520,7 @@ def run_rank(args, rank, world, local_rank, ranks, comm, shared, backend):
                 if rk_name != "k_bid_tiled":
                     return True
                 targs = k[k.index("<") + 1:k.rindex(">")].split(",")
-                return len(targs) >= 2 and targs[-2].strip() == "0"
+                return len(targs) >= 10 and targs[9].strip() == "0"  # <threads, rows, batch, depth, cols, loaders, ABL, lanes, split, MODE, ...>
             tk = sorted(((k, v) for k, v in tj["kernels"].items() if is_bid_instance(k)),
                         key=lambda kv: -(kv[1]["read_avg"] + kv[1]["write_avg"]) * kv[1]["launches"])
             if tk and tj.get("source_sha256") == source_digest():

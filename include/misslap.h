@@ -152,7 +152,10 @@ typedef struct misslap_meta {
     int32_t phases_with_lines;   /* eps-phases of the solve that ran WITH candidate lines (all of them unless eps fell below
                                     the rounding error of a price update on the way: see misslap_create) */
     int32_t eps_phases;          /* eps-phases of the solve (nreductions + 1 when it ran to its end) */
-    int32_t reserved_j;
+    int32_t filter_undecided;    /* -1: the full-scan engine's scans are exact.  >= 0: they run as fp32-tile FILTER scans
+                                    (opt-in, MISSLAP_TILED_P32=1: price tiles in single precision, the two best edges of a
+                                    row confirmed exactly) and this many bids of the solve were handed to the exact scan
+                                    because the rounding margin could not separate a row's second and third value */
 } misslap_meta;
 
 /* Snapshot of the round state (tests / multi-GPU driver). */

@@ -47,7 +47,7 @@ class Meta(C.Structure):
         ("tail_stats", C.c_double * 12),
         ("complete_assignment", C.c_int32), ("valid_assignment", C.c_int32), ("lines_active", C.c_int32),
         ("reserved_i", C.c_int32), ("sharded_rounds", C.c_int64),
-        ("tiled_format", C.c_int32), ("phases_with_lines", C.c_int32), ("eps_phases", C.c_int32), ("reserved_j", C.c_int32),
+        ("tiled_format", C.c_int32), ("phases_with_lines", C.c_int32), ("eps_phases", C.c_int32), ("filter_undecided", C.c_int32),
     ]
 
 

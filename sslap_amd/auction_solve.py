@@ -224,6 +224,7 @@ class AuctionSolver:
                  cand_hits=int(m.cand_hits), cand_edges=int(m.cand_edges), lines_active=int(m.lines_active),
                  sharded_rounds=int(m.sharded_rounds), tiled_format=int(m.tiled_format),
                  phases_with_lines=int(m.phases_with_lines), eps_phases=int(m.eps_phases),
+                 filter_undecided=int(m.filter_undecided),
                  # validity of the assignment as the reference's benchmark harness forms it (benchmarking.py:56-64),
                  # reduced on the device: (np.unique(sol).size == N, (sol >= 0).all(), (sol < N).all()), and
                  # (mat[arange(N), sol] >= 0).all()

@@ -304,6 +304,9 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
                         MISSLAP_FOR_TILED_SHAPES(X)
 #undef X
                     }
+                    HIP_TRY(hipFuncSetAttribute((const void *)MISSLAP_BID_KERNEL_P32(4), at, (int)tiled_lds_bytes(kTileColsHalf)));
+                    HIP_TRY(hipFuncSetAttribute((const void *)MISSLAP_BID_KERNEL_P32(8), at, (int)tiled_lds_bytes(kTileColsHalf)));
+                    HIP_TRY(hipFuncSetAttribute((const void *)MISSLAP_BID_KERNEL_P32(16), at, (int)tiled_lds_bytes(kTileColsHalf)));
                     switch (check_lanes(h)) {  // the check pass on the same engine (launch_rows_all)
 #define X(GL)                                                                                                        \
     case GL:                                                                                                         \
@@ -350,6 +353,15 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
                 blk.want(&h->pmax_bits, 1);
                 h->cmax32 = (float)max_abs_d;
             }
+            // the fp32-tile filter scans of the full-scan engine (kernels_tiled.hpp, kP32; opt-in): format 0 in the
+            // production shapes, costs of ordinary magnitude
+            const char *pe = std::getenv("MISSLAP_TILED_P32");
+            const bool p32_shape = h->tiled_shape == 0 || h->tiled_shape == 8 || h->tiled_shape == 9;
+            if (pe && pe[0] == '1' && h->tiled_ok && h->tiled_fmt == 0 && p32_shape && range_ok) {
+                blk.want(&h->tprice32, Mpad + 256);
+                blk.want(&h->und_list, N);
+                h->cmax32 = (float)max_abs_d;
+            }
         }
         h->line_maintenance = cand_mode != 2;
         if (cand_mode != 1) {  // candidate lines (cand_mode 1: off -- A/B timing, parity tests, the precision guard)
@@ -391,6 +403,7 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
         if ((rc = blk.commit(&h->blocks.back()))) return rc;
     }
     HIP_TRY(hipMemsetAsync(h->price, 0, sizeof(double) * Mpad, h->stream));
+    if (h->tprice32) HIP_TRY(hipMemsetAsync(h->tprice32, 0, sizeof(float) * (Mpad + 256), h->stream));  // = the prices: all zero
     HIP_TRY(hipMemsetAsync(h->bid_rec, 0, sizeof(int4) * kRoundSmallMax, h->stream));
     HIP_TRY(hipMemsetAsync(h->wg_stats, 0, sizeof(unsigned long long) * kStatWords * (size_t)h->wg_stats_slots, h->stream));
     if (h->split_cnt) HIP_TRY(hipMemsetAsync(h->split_cnt, 0, sizeof(int) * ((size_t)N / 256 + 1024), h->stream));

@@ -54,6 +54,7 @@ RoundArgs round_args(misslap_solver *h) {
     a.price32 = nullptr;  // (set by launch_bid for the launches that scan through the filter)
     a.pmax_bits = h->pmax_bits;
     a.cmax = h->cmax32;
+    a.tprice32 = h->tprice32;
     return a;
 }
 
@@ -253,7 +254,29 @@ int launch_bid_tiled(misslap_solver *h) {
     }
     const size_t lds = tiled_lds_bytes(shp[4]);
     const dim3 g((unsigned)grid);
-    if (h->tiled_fmt == 0) {
+    if (h->tprice32 && h->tiled_fmt == 0) {
+        // fp32-tile filter scan (kernels_tiled.hpp, kP32): the mirror is current (rebuilt here if a kernel that does not
+        // keep it has written prices since), the scan decides what the rounding margin lets it decide, the exact scan of
+        // the persons it hands over follows in the same stream -- and inside the same pair of events
+        if (!h->tmirror_valid) {
+            MISSLAP_LAUNCH_PLAIN(h, k_tile_mirror, dim3(std::min(blocks_for(h->n_cols, 1024), 4 * h->n_cus)), dim3(1024), 0,
+                                 (const double *)h->price, h->tprice32, h->n_cols);
+            h->tmirror_valid = true;
+        }
+        HIP_TRY(stream_memset(h, &h->ctl->n_und, 0, sizeof(int)));
+        ta.price32 = h->tprice32;
+        ta.und = h->und_list;
+        ta.cmax = h->cmax32;
+        if (pr) (void)hipEventRecord(pr->start, h->stream);
+        switch (shp[6]) {
+            case 4: MISSLAP_LAUNCH_PLAIN(h, (MISSLAP_BID_KERNEL_P32(4)), g, dim3(1024), lds, a, ta); break;
+            case 8: MISSLAP_LAUNCH_PLAIN(h, (MISSLAP_BID_KERNEL_P32(8)), g, dim3(1024), lds, a, ta); break;
+            default: MISSLAP_LAUNCH_PLAIN(h, (MISSLAP_BID_KERNEL_P32(16)), g, dim3(1024), lds, a, ta); break;
+        }
+        MISSLAP_LAUNCH_PLAIN(h, (k_bid_undecided<EdgesF32>), dim3(std::min(64, h->n_cus)), dim3(kBidBlock), 0, a, EdgesF32{h->edges32},
+                             (const int2 *)h->und_list);
+        if (pr) (void)hipEventRecord(pr->stop, h->stream);
+    } else if (h->tiled_fmt == 0) {
         switch (h->tiled_shape) {
 #define X(I, TH, R, B, D, TC, LD, GL, CS) \
     case I:                                                                                                            \
@@ -294,6 +317,7 @@ int launch_bid(misslap_solver *h) {
     h->ctl_fresh = false;
     // (not behind a full-scan engine launch: the engines always feed best_key, which k_round_small ignores)
     h->round_small = use_round_small(h) && !(h->tiled_ok && h->K_ub >= h->tiled_min_K);
+    if (h->round_small) h->tmirror_valid = false;  // (k_round_small / k_round_fused write prices without the engine's fp32 mirror)
     if (h->tiled_ok && h->K_ub >= h->tiled_min_K) {
         int rc = launch_bid_tiled(h);  // no-op on the device when K < tiled_min_K
         if (rc) return rc;
@@ -424,6 +448,7 @@ int launch_apply(misslap_solver *h) {
 int launch_tail(misslap_solver *h) {
     if (h->thr <= 0) return MISSLAP_OK;
     h->ctl_fresh = false;
+    h->tmirror_valid = false;  // (the tail kernels write prices without the engine's fp32 mirror)
     // Rows of a few hundred edges keep no lines until the solve has shown that its tail is long: that many tail rounds
     // (a tail round without a line is a row scan by one wavefront, 1.5-4 us at 300-1000 edges; the pass that builds the
     // lines of every row costs milliseconds at C4's 100 000 rows and pays for itself within a phase at a dense

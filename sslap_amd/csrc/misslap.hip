@@ -274,8 +274,9 @@ MISSLAP_API int misslap_phase_end(misslap_solver *h, int32_t *finished) {
         } else {
             h->eps = h->eps * h->theta;  // :283 (fp32 product)
             MISSLAP_LAUNCH(h, k_reset_phase, (F_k_reset_phase), 256, dim3(blocks_for(h->n_rows > h->n_cols ? h->n_rows : h->n_cols, 256)),
-                           dim3(256), h->ctl, h->p2o, h->o2p, h->rec, h->U, h->n_rows, h->n_cols);
+                           dim3(256), h->ctl, h->p2o, h->o2p, h->rec, h->U, h->n_rows, h->n_cols, (const double *)h->price, h->tprice32);
             HIP_TRY(hipGetLastError());
+            h->tmirror_valid = true;  // (k_reset_phase has rebuilt the fp32 mirror of the prices, if the handle keeps one)
             h->live_valid = false;  // (K was changed by a launch without a ticket; the mirror below is current)
             h->nreductions += 1;  // :292
             h->K_ub = h->n_rows;
@@ -385,6 +386,7 @@ MISSLAP_API int misslap_finish(misslap_solver *h, int32_t *person_to_object_out,
     meta->tiled_format = h->tiled_ok ? h->tiled_fmt : 0;
     meta->phases_with_lines = h->phases_with_lines;
     meta->eps_phases = h->phases_run;
+    meta->filter_undecided = h->tprice32 ? (int32_t)std::min<unsigned long long>(c.und_total, 0x7fffffffull) : -1;
     if (h->profile && h->prof_used) {
         std::vector<unsigned long long> le(2 * (size_t)h->launch_idx);
         if (h->launch_idx)

@@ -34,7 +34,7 @@ def test_struct_layouts_match_header():
     fields = {"misslap_options": ["max_iter", "tail_threshold", "rounds_per_sync", "tiled_min_K", "cand_mode",
                                   "cand_refresh_min", "reserved", "input_stream"],
               "misslap_meta": ["struct_size", "start_eps", "its", "obj_f64", "edges_scanned", "bid_ms", "tail_edges", "tiled_min_K", "bid_edges_read", "fullscan_edges_read", "shard_edges", "cand_hits", "tail_stats",
-                               "complete_assignment", "valid_assignment", "lines_active", "sharded_rounds", "tiled_format", "phases_with_lines", "eps_phases"],
+                               "complete_assignment", "valid_assignment", "lines_active", "sharded_rounds", "tiled_format", "phases_with_lines", "eps_phases", "filter_undecided"],
               "misslap_status": ["K", "error_bits", "rounds_per_sync", "shard_min_K"]}
     prog = ['#include <stdio.h>', '#include <stddef.h>', '#include "misslap.h"', 'int main(void){']
     for s, fs in fields.items():

@@ -968,7 +968,7 @@ def test_abi1_caller_is_still_served(gpu_lib):
     class MetaV1(C.Structure):
         _fields_ = [f for f in _lib.Meta._fields_[2:] if f[0] not in ("complete_assignment", "valid_assignment",
                                                                      "lines_active", "reserved_i", "sharded_rounds", "tiled_format",
-                                                                     "phases_with_lines", "eps_phases", "reserved_j")]
+                                                                     "phases_with_lines", "eps_phases", "filter_undecided")]
     assert C.sizeof(OptionsV1) == 88 and C.sizeof(MetaV1) == 376
     loc, val = synth.gen_sparse(1200, 1200, 0.02, seed=3)
     ref = orc.auction_solve(loc=loc, val=val.copy(), problem="max", cardinality_check=False)
@@ -1237,6 +1237,56 @@ def test_repeated_entries_on_the_engine_round_by_round(shape, f64, gpu_lib):
         assert np.array_equal(sg["U"], so["U"]), r
         assert np.array_equal(sg["p"].view(np.uint64), so["p"].view(np.uint64)), r
         assert np.array_equal(sg["p2o"], so["p2o"]) and np.array_equal(sg["o2p"], so["o2p"]), r
+
+
+@pytest.mark.parametrize("shape", [None, 8, 9])
+@pytest.mark.parametrize("spec,prob,few_undecided", [
+    (dict(kind="sparse", n=6000, m=40000, density=0.001), "max", True),           # 3 column tiles, rectangular, float costs
+    (dict(kind="sparse", n=4200, m=12000, density=0.01), "min", True),            # long segments: overflow lists
+    (dict(kind="sparse", n=5000, m=5000, density=0.01, ints=6), "max", False),    # ties at the top everywhere: the exact scan decides
+    (dict(kind="sparse", n=4500, m=33000, density=0.0012, ints=3), "min", False), # ties across tiles
+    (dict(kind="single", n=3000, density=0.01, n_single=60), "max", True),        # one-entry rows: +inf bids, infinite prices
+])
+def test_fp32_tile_filter_scan_round_by_round(spec, prob, few_undecided, shape, gpu_lib, monkeypatch):
+    """The full-scan engine as a FILTER scan (MISSLAP_TILED_P32=1, kernels_tiled.hpp kP32: price tiles in single
+    precision from an fp32 mirror of the prices; a lane group keeps its three largest fp32 values, the two best edges are
+    confirmed with exact prices when the rounding margin separates the second from the third, everybody else goes to
+    the exact wave-per-row scan behind it), forced for every grid round: full state vs the oracle."""
+    monkeypatch.setenv("MISSLAP_TILED_P32", "1")
+    loc, val = cases.synth_inputs(spec)
+    kw = dict(tiled_shape=shape) if shape else {}
+    for r in [1, 2, 3, 5, 8, 13, 21, 40, 80, 200]:
+        o = orc.from_sparse(loc, val.copy(), problem=prob, max_iter=r, cardinality_check=False)
+        o.solve()
+        so = o.state()
+        g = from_sparse(loc, val.copy(), problem=prob, max_iter=r, cardinality_check=False, tail_threshold=0,
+                        tiled_min_k=1, engine=1, **kw)
+        g.solve()
+        assert g.gpu["tiled_active"] == 1 and g.gpu["tiled_format"] == 0 and g.gpu["filter_undecided"] >= 0
+        sg = g.state()
+        assert sg["its"] == so["its"] and sg["K"] == so["K"], r
+        assert np.array_equal(sg["U"], so["U"]), r
+        assert np.array_equal(sg["p"].view(np.uint64), so["p"].view(np.uint64)), r
+        assert np.array_equal(sg["p2o"], so["p2o"]) and np.array_equal(sg["o2p"], so["o2p"]), r
+    frac = g.gpu["filter_undecided"] / g.gpu["bids_made"]  # (of the last, longest run)
+    assert (frac < 0.05) if few_undecided else (frac > 0.01), (frac, g.gpu["filter_undecided"], g.gpu["bids_made"])
+
+
+@pytest.mark.parametrize("cfg", ["C2", "C3", "C4"])
+def test_fp32_tile_filter_at_baseline_sizes(cfg, golden_large, gpu_lib, monkeypatch):
+    """... and whole solves at the BASELINE sizes (tail kernels, partial rounds, phase resets: every path that keeps or
+    rebuilds the fp32 mirror): the reference's assignment hash, round count and objective."""
+    monkeypatch.setenv("MISSLAP_TILED_P32", "1")
+    g = golden_large["cases"][cfg]
+    spec, kw = cases_mod.LARGE_CASES[cfg]
+    loc, val = _config_arrays(cfg)[:2]
+    s = from_sparse(loc, val, cardinality_check=False, **kw)
+    sol = s.solve()
+    assert s.gpu["tiled_active"] == 1 and s.gpu["tiled_format"] == 0
+    assert 0 <= s.gpu["filter_undecided"] < 0.02 * s.gpu["bids_made"]
+    assert synth.sol_digest(sol) == g["sol_sha256"]
+    assert s.meta["its"] == g["meta"]["its"] and s.gpu["obj_f64"] == g["obj_f64"]
+    assert s.gpu["edges_scanned"] == g["edges_scanned"]
 
 
 @pytest.mark.parametrize("thr", [None, 0, 16])
