@@ -252,6 +252,11 @@ struct misslap_solver {
     bool round_done = false;   // the bid launch of the current round has closed it
     int cand_build_max_K = 0x7fffffff;
     int tail_round_budget = kLongRowTailBudget;
+    // No tail kernel instance runs more than so many rounds before it returns to the host (which looks at the status and
+    // launches again): a degenerate instance -- integer costs of 1e7 against eps of 1e-5 are price wars of 1e10 rounds --
+    // would otherwise sit in ONE launch for minutes (until max_iter).  ~2-4 s of rounds; MISSLAP_TAIL_LAUNCH_ROUNDS (read
+    // per create) changes it, tests use a small value.
+    int tail_launch_rounds = 1 << 22;
     int max_row_len = 0;
     long long avg_row_len = 0;
     // Lines in USE: the handle has them and its rows can keep one -- rows of at most kCandRowMax edges, or longer ones

@@ -558,6 +558,7 @@ int new_handle(misslap_solver **out, const misslap_options *opt, int abi, missla
     h->thr = opt->tail_threshold >= 0 ? opt->tail_threshold : -1;  // -1: resolved in build_from_device_coo
     h->order_partial = opt->partial_in_list_order == 0;
     if (const char *e = std::getenv("MISSLAP_APPLY_BIDDERS_RATIO")) h->apply_bidders_ratio = std::max(1, std::atoi(e));
+    if (const char *e = std::getenv("MISSLAP_TAIL_LAUNCH_ROUNDS")) h->tail_launch_rounds = std::max(1, std::atoi(e));  // (read per create)
     if (opt->cand_build_max_K > 0) h->cand_build_max_K = opt->cand_build_max_K;
     if (opt->cand_refresh_min > 0) h->cand_refresh_min = opt->cand_refresh_min - 1;
     h->rounds_per_sync = opt->rounds_per_sync > 0 ? opt->rounds_per_sync : kDefaultRoundsPerSync;

@@ -481,6 +481,7 @@ int launch_tail(misslap_solver *h) {
     a.round_budget = h->long_rows && lines && h->line_maintenance ? (budget_env > 0 ? budget_env : h->tail_round_budget)
                      : h->long_rows_later                            ? (int)std::min<long long>(std::max<long long>(long_after, 1), 1 << 30)
                                                                      : 0;
+    if (a.round_budget == 0 || a.round_budget > h->tail_launch_rounds) a.round_budget = h->tail_launch_rounds;
     a.thr = h->thr;
     a.eps = h->eps;
     ProfRec *pr = nullptr;

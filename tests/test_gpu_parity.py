@@ -1289,6 +1289,32 @@ def test_fp32_tile_filter_at_baseline_sizes(cfg, golden_large, gpu_lib, monkeypa
     assert s.gpu["edges_scanned"] == g["edges_scanned"]
 
 
+@pytest.mark.parametrize("rounds", [1, 7, 300])
+def test_tail_launches_are_bounded_in_rounds(rounds, gpu_lib, monkeypatch):
+    """No tail kernel instance runs more than MISSLAP_TAIL_LAUNCH_ROUNDS rounds (default 2^22: a degenerate instance --
+    scaled integer costs against a tiny eps -- is a price war of 1e10 rounds, and ONE launch would sit on the device until
+    max_iter); the host looks at the status and launches again.  Forced to 1 / 7 / 300 rounds per launch: the result is
+    the reference's, bit for bit, through hundreds of returns."""
+    monkeypatch.setenv("MISSLAP_TAIL_LAUNCH_ROUNDS", str(rounds))
+    for spec, prob, max_iter in [(dict(kind="sparse", n=700, m=700, density=0.02, ints=4), "max", 10**8),
+                                 (dict(kind="sparse", n=2500, m=3000, density=0.004), "min", 10**8),
+                                 (dict(kind="sparse", n=900, m=900, density=0.01, ints=11), "max", 1234)]:
+        if rounds == 1 and spec["n"] > 1000:
+            continue  # (thousands of launches: the small instances are enough for the one-round budget)
+        loc, val = cases.synth_inputs(spec)
+        if max_iter != 10**8:
+            val = np.round(val * 1e6)  # the degenerate kind: it would run for ~1e10 rounds
+        o = orc.from_sparse(loc, val.copy(), problem=prob, max_iter=max_iter, cardinality_check=False)
+        osol = o.solve()
+        so = o.state()
+        g = from_sparse(loc, val.copy(), problem=prob, max_iter=max_iter, cardinality_check=False)
+        gsol = g.solve()
+        sg = g.state()
+        assert np.array_equal(gsol, osol) and sg["its"] == so["its"] and sg["K"] == so["K"]
+        assert np.array_equal(sg["p"].view(np.uint64), so["p"].view(np.uint64)) and np.array_equal(sg["U"], so["U"])
+        assert all(g.meta[k] == o.meta[k] for k in cases.META_KEYS)
+
+
 @pytest.mark.parametrize("thr", [None, 0, 16])
 def test_falling_prices_without_lines_equal_the_reference(thr, gpu_lib):
     """Costs of ~2^50 over four binades against eps down to 0.15 / N: a price update fl(fl(c - w) + eps) rounds DOWN

@@ -39,6 +39,8 @@ for seed in range(first, first + count):
         val = np.round(val * float(r.choice([1e6, 1e8, 1e9])))
     kw = dict(problem=prob, cardinality_check=False, max_iter=int(r.choice([10**8, 10**8, 10**8, 3000, 211, 17])),
               eps_start=float(r.choice([0.0, 0.0, 1.0, 0.01])))
+    if seed % 11 == 7:  # scaled integer costs against eps ~ 1 / N: price wars of (cost unit / eps) ~ 1e10 rounds (seed 810);
+        kw["max_iter"] = min(kw["max_iter"], 200000)  # the reference would run to max_iter as well -- compare the state there
     gpu = dict(tail_threshold=[None, 0, 3, 17, 40, 200, 512][seed % 7], tiled_min_k=[None, None, 1, -1][seed % 4],
                rounds_per_sync=[None, 1, 5][seed % 3], cand_refresh=[None, None, 0, 30, 9][seed % 5],
                cand_build_max_k=[None, None, None, 50, 900][(seed // 3) % 5], order_partial=[None, False][(seed // 2) % 2],
