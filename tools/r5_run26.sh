@@ -1,4 +1,6 @@
 mkdir -p gpurun_out/r5fuzz
-timeout -k 10 500 python3 tools/fuzz_gpu.py 800 400 > gpurun_out/r5fuzz/fuzz_gpu_800_1200.txt 2>&1; tail -1 gpurun_out/r5fuzz/fuzz_gpu_800_1200.txt
-timeout -k 10 300 python3 tools/fuzz_batch.py 400 150 > gpurun_out/r5fuzz/fuzz_batch_400_550.txt 2>&1; tail -1 gpurun_out/r5fuzz/fuzz_batch_400_550.txt
-timeout -k 10 300 python3 tools/fuzz_sharded.py 120 120 > gpurun_out/r5fuzz/fuzz_sharded_120_240.txt 2>&1; tail -1 gpurun_out/r5fuzz/fuzz_sharded_120_240.txt
+for first in 1200 1600 2000; do
+  timeout -k 10 700 python3 tools/fuzz_gpu.py $first 400 > gpurun_out/r5fuzz/fuzz_gpu_${first}.txt 2>&1; tail -1 gpurun_out/r5fuzz/fuzz_gpu_${first}.txt
+done
+timeout -k 10 400 python3 tools/fuzz_batch.py 400 200 > gpurun_out/r5fuzz/fuzz_batch_400_600.txt 2>&1; tail -1 gpurun_out/r5fuzz/fuzz_batch_400_600.txt
+timeout -k 10 400 python3 tools/fuzz_sharded.py 120 180 > gpurun_out/r5fuzz/fuzz_sharded_120_300.txt 2>&1; tail -1 gpurun_out/r5fuzz/fuzz_sharded_120_300.txt
