@@ -112,6 +112,8 @@ const int kTiledShapes[kNumTiledShapes][8] = {
 // 9, i.e. {1024 threads, 4 persons per lane group, 2 in flight, 2 loads per segment, half tiles, 3 loaders} x lanes
 #define MISSLAP_BID_KERNEL_FMT(GL, FMT) k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 3, 0, GL, 1, 0, FMT>
 // ... and the fp32-tile filter scan (kP32) of format 0 in the same three shapes
+// ... and the backward walk (kRev) of the column-keyed formats 0 / 1 in the same three shapes
+#define MISSLAP_BID_KERNEL_REV(GL, FMT) k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 3, 0, GL, 1, 0, FMT, 0, 1>
 #define MISSLAP_BID_KERNEL_P32(GL) k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 3, 0, GL, 1, 0, 0, 1>
 #define MISSLAP_FOR_FMT_LANES(X) X(1, 4) X(1, 8) X(1, 16) X(2, 4) X(2, 8) X(2, 16) X(3, 4) X(3, 8) X(3, 16)
 inline size_t tiled_lds_bytes(int tile_cols) {  // see the LDS map in k_bid_tiled; + statistics scratch
@@ -287,6 +289,7 @@ struct misslap_solver {
     // fp32-tile filter scans of the full-scan engine (opt-in, MISSLAP_TILED_P32=1; kernels_tiled.hpp, kP32)
     float *tprice32 = nullptr;   // fp32 mirror of the prices, T * kTileCols + 256 entries (the fills run past a tile's end)
     int2 *und_list = nullptr;    // [n_rows] persons a filter scan could not decide
+    bool walk_rev_next = false;  // the next engine launch of this eps-phase walks the column tiles backwards (walk_backwards)
     bool tmirror_valid = true;   // no kernel that does not keep the mirror (tail kernels, small rounds) has written a price since its last rebuild
     bool ece_flag_clear = false;  // Ctl::ece_fail is 0 on the device (k_init_state, k_reset_phase) and no test has run since
     int ctl_fresh = 0;  // nothing enqueued since the last read and the pinned mirror h_ctl holds: 2 = the device's whole

@@ -304,6 +304,9 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
                         MISSLAP_FOR_TILED_SHAPES(X)
 #undef X
                     }
+                    HIP_TRY(hipFuncSetAttribute((const void *)MISSLAP_BID_KERNEL_REV(4, 0), at, (int)tiled_lds_bytes(kTileColsHalf)));
+                    HIP_TRY(hipFuncSetAttribute((const void *)MISSLAP_BID_KERNEL_REV(8, 0), at, (int)tiled_lds_bytes(kTileColsHalf)));
+                    HIP_TRY(hipFuncSetAttribute((const void *)MISSLAP_BID_KERNEL_REV(16, 0), at, (int)tiled_lds_bytes(kTileColsHalf)));
                     HIP_TRY(hipFuncSetAttribute((const void *)MISSLAP_BID_KERNEL_P32(4), at, (int)tiled_lds_bytes(kTileColsHalf)));
                     HIP_TRY(hipFuncSetAttribute((const void *)MISSLAP_BID_KERNEL_P32(8), at, (int)tiled_lds_bytes(kTileColsHalf)));
                     HIP_TRY(hipFuncSetAttribute((const void *)MISSLAP_BID_KERNEL_P32(16), at, (int)tiled_lds_bytes(kTileColsHalf)));
@@ -321,6 +324,7 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
 #define X(FMT, GL)                                                                                                   \
     case FMT * 100 + GL:                                                                                             \
         HIP_TRY(hipFuncSetAttribute((const void *)MISSLAP_BID_KERNEL_FMT(GL, FMT), at, (int)tiled_lds_bytes(kTileColsHalf)));   \
+        if (FMT == 1) HIP_TRY(hipFuncSetAttribute((const void *)MISSLAP_BID_KERNEL_REV(GL, 1), at, (int)tiled_lds_bytes(kTileColsHalf))); \
         HIP_TRY(hipFuncSetAttribute((const void *)MISSLAP_CHECK_KERNEL_FMT(GL, FMT), at, (int)tiled_lds_bytes(kTileColsHalf))); \
         break;
                         MISSLAP_FOR_FMT_LANES(X)

@@ -207,6 +207,22 @@ int status_wait(misslap_solver *h, int slot) {
     return MISSLAP_OK;
 }
 
+// Does this engine launch walk the column tiles backwards?  The first scan of an eps-phase (K = N: tail kernels lie in
+// front of it, the cache holds nothing of the copy) walks forwards, every further launch of the phase in the direction
+// opposite to the one before it.  Column-keyed formats 0 / 1 in the production shapes; MISSLAP_TILED_ALTERNATE=0: never.
+bool walk_backwards(misslap_solver *h, const int *shp) {
+    static const bool alternate = [] {
+        const char *e = std::getenv("MISSLAP_TILED_ALTERNATE");
+        return !(e && e[0] == '0');
+    }();
+    const bool can = alternate && MISSLAP_TILED_KEYCOL_ON && h->tiled_fmt <= 1 && shp[7] == 1 &&
+                     (h->tiled_shape == 0 || h->tiled_shape == 8 || h->tiled_shape == 9);
+    if (h->phase_fresh) h->walk_rev_next = false;
+    const bool rev = can && h->walk_rev_next;
+    h->walk_rev_next = !h->walk_rev_next;
+    return rev;
+}
+
 int launch_bid_tiled(misslap_solver *h) {
     h->ctl_fresh = false;
     RoundArgs a = round_args(h);
@@ -276,6 +292,20 @@ int launch_bid_tiled(misslap_solver *h) {
         MISSLAP_LAUNCH_PLAIN(h, (k_bid_undecided<EdgesF32>), dim3(std::min(64, h->n_cus)), dim3(kBidBlock), 0, a, EdgesF32{h->edges32},
                              (const int2 *)h->und_list);
         if (pr) (void)hipEventRecord(pr->stop, h->stream);
+    } else if (walk_backwards(h, shp)) {
+        // the launches of an eps-phase alternate their direction over the column tiles (kernels_tiled.hpp, kRev): this one
+        // reads first what the one before it touched last
+        const int key = h->tiled_fmt * 100 + shp[6];
+        switch (key) {
+#define X(FMT, GL) \
+    case FMT * 100 + GL:                                                                                               \
+        if (h->batch) MISSLAP_LAUNCH_PLAIN(h, (MISSLAP_BID_KERNEL_REV(GL, FMT)), g, dim3(1024), lds, a, ta);                  \
+        else MISSLAP_LAUNCH_TIMED(pr, (MISSLAP_BID_KERNEL_REV(GL, FMT)), g, dim3(1024), (unsigned)lds, h->stream, a, ta);     \
+        break;
+            X(0, 4) X(0, 8) X(0, 16) X(1, 4) X(1, 8) X(1, 16)
+#undef X
+            default: return fail(MISSLAP_ERR_STATE, "no backward instance for format %d with %d lanes per person", h->tiled_fmt, shp[6]);
+        }
     } else if (h->tiled_fmt == 0) {
         switch (h->tiled_shape) {
 #define X(I, TH, R, B, D, TC, LD, GL, CS) \

@@ -572,6 +572,10 @@ __device__ __forceinline__ T split_load(const T *p) {
 // inside the tile that holds it the edge is recognised by its 16-bit price slot, with no column arithmetic per
 // element.  No bids, no statistics; the result of a person is handled by final_person().  a.eps = the eps of the test.
 // kFmt: the record format of the tile-major copy (TileFmt; the host launches the instance of the handle's format).
+#ifndef MISSLAP_TILED_KEYCOL
+#define MISSLAP_TILED_KEYCOL 1  // (0: positions in every format -- A/B builds)
+#endif
+#define MISSLAP_TILED_KEYCOL_ON (MISSLAP_TILED_KEYCOL != 0)
 // kP32 = 1 (round 5, opt-in: MISSLAP_TILED_P32): the price tiles are SINGLE precision -- filled from the fp32 mirror
 // of the prices (TiledArgs::price32: half the L2 -> LDS fill bytes, which are more than the edge bytes of a scan) -- and
 // the scan is a FILTER: a lane keeps the three largest a = fl32(cost - p32) it meets and the column / cost of the first
@@ -582,10 +586,19 @@ __device__ __forceinline__ T split_load(const T *p) {
 // fp32 subtraction within 2^-24 |a|, and |p| <= |a| + |cost| + ...; the margin is twice that on both sides.  Otherwise
 // (ties / near-ties, fewer than two finite values) the person goes to TiledArgs::und and a wave-per-row exact scan
 // (k_bid_undecided) forms its bid.  Only for format 0, the unsplit shapes, bid scans.
-template <int kTileThreads, int kTileRows, int kTileBatch, int kTileDepth, int kTileCols, int kLoaders, int ABL = 0, int kGL = 4, int kCS = 1, int MODE = 0, int kFmt = 0, int kP32 = 0>
+template <int kTileThreads, int kTileRows, int kTileBatch, int kTileDepth, int kTileCols, int kLoaders, int ABL = 0, int kGL = 4, int kCS = 1, int MODE = 0, int kFmt = 0, int kP32 = 0, int kRev = 0>
 __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledArgs ta) {
     typedef TileFmt<kFmt> F;
     typedef typename F::VT VT;
+    // kRev = 1: the column tiles are walked from the last to the first.  Two passes over the tile-major copy in the SAME
+    // direction meet the Infinity Cache in LRU order (a scan's 257 MB against 256 MB of cache: what the first pass touched
+    // first is what its own tail has just evicted); a pass in the opposite direction reads first what the previous one
+    // touched last (back to back, C3: 73 -> 64 us).  The partial rounds of an eps-phase follow its full scan directly, so
+    // the host alternates the direction from one engine launch of a phase to the next.  A lane of a format-0 / 1 scan
+    // then meets its tiles in DESCENDING column order while ">=" orders equal values in ascending order: a step whose
+    // best merely TIES the best of the tiles walked before it (larger columns: later stored) is undone (`tie_only`).
+    static_assert(kRev == 0 || (MODE == 0 && kCS == 1 && ABL == 0 && kP32 == 0 && !F::kG && kTileCols != kTileColsBig && kLoaders > 0 && MISSLAP_TILED_KEYCOL_ON),
+                  "the backward walk: column-keyed bid scans (formats 0 / 1) of the unsplit double-buffered shapes");
     static_assert(kP32 == 0 || (MODE == 0 && kCS == 1 && kFmt == 0 && ABL == 0 && kTileCols != kTileColsBig && kLoaders > 0),
                   "the fp32-tile filter: format 0 bid scans of the unsplit double-buffered shapes");
     static_assert(kFmt == 0 || (kCS == 1 && ABL == 0), "column split and ablations exist for the 6 B/edge format only");
@@ -641,9 +654,6 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
     // within the row and monotone in the stored index -- and it travels with the best element anyway (scol).  The tile
     // loop of a bid scan therefore does not track positions at all (two instructions per element less); sg takes the
     // columns over behind the loop, and the overflow entries and the merges order equal values by it as before.
-#ifndef MISSLAP_TILED_KEYCOL
-#define MISSLAP_TILED_KEYCOL 1  // (0: positions in every format -- A/B builds)
-#endif
     constexpr bool kKeyCol = MISSLAP_TILED_KEYCOL && MODE == 0 && kCS == 1 && !F::kG && ABL == 0;  // (the ablations carry no column)
     int sg[kTileRows];  // position of the lane's best element (kKeyCol: its column, from behind the tile loop on) ...
     // ... and its column and cost.  They are NOT updated per element (two more selects in the inner loop): after a step
@@ -731,6 +741,10 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
                                                  (__attribute__((address_space(3))) void *)(dst + piece * 128), 16, 0,
                                                  0);
     };
+    auto rt = [&](int u) {  // step u of the walk -> its tile (steps past the end repeat the last one: prefetches only)
+        const int uc = min(u, t_hi - 1);
+        return kRev ? t_lo + t_hi - 1 - uc : uc;
+    };
     if (loader) {
         const int me = wave_u - (kWaves - kLoaders);
 #ifndef MISSLAP_TILED_TOUCH
@@ -759,15 +773,15 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)touch_dst, 1, 0, 0);
         };
-        if (t_lo < t_hi) dma_fill(t_lo, me, kLoaders);
-        if (MISSLAP_TILED_TOUCH > 0) touch(t_lo + 1);
+        if (t_lo < t_hi) dma_fill(rt(t_lo), me, kLoaders);
+        if (MISSLAP_TILED_TOUCH > 0) touch(rt(t_lo + 1));
         for (int tile = t_lo; tile < t_hi; ++tile) {
             // my pieces of tile `tile` have landed (a touch issued behind them may still be in flight)
             if (MISSLAP_TILED_TOUCH > 0) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (ABL != 4) __syncthreads();                    // ... and tile - 1 is no longer read
-            if (tile + 1 < t_hi) dma_fill(tile + 1, me, kLoaders);
-            if (MISSLAP_TILED_TOUCH > 0) touch(tile + 1 + MISSLAP_TILED_TOUCH);
+            if (tile + 1 < t_hi) dma_fill(rt(tile + 1), me, kLoaders);
+            if (MISSLAP_TILED_TOUCH > 0) touch(rt(tile + 1 + MISSLAP_TILED_TOUCH));
         }
         if (MISSLAP_TILED_TOUCH > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -895,13 +909,14 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
         Seg sq[kQ + 1];
         Edges eq[kE + 1];
 #pragma unroll
-        for (int k = 0; k < kQ; ++k) load_seg(t_lo + k / NBE, k % NBE, sq[k]);
+        for (int k = 0; k < kQ; ++k) load_seg(rt(t_lo + k / NBE), k % NBE, sq[k]);
 #pragma unroll
         for (int k = 0; k < kE; ++k) load_edges(sq[k], eq[k]);
         Seg &seg_cur = sq[0];
         Edges &e_cur = eq[0];
-        if (kLoaders == 0 && kDouble) dma_fill(t_lo, wave_u, kWaves);
-        for (int tile = t_lo; tile < (loader ? t_lo : t_hi); ++tile) {
+        if (kLoaders == 0 && kDouble) dma_fill(rt(t_lo), wave_u, kWaves);
+        for (int tile_u = t_lo; tile_u < (loader ? t_lo : t_hi); ++tile_u) {
+            const int tile = rt(tile_u);  // (the tile of this step of the walk)
             if (!kDouble) {
                 __syncthreads();  // every lookup of the previous tile is done
                 dma_fill(tile, wave_u, kWaves);
@@ -912,8 +927,8 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
             for (int b = 0; b < NBE; ++b) {
                 // issue: edges of step s + kE, segment entries of step s + kQ
                 load_edges(sq[kE], eq[kE]);
-                load_seg(tile + (b + kQ) / NBE, (b + kQ) % NBE, sq[kQ]);
-                if (kDouble && kLoaders == 0 && b == 0 && tile + 1 < t_hi) dma_fill(tile + 1, wave_u, kWaves);
+                load_seg(rt(tile_u + (b + kQ) / NBE), (b + kQ) % NBE, sq[kQ]);
+                if (kDouble && kLoaders == 0 && b == 0 && tile_u + 1 < t_hi) dma_fill(rt(tile_u + 1), wave_u, kWaves);
 #ifdef MISSLAP_TILED_STAMP
                 // this step's edges: everything but the loads just issued (edges of the next step + two segment entries
                 // per person of the step after it)
@@ -956,6 +971,8 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
                         const int j = b * kTileBatch + jj;
                         const int q0 = seg_s0(seg_cur, jj) + 2 * gl;
                         int sslot = -1;  // slot of the best element if it moved in this step
+                        const double sv0 = sv[j];  // (kRev) the best value and its cost before this step
+                        const VT sc0 = scost[j];
                         const int want8 = (MODE == 1 && tile == wtile[j]) ? wslot8[j] : -1;  // (MODE 1) no slot offset is negative
 #pragma unroll
                         for (int d = dlo; d < dhi; ++d) {
@@ -1020,6 +1037,11 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
                         // note_best: a person whose best element moved takes its column and cost from the registers just
                         // consumed -- element rel = 2 * kGL * d + h of my share of the segment; the slot of an edge is its
                         // column relative to the tile (+ the buffer of the tile's parity, see k_tile_scatter)
+                        if constexpr (kRev != 0) {  // a best that only TIES the one of the tiles walked before (larger columns) stays with them
+                            const bool tie_only = (sslot >= 0) & (sv[j] == sv0) & (scol[j] >= 0);
+                            scost[j] = tie_only ? sc0 : scost[j];
+                            sslot = tie_only ? -1 : sslot;
+                        }
                         if (kCS == 1 && ABL == 0) scol[j] = sslot >= 0 ? col0 + sslot : scol[j];
                     }
                 };
