@@ -524,8 +524,16 @@ def run_rank(args, rank, world, local_rank, ranks, comm, shared, backend):
             tk = sorted(((k, v) for k, v in tj["kernels"].items() if is_bid_instance(k)),
                         key=lambda kv: -(kv[1]["read_avg"] + kv[1]["write_avg"]) * kv[1]["launches"])
             if tk and tj.get("source_sha256") == source_digest():
-                traffic = round(tk[0][1]["read_avg"] + tk[0][1]["write_avg"])
-                traffic_meta["traffic_kernel"] = tk[0][0]
+                if rk_name == "k_bid_tiled":
+                    # the bid scans of the engine are TWO instances since the launches of a phase alternate their walking
+                    # direction (kRev): bytes per launch = the launch-weighted mean over both, like avg_launch_us
+                    n_l = sum(v["launches"] for _, v in tk)
+                    traffic = round(sum((v["read_avg"] + v["write_avg"]) * v["launches"] for _, v in tk) / max(n_l, 1))
+                    traffic_meta["traffic_kernel"] = " + ".join(k for k, _ in tk)
+                    traffic_meta["traffic_launches_measured"] = n_l
+                else:
+                    traffic = round(tk[0][1]["read_avg"] + tk[0][1]["write_avg"])
+                    traffic_meta["traffic_kernel"] = tk[0][0]
             else:
                 traffic_meta["traffic_stale"] = True
         # metric (ii) of SURVEY 8(d): throughput over ALL grid-kernel bid launches (full-scan engine + k_bid), from
