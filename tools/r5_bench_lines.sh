@@ -1,3 +1,5 @@
+# the bench.py lines of every profiled config (after the PMC files of the same sources are installed), the default
+# bench line, a sharded fuzz run -> gpurun_out/r5prof
 set -e
 for c in C3 C2 C4 C5 C1 D1; do bash tools/profile_round.sh r5prof $c bench; done
 EXTRA="--values f64" TAG=_f64 bash tools/profile_round.sh r5prof C3 bench

@@ -2,6 +2,9 @@
 # How the profiles/r05_* files of a round are made (GPU box; three gpurun calls A / B / C, each below 20 minutes):
 #   bash tools/r5_profile_all.sh A|B|C      -> gpurun_out/r5prof/...;  then  python tools/install_profiles.py r5prof r05
 # Every config: bench.py line, rocprofv3 --kernel-trace --stats, PMC passes (tools/profile_round.sh).
+# bench.py looks the PMC traffic of its roofline kernel up in profiles/ (same kernel sources only), so the bench lines are
+# taken once more after the install:  bash tools/r5_bench_lines.sh; python tools/install_profiles.py r5prof r05 bench.
+# tools/r5_verify.sh: the whole -m gpu suite, plain and with every device block poisoned, + a sharded fuzz run.
 set -e
 case "$1" in
 A) for c in C3 C2 C4; do bash tools/profile_round.sh r5prof $c bench stats pmc; done ;;
