@@ -478,15 +478,30 @@ __device__ __forceinline__ void cand_eval2_r(Slot &slot, const PriceRec r, const
 // The same for ONE person (lanes 0..31 hold its line, `cls` = the lane is one of them and its slot is a candidate
 // slot, i.e. 1 <= lane <= kCandMax): the chain of single-bidder rounds is half of all rounds at C3 and two thirds
 // at C5, and a round is bound by the length of this dependent instruction sequence, not by memory.
+// the lane's record gather of a one-person line evaluation (split off: a caller may issue the gather of the NEXT round's
+// line ahead of a barrier and evaluate it behind it, kernels_tail.hpp)
+template <class Slot, class Src>
+__device__ __forceinline__ PriceRec cand_gather1(const Slot &slot, const bool cls, const Src &src) {
+    const bool is_cand = cls & (slot.x >= 0);
+    return src.get(is_cand ? slot.x : 0);
+}
+template <class Slot, class Early, class S = NoStamp>
+__device__ __forceinline__ void cand_eval1_r(Slot &slot, const PriceRec r, const bool cls, const double eps, CandBid &out,
+                                             int &err, Early &&early, const S &stamp = S());
 template <class Slot, class Src, class Early, class S = NoStamp>
 __device__ __forceinline__ void cand_eval1(Slot &slot, const bool cls, const Src &src, const double eps, CandBid &out,
                                            int &err, Early &&early, const S &stamp = S()) {
+    stamp(1);  // (diagnostic builds: drains the memory counters) the line has landed
+    const PriceRec r = cand_gather1(slot, cls, src);
+    stamp(2);  // the records have landed
+    cand_eval1_r(slot, r, cls, eps, out, err, early, stamp);
+}
+template <class Slot, class Early, class S>
+__device__ __forceinline__ void cand_eval1_r(Slot &slot, const PriceRec r, const bool cls, const double eps, CandBid &out,
+                                             int &err, Early &&early, const S &stamp) {
     const int lane = lane_id();
     const double ninf = -__builtin_huge_val();
-    stamp(1);  // (diagnostic builds: drains the memory counters) the line has landed
     const bool is_cand = cls & (slot.x >= 0);
-    const PriceRec r = src.get(is_cand ? slot.x : 0);
-    stamp(2);  // the records have landed
     const double cost = slot_cost(slot);
     const double tau = readlane_f64(__hiloint2double(slot.y, slot.x), 0);
     out.len = __builtin_amdgcn_readlane(slot.x, kCandLanes - 1);

@@ -110,8 +110,10 @@ struct F_k_sync_from_rec {  // (the body as a callable: what a batched launch ru
 
 
 // per-wavefront statistics, flushed once when the kernel ends
+// (what can be derived is not counted in the rounds: line hits = bids - misses, their edges = edges - miss_edges)
 struct TailStats {
-    unsigned long long edges, bids, hits, hit_edges, builds;
+    unsigned long long edges, miss_edges, builds;
+    unsigned bids, misses;
     int err;
     double hint;  // cand_build's search distance, carried from one build of this wavefront to the next
 };
@@ -201,13 +203,18 @@ __device__ __forceinline__ void bid_two(const TailArgs &a, const E &ed, const in
             }
             bd.want = bd.want && a.cand != nullptr;
             bd_person = bd.want ? pi[X] : -1;
-        } else {
-            st.hits += 1;
-            st.hit_edges += (unsigned long long)b[X].len;
+            st.misses += 1;
+            st.miss_edges += (unsigned long long)b[X].len;
         }
         st.edges += (unsigned long long)b[X].len;
         st.bids += 1;
     }
+}
+
+// rounds a mode may run, as 32 bits (a mode that stops short of K's range or max_iter is simply entered again: budgeted
+// launches already work that way)
+__device__ __forceinline__ int round_limit(long long nits, long long max_iter) {
+    return (int)min(max_iter - nits, (long long)0x7fffffff);
 }
 
 // ---- chain mode: K == 1 --------------------------------------------------------------------------------------------
@@ -236,6 +243,8 @@ __device__ __forceinline__ void tail_chain_mode(const TailArgs &a, const E &ed, 
         }
     };
     request(pi, ps);
+    const int rmax = round_limit(nits, max_iter);  // (rounds are counted in 32 bits inside a mode)
+    int r = 0;
 #ifdef MISSLAP_TAIL_STAMP
     // diagnostic build: cycles per segment of a chain round -> Ctl::dbg[6..11]: [6] wait for the line, [7] record
     // gather, [8] winner known + next line requested, [9] rest of the evaluation, [10] full scan of a missed person,
@@ -255,9 +264,9 @@ __device__ __forceinline__ void tail_chain_mode(const TailArgs &a, const E &ed, 
                 request(sp, 0);
             }, stamp);
         stamp.light(4);
-        CandBuildArgs bd;
-        bool build = false;
-        if (!b.hit) {  // wave-uniform
+        if (!b.hit) {  // wave-uniform (rare behind the maintenance pass: the scan and the line's rebuild stay inside this
+                       // block -- what the rebuild needs must not be carried across the join with the common path)
+            CandBuildArgs bd;
             if (E::kCand) {
                 const typename E::Raw none[4] = {};
                 const int e = a.row_ptr[pi + 1];
@@ -265,26 +274,24 @@ __device__ __forceinline__ void tail_chain_mode(const TailArgs &a, const E &ed, 
             } else {
                 wave_bid_full<E, RecSource, true, true>(ed, src, ps, ev, row, eps, b, bd, st.err);
             }
-            build = bd.want && lines;
-        } else {
-            st.hits += 1;
-            st.hit_edges += (unsigned long long)b.len;
+            st.misses += 1;
+            st.miss_edges += (unsigned long long)b.len;
+            if (bd.want && lines) tail_build(a, pi, bd, eps, st);
         }
         stamp.light(5);
         st.edges += (unsigned long long)b.len;
         st.bids += 1;
-        nits += 1;
+        r += 1;
         if (lane == 0) apply_winner(a, pi, ps, b.obj, b.prev, b.key);  // ASSIGN (:396-418)
-        const int built = pi;
         pi = b.prev;  // the evicted owner inherits the slot (:409) and bids next; -1: everybody is assigned
         ps = b.pstart;
-        K = pi != -1;
-        const bool done = K == 0 || nits >= max_iter;
+        const bool done = pi < 0 || r >= rmax;
         if (!done && sp != pi) request(pi, ps);  // (a scanned row decided differently from its line)
-        if (build) tail_build(a, built, bd, eps, st);
         stamp.light(6);
         if (done) break;
     }
+    K = pi != -1;
+    nits += r;
 #ifdef MISSLAP_TAIL_STAMP
     if (lane == 0) {
         for (int k = 1; k <= 6; ++k) a.ctl->dbg[5 + k] += sacc[k];
@@ -622,9 +629,8 @@ __device__ __forceinline__ void tail_duo_mode(const TailArgs &a, const E &ed, in
             const int e = a.row_ptr[me + 1 + lane_zero()];
             wave_bid_full<E, RecSource, true, false>(ed, src, mys, e, none, eps, b, bd, st.err);
             bd_person = bd.want ? me : -1;
-        } else {
-            st.hits += 1;
-            st.hit_edges += (unsigned long long)b.len;
+            st.misses += 1;
+            st.miss_edges += (unsigned long long)b.len;
         }
         st.edges += (unsigned long long)b.len;
         st.bids += 1;
@@ -745,9 +751,8 @@ __device__ __forceinline__ void tail_team1_mode(const TailArgs &a, const E &ed, 
                 const int e = a.row_ptr[pi + 1 + lane_zero()];
                 wave_bid_full<E, RecSource, true, false>(ed, src, ps, e, none, eps, b, bd, st.err);
                 bd_person = bd.want ? pi : -1;
-            } else {
-                st.hits += 1;
-                st.hit_edges += (unsigned long long)b.len;
+                st.misses += 1;
+                st.miss_edges += (unsigned long long)b.len;
             }
             st.edges += (unsigned long long)b.len;
             st.bids += 1;
@@ -853,6 +858,397 @@ __device__ __forceinline__ void tail_team1_mode(const TailArgs &a, const E &ed, 
     __syncthreads();
 }
 
+// ---- the team and duo rounds of handles with lines: few instructions, one barrier, the next gather issued ahead ---------
+// A wavefront of the tail issues one instruction every ~8 cycles whatever the instruction is (tools/micro/
+// exec_mask_bench.hip: dependent VALU 8.2 cycles, independent 6.1; profiles/r06_tail_overheads.txt), so a round is as long
+// as the instructions on its wavefront plus the memory waits it cannot hide.  What a team / duo round does BESIDES the
+// evaluation of its line is therefore written to be few instructions:
+//   * a slot publishes TWO 16-byte LDS entries ahead of the barrier: the price record its winning bid would write
+//     {bid, bidder, bidder's row start} and {object, its owner, the owner's row start};
+//   * the clean test -- no object bid on twice, no chain ends (an unowned object won): 99.9 % of the rounds -- moves IN
+//     FRONT of the barrier: each bidder swaps the round's number into a table slot keyed by its object's hash (one
+//     ds_wrxchg per wavefront; meeting the round's own number = two bids on one hash) and writes the round's number into
+//     the dirty word of the round's parity if that, or the end of a chain, is seen.  Behind the barrier the test is ONE
+//     broadcast LDS read.  Round numbers only grow, so neither the table nor the dirty words are ever reset; a false
+//     positive (two objects, one hash: < 1 % of the rounds) only sends the round through the exact RESOLVE / ASSIGN /
+//     push_all_left (auction_.pyx:375-385 strict ">", :396-418, :137-162), which is the code every round ran before;
+//   * in a clean round every bidder wins and every slot passes to the owner its bidder evicts (:409): a wavefront's next
+//     bidder is in its own registers, and ALL winners' records are one 16-byte store on lanes = slots (every serving
+//     wavefront stores them all itself: its later gathers follow them in program order);
+//   * the record gather of the NEXT bid is issued AHEAD of the barrier, as soon as the next bidder's line has landed, and
+//     made exact behind it: a candidate whose object was bid on in this round takes the PUBLISHED record (whether the
+//     gather saw the old or the new one does not matter); every other record cannot have changed (:394-427 writes only
+//     the objects bid on), and the next round's stores lie behind ITS barrier, which no wavefront reaches before its
+//     gather has landed.  "Bid on in this round" is read off the same hash table (own object: patched from registers;
+//     any other hit -- rare -- walks the published slots);
+//   * rounds are counted in 32 bits inside a mode (a launch is bounded by TailArgs::round_budget / 2^31 rounds) and the
+//     statistics that can be derived (line hits = bids - misses) are not counted;
+//   * wavefronts whose slot lies beyond K (K never grows) END after one more barrier: the barrier is then between the
+//     serving wavefronts only.
+#ifndef MISSLAP_TAIL_PIPE
+#define MISSLAP_TAIL_PIPE 3  // bit 0: the team rounds, bit 1: the duo rounds (0: the rounds as they were before round 6)
+#endif
+constexpr int kPipeTab = 4096;  // (K = 16: 3 % false positives of the clean test, K = 6: 0.4 %)
+__device__ __forceinline__ int pipe_hash(int obj) { return (int)(((unsigned)obj * 2654435761u) >> 20); }
+static_assert((1 << 12) == kPipeTab, "pipe_hash keeps the top 12 bits");
+__device__ __forceinline__ void patch_rec(PriceRec &r, const bool take, const PriceRec &nw) {
+    r.price = take ? nw.price : r.price;
+    r.owner = take ? nw.owner : r.owner;
+    r.ostart = take ? nw.ostart : r.ostart;
+}
+struct __attribute__((aligned(16))) PipeSlot {
+    PriceRec rec;  // what the slot's winning bid writes: {bid, bidder, bidder's row start}
+    int4 aux;      // {object bid on, its owner, the owner's row start, -}
+};
+struct __attribute__((aligned(16))) PipeLds {
+    PipeSlot slot[2][kTeamMax];  // by round parity
+    int dirty[2];                // number of the last round (of this parity) that needs the exact RESOLVE
+    int pad[2];
+    int tab[kPipeTab];           // hash of an object -> number of the last round in which it was bid on
+};
+
+// returns true when this wavefront has LEFT (its slot lies beyond K): the caller flushes its statistics and ends
+template <class E>
+__device__ __forceinline__ bool tail_team1_pipe(const TailArgs &a, const E &ed, int *sU, int *sStart, int &K,
+                                                long long &nits, const long long max_iter, const double eps,
+                                                TailStats &st) {
+    const int lane = lane_id(), l32 = lane & (kCandLanes - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    __shared__ PipeLds L;
+    const RecSource src{a.rec};
+    const bool cls = (lane >= 1) & (lane <= kCandMax);
+    const int n0 = wave;  // my slot
+    int pi = n0 < K ? __builtin_amdgcn_readfirstlane(sU[min(n0, kTailMax - 1)]) : -1;
+    int ps = n0 < K ? __builtin_amdgcn_readfirstlane(sStart[min(n0, kTailMax - 1)]) : 0;
+    for (int h = threadIdx.x; h < kPipeTab; h += blockDim.x) L.tab[h] = -1;  // (round numbers are >= 0)
+    if (threadIdx.x < 2) L.dirty[threadIdx.x] = -1;
+    typename E::Slot slot = cand_no_line<typename E::Slot>();
+    auto request = [&](int person) { slot = line_of<E>(a, person, l32); };
+    if (n0 < K) request(pi);
+    __syncthreads();  // (sU / sStart have been read by everybody, the tables are set)
+#ifdef MISSLAP_TAIL_STAMP_TEAM
+    // diagnostic build: cycles of wavefront 0 per segment of a team round -> Ctl::dbg[6..11]: [6] evaluation of my slot up
+    // to the bid, [7] publish + wait for the next line + next gather issued, [8] barrier, [9] LDS reads landed, [10] the
+    // gather issued ahead has landed, [11] patch / winners' stores / re-request / line rebuild
+    unsigned long long sacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sprev = __builtin_amdgcn_s_memtime();
+    const CycleStamp stamp{sacc, &sprev, wave == 0};
+#else
+    const NoStamp stamp;
+#endif
+    const int rmax = round_limit(nits, max_iter);
+    int r = 0;  // rounds done here = the round's number
+    PriceRec grec = PriceRec{0.0, -1, 0};
+    bool have_g = false;  // grec = the (exact) records of my slot's line, gathered ahead
+    int par = 0;
+    const int ls = min(lane, kTeamMax - 1);
+    for (;;) {
+        if (n0 >= K) {  // wave-uniform: my slot fell away (slots < K are always occupied: the list is compact)
+            if (lane == 0) {
+                sU[n0] = -1;  // (I end behind this barrier; the serving wavefronts hand their slots back)
+                sStart[n0] = 0;
+            }
+            tail_barrier_lds();
+            nits += r;
+            return true;
+        }
+        int sp = -2;  // the person whose line was requested early (-2: nothing requested)
+        CandBid b;
+        b.hit = false;
+        stamp.light(0);
+        // BID for my slot (auction_.pyx:339-365)
+        if (!have_g) grec = cand_gather1(slot, cls, src);
+        cand_eval1_r(slot, grec, cls, eps, b, st.err, [&](const CandBid &w) {
+            sp = w.prev;
+            request(sp);  // the owner my bidder evicts if it wins
+        });
+        if (!b.hit) {  // (rare behind the maintenance pass: the scan and the line's rebuild stay inside this block)
+            CandBuildArgs bd;
+            const typename E::Raw none[4] = {};
+            const int e = a.row_ptr[pi + 1 + lane_zero()];
+            wave_bid_full<E, RecSource, true, false>(ed, src, ps, e, none, eps, b, bd, st.err);
+            st.misses += 1;
+            st.miss_edges += (unsigned long long)b.len;
+            if (bd.want) tail_build(a, pi, bd, eps, st);
+            b.hit = false;
+        }
+        st.edges += (unsigned long long)b.len;
+        st.bids += 1;
+        stamp.light(1);
+        PriceRec mine;
+        mine.price = key_to_bid(b.key);
+        mine.owner = pi;
+        mine.ostart = ps;
+        if (lane == 0) {
+            const int old = atomicExch(&L.tab[pipe_hash(b.obj)], r);
+            L.slot[par][n0].rec = mine;
+            L.slot[par][n0].aux = make_int4(b.obj, b.prev, b.pstart, 0);
+            if (old == r || b.prev < 0) L.dirty[par] = r;
+        }
+        // the gather of the NEXT round, ahead of the barrier (a scanned row may have decided differently from its
+        // line: then nothing was requested for the right person, and the next round gathers behind the barrier)
+        const bool have_n = b.hit && b.prev >= 0;
+        PriceRec nrec = PriceRec{0.0, -1, 0};
+        int hc = 0;
+        if (have_n) {
+            nrec = cand_gather1(slot, cls, src);
+            hc = pipe_hash(slot.x);
+        }
+        stamp.light(2);
+        tail_barrier_lds();  // the bids are in LDS and every gather of the round has been ISSUED against the old records
+        stamp.light(3);
+        {
+            const int dflag = L.dirty[par];
+            const PriceRec lrec = L.slot[par][ls].rec;  // lanes = slots
+            const int lobj = L.slot[par][ls].aux.x;
+            int tb = L.tab[hc];  // (>= r: bid on in this round -- or, if a fast wavefront is already publishing, the next)
+            asm volatile("" : "+v"(tb));  // (read with the others, not behind the test of the dirty word)
+#ifdef MISSLAP_TAIL_STAMP_TEAM
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            stamp.light(4);  // the LDS reads have landed
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            stamp.light(5);  // the gather issued ahead of the barrier has landed
+#endif
+            if (__builtin_amdgcn_readfirstlane(dflag) != r) {
+                // CLEAN: every bidder wins (:375-385 has nothing to resolve); the list keeps its shape.  The records
+                // gathered ahead are made exact FIRST and the winners' stores (ASSIGN, :396-418) are issued behind that:
+                // a wait for the gather that has a store behind it in the queue would wait for the store's round trip too
+                if (have_n) {
+                    const int c = slot.x;
+                    const bool own = c == b.obj;
+                    patch_rec(nrec, own, mine);
+                    if (__any((tb >= r) & !own & cls & (c >= 0))) {  // rare: another slot bid on a candidate of my next bidder
+                        for (int m = 0; m < K; ++m) {
+                            const int om = __builtin_amdgcn_readlane(lobj, m);
+                            PriceRec rm;
+                            rm.price = readlane_f64(lrec.price, m);
+                            rm.owner = __builtin_amdgcn_readlane(lrec.owner, m);
+                            rm.ostart = __builtin_amdgcn_readlane(lrec.ostart, m);
+                            patch_rec(nrec, c == om, rm);
+                        }
+                    }
+                }
+                if (lane < K) a.rec[lobj] = lrec;
+                pi = b.prev;
+                ps = b.pstart;
+                grec = nrec;
+                have_g = have_n;
+            } else {
+                // RESOLVE / ASSIGN / push_all_left in full, on lanes = slots
+                const bool act = lane < K;
+                const int4 laux = L.slot[par][ls].aux;
+                const unsigned long long lkey = act ? bid_to_key(lrec.price) : 0ull;
+                const int lo = act ? laux.x : (-2 - lane);
+                const int lprev = act ? laux.y : 0, lpst = act ? laux.z : 0;
+                int u = act ? lrec.owner : -1;  // the list: lane l holds slot l
+                int sx = act ? lrec.ostart : 0;
+                bool lose = false;
+                for (int m = 0; m < K; ++m) {  // :375-385, all pairs via readlane
+                    const int om = __builtin_amdgcn_readlane(lo, m);
+                    const bool same = (om == lo) && (m != lane);
+                    if (__any(same)) {  // wave-uniform
+                        const unsigned long long km = readlane_u64(lkey, m);
+                        lose |= same && (km > lkey || (km == lkey && m < lane));
+                    }
+                }
+                const bool won = act && !lose;
+                if (won) apply_winner(a, u, sx, lo, lprev, lkey);  // :396-418
+                u = won ? lprev : u;  // the evicted owner inherits the slot (:409) / hole (:412) / a loser stays
+                sx = won ? lpst : sx;
+                const unsigned long long kmask = (1ull << K) - 1ull;
+                const unsigned long long holes = __ballot(act && u == -1) & kmask;
+                const int Kn = K - __popcll(holes);
+                const unsigned long long lmask = (1ull << Kn) - 1ull;
+                unsigned long long hl = holes & lmask;            // empty slots left of K'
+                unsigned long long mv = ~holes & ~lmask & kmask;  // persons right of K'
+                while (hl) {  // wave-uniform: k-th hole <- k-th mover (:137-162)
+                    const int hk = __ffsll((long long)hl) - 1, mk = __ffsll((long long)mv) - 1;
+                    const int mu = __builtin_amdgcn_readlane(u, mk), ms = __builtin_amdgcn_readlane(sx, mk);
+                    if (lane == hk) {
+                        u = mu;
+                        sx = ms;
+                    }
+                    hl &= hl - 1;
+                    mv &= mv - 1;
+                }
+                K = Kn;
+                pi = n0 < K ? __builtin_amdgcn_readlane(u, min(n0, kWave - 1)) : -1;
+                ps = n0 < K ? __builtin_amdgcn_readlane(sx, min(n0, kWave - 1)) : 0;
+                have_g = false;
+            }
+        }
+        par ^= 1;
+        r += 1;
+        const bool done = K <= 2 || r >= rmax;
+        // my slot's new occupant is usually exactly the person whose line was requested early; otherwise (a scanned
+        // row, a lost bid, a moved person) request now
+        if (!done && n0 < K && sp != pi) request(pi);
+        stamp.light(6);
+        if (done) break;
+    }
+    nits += r;
+#ifdef MISSLAP_TAIL_STAMP_TEAM
+    if (threadIdx.x == 0)
+        for (int k = 1; k <= 6; ++k) a.ctl->dbg[5 + k] += sacc[k];
+#endif
+    // hand the list back: every wavefront that is still here writes its own slot
+    if (lane == 0 && n0 < kTeamMax) {
+        sU[n0] = pi;
+        sStart[n0] = ps;
+    }
+    __syncthreads();
+    return false;
+}
+
+// duo mode in the same form: two wavefronts, one bidder each; clean = two different objects, both owned
+template <class E>
+__device__ __forceinline__ void tail_duo_pipe(const TailArgs &a, const E &ed, int *sU, int *sStart, int &K,
+                                              long long &nits, const long long max_iter, const double eps,
+                                              TailStats &st) {
+    const int lane = lane_id(), l32 = lane & (kCandLanes - 1);
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // 0 or 1: my slot
+    const int o = w ^ 1;
+    __shared__ PipeSlot D[2][2];
+    const RecSource src{a.rec};
+    const bool cls = (lane >= 1) & (lane <= kCandMax);
+    int me = __builtin_amdgcn_readfirstlane(sU[w]), mys = __builtin_amdgcn_readfirstlane(sStart[w]);
+    typename E::Slot slot = cand_no_line<typename E::Slot>();
+    auto request = [&](int person) { slot = line_of<E>(a, person, l32); };
+    request(me);
+    tail_barrier_lds();  // (sU / sStart have been read by both)
+#ifdef MISSLAP_TAIL_STAMP_DUO
+    // diagnostic build: cycles of wavefront 0 per segment of a duo round -> Ctl::dbg[6..10]: [6] evaluation up to the bid
+    // (incl. what is left of the gather's latency), [7] publish + wait for the next line + next gather issued, [8]
+    // barrier (= the other wavefront), [9] exchange / patch / stores, [10] re-request, line rebuild
+    unsigned long long sacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sprev = __builtin_amdgcn_s_memtime();
+    const CycleStamp stamp{sacc, &sprev, w == 0};
+#else
+    const NoStamp stamp;
+#endif
+    const int rmax = round_limit(nits, max_iter);
+    int r = 0;
+    PriceRec grec = PriceRec{0.0, -1, 0};
+    bool have_g = false;
+    int par = 0;
+    for (;;) {
+        int sp = -2;  // the person whose line was requested early (-2: nothing requested)
+        CandBid b;
+        b.hit = false;
+        stamp.light(0);
+        if (!have_g) grec = cand_gather1(slot, cls, src);
+        cand_eval1_r(slot, grec, cls, eps, b, st.err, [&](const CandBid &x) {
+            sp = x.prev;
+            request(sp);  // the owner my bidder evicts if it wins
+        });
+        if (!b.hit) {  // (rare behind the maintenance pass: the scan and the line's rebuild stay inside this block)
+            CandBuildArgs bd;
+            const typename E::Raw none[4] = {};
+            const int e = a.row_ptr[me + 1 + lane_zero()];
+            wave_bid_full<E, RecSource, true, false>(ed, src, mys, e, none, eps, b, bd, st.err);
+            st.misses += 1;
+            st.miss_edges += (unsigned long long)b.len;
+            if (bd.want) tail_build(a, me, bd, eps, st);
+            b.hit = false;
+        }
+        st.edges += (unsigned long long)b.len;
+        st.bids += 1;
+        stamp.light(1);
+        PriceRec mine;
+        mine.price = key_to_bid(b.key);
+        mine.owner = me;
+        mine.ostart = mys;
+        if (lane == 0) {
+            D[par][w].rec = mine;
+            D[par][w].aux = make_int4(b.obj, b.prev, b.pstart, 0);
+        }
+        const bool have_n = b.hit && b.prev >= 0;
+        PriceRec nrec = PriceRec{0.0, -1, 0};
+        if (have_n) nrec = cand_gather1(slot, cls, src);  // the gather of the NEXT round, ahead of the barrier
+        stamp.light(2);
+        tail_barrier_lds();  // both bids are in LDS and both gathers of the round have been issued against the old records
+        stamp.light(3);
+        const PriceRec orec = D[par][o].rec;  // (one address for the whole wavefront)
+        const int4 oaux = D[par][o].aux;
+        r += 1;
+        const int unclean = __builtin_amdgcn_readfirstlane((int)(oaux.x == b.obj) | (int)(oaux.y < 0)) | (int)(b.prev < 0);
+        if (!unclean) {
+            // both bidders win different owned objects (:375-385 has nothing to resolve) and both slots pass to the
+            // evicted owners.  The records gathered ahead are made exact FIRST, the stores (ASSIGN, :396-418, by both
+            // wavefronts alike: lane 0 my record, lane 1 the other's) are issued behind that
+            if (have_n) {
+                const int c = slot.x;
+                patch_rec(nrec, c == b.obj, mine);
+                patch_rec(nrec, c == oaux.x, orec);
+            }
+            if (lane < 2) {
+                PriceRec rr = mine;
+                patch_rec(rr, lane == 1, orec);
+                a.rec[lane == 1 ? oaux.x : b.obj] = rr;
+            }
+            me = b.prev;
+            mys = b.pstart;
+            grec = nrec;
+            have_g = have_n;
+        } else {
+            // the two bids by slot, RESOLVE (:375-385: strict ">", the earlier list position keeps an object on equal
+            // bids), ASSIGN (:396-418) by both wavefronts alike, push_all_left (:137-162) on two slots
+            const unsigned long long okey = bid_to_key(readlane_f64(orec.price, 0));
+            const int oobj = __builtin_amdgcn_readfirstlane(oaux.x), oprev = __builtin_amdgcn_readfirstlane(oaux.y);
+            const int opst = __builtin_amdgcn_readfirstlane(oaux.z);
+            const int ome = __builtin_amdgcn_readfirstlane(orec.owner), omys = __builtin_amdgcn_readfirstlane(orec.ostart);
+            int pi[2], ps[2];
+            pi[0] = w ? ome : me, pi[1] = w ? me : ome;
+            ps[0] = w ? omys : mys, ps[1] = w ? mys : omys;
+            const unsigned long long key0 = w ? okey : b.key, key1 = w ? b.key : okey;
+            const int obj0 = w ? oobj : b.obj, obj1 = w ? b.obj : oobj;
+            const int prev0 = w ? oprev : b.prev, prev1 = w ? b.prev : oprev;
+            const int pst0 = w ? opst : b.pstart, pst1 = w ? b.pstart : opst;
+            bool win0 = true, win1 = true;
+            if (obj0 == obj1) {
+                if (key1 > key0) win0 = false;
+                else win1 = false;
+            }
+            if (lane == 0) {
+                if (win0) apply_winner(a, pi[0], ps[0], obj0, prev0, key0);
+                if (win1) apply_winner(a, pi[1], ps[1], obj1, prev1, key1);
+            }
+            if (win0) {
+                pi[0] = prev0;
+                ps[0] = pst0;
+            }
+            if (win1) {
+                pi[1] = prev1;
+                ps[1] = pst1;
+            }
+            if (pi[0] == -1 && pi[1] != -1) {
+                pi[0] = pi[1];
+                ps[0] = ps[1];
+                pi[1] = -1;
+            }
+            K = (pi[0] != -1) + (pi[1] != -1);
+            me = w ? pi[1] : pi[0];
+            mys = w ? ps[1] : ps[0];
+            have_g = false;
+        }
+        stamp.light(4);
+        par ^= 1;
+        const bool done = K <= 1 || r >= rmax;
+        // the early request assumed "my bidder wins, nobody moves"; otherwise request again
+        if (!done && sp != me) request(me);
+        stamp.light(5);
+        if (done) break;
+    }
+    nits += r;
+#ifdef MISSLAP_TAIL_STAMP_DUO
+    if (w == 0 && lane == 0)
+        for (int k = 1; k <= 5; ++k) a.ctl->dbg[5 + k] += sacc[k];
+#endif
+    if (lane == 0) {  // every wavefront hands its own slot back
+        sU[w] = me;
+        sStart[w] = mys;
+    }
+    tail_barrier_lds();
+}
+
 // kThreads = kTailMax (512): every mode.  kThreads = 1024 ("block only"): the rounds with more than kTeamMax bidders
 // with SIXTEEN wavefronts -- half the sweeps per wavefront in pass A, which is where a block round spends its time --
 // and nothing else: the solo / team code needs more than the 128 registers a 1024-thread workgroup leaves a
@@ -910,7 +1306,8 @@ __device__ __forceinline__ void k_tail_body(TailArgs a, E ed) {
         }
     const double eps = (double)a.eps;
     TailStats st;
-    st.edges = st.bids = st.hits = st.hit_edges = st.builds = 0ull;
+    st.edges = st.miss_edges = st.builds = 0ull;
+    st.bids = st.misses = 0u;
     st.err = 0;
     st.hint = 0.0;
     if (t == 0) sMissCnt = 0;
@@ -933,17 +1330,18 @@ __device__ __forceinline__ void k_tail_body(TailArgs a, E ed) {
     auto flush_stats = [&]() {  // a wavefront's statistics, once, when it leaves the kernel
         if (lane == 0) {
             if (st.bids) {
+                const unsigned long long hits = (unsigned long long)(st.bids - st.misses), hit_edges = st.edges - st.miss_edges;
                 atomicAdd(&ctl->edges, st.edges);
                 atomicAdd(&ctl->tail_edges, st.edges);
-                atomicAdd(&ctl->bids, st.bids);
-                if (st.hits) {
-                    atomicAdd(&ctl->cand_hits, st.hits);
-                    atomicAdd(&ctl->cand_edges, st.hit_edges);
+                atomicAdd(&ctl->bids, (unsigned long long)st.bids);
+                if (hits) {
+                    atomicAdd(&ctl->cand_hits, hits);
+                    atomicAdd(&ctl->cand_edges, hit_edges);
                 }
-                atomicAdd(&ctl->dbg[12], st.bids);  // the tail's own totals: bids, line hits, line builds
-                atomicAdd(&ctl->dbg[13], st.hits);
+                atomicAdd(&ctl->dbg[12], (unsigned long long)st.bids);  // the tail's own totals: bids, line hits, line builds
+                atomicAdd(&ctl->dbg[13], hits);
                 atomicAdd(&ctl->dbg[14], st.builds);
-                atomicAdd(&ctl->dbg[15], st.hit_edges);
+                atomicAdd(&ctl->dbg[15], hit_edges);
             }
             if (st.err) atomicOr(&ctl->err, st.err);
         }
@@ -954,7 +1352,10 @@ __device__ __forceinline__ void k_tail_body(TailArgs a, E ed) {
             // ---- K <= 2, lines: duo mode while two bidders are left (wavefronts 0 and 1, one bidder each), then
             // wavefront 0 runs the single-bidder chain alone
             mode_begin(0);
-            if (K == 2) tail_duo_mode(a, ed, sU, sStart, K, nits, max_iter, eps, st);
+            if (K == 2) {
+                if (MISSLAP_TAIL_PIPE & 2) tail_duo_pipe(a, ed, sU, sStart, K, nits, max_iter, eps, st);
+                else tail_duo_mode(a, ed, sU, sStart, K, nits, max_iter, eps, st);
+            }
             if (wave == 1) {
                 flush_stats();
                 return;
@@ -974,7 +1375,14 @@ __device__ __forceinline__ void k_tail_body(TailArgs a, E ed) {
         if (kTeamOnly) {
             if (K > 2 && nits < max_iter) {
                 mode_begin(1);
-                tail_team1_mode(a, ed, sU, sStart, K, nits, max_iter, eps, st);
+                if (MISSLAP_TAIL_PIPE & 1) {
+                    if (tail_team1_pipe(a, ed, sU, sStart, K, nits, max_iter, eps, st)) {  // (this wavefront's slot fell away)
+                        flush_stats();
+                        return;
+                    }
+                } else {
+                    tail_team1_mode(a, ed, sU, sStart, K, nits, max_iter, eps, st);
+                }
                 mode_end(1);
             }
             break;
@@ -988,7 +1396,8 @@ __device__ __forceinline__ void k_tail_body(TailArgs a, E ed) {
                 return;
             }
             mode_begin(0);
-            tail_duo_mode(a, ed, sU, sStart, K, nits, max_iter, eps, st);
+            if (MISSLAP_TAIL_PIPE & 2) tail_duo_pipe(a, ed, sU, sStart, K, nits, max_iter, eps, st);
+            else tail_duo_mode(a, ed, sU, sStart, K, nits, max_iter, eps, st);
             if (wave == 1) {
                 flush_stats();
                 return;
@@ -1080,8 +1489,6 @@ __device__ __forceinline__ void k_tail_body(TailArgs a, E ed) {
                                 sPrev[n] = b[X].prev;
                                 sPst[n] = b[X].pstart;
                             }
-                            st.hits += 1;
-                            st.hit_edges += (unsigned long long)b[X].len;
                             st.edges += (unsigned long long)b[X].len;
                             st.bids += 1;
                         } else if (lane == 0) {
@@ -1110,7 +1517,9 @@ __device__ __forceinline__ void k_tail_body(TailArgs a, E ed) {
                     sPst[n] = bm.pstart;
                 }
                 st.edges += (unsigned long long)bm.len;
+                st.miss_edges += (unsigned long long)bm.len;
                 st.bids += 1;
+                st.misses += 1;
                 if (ba.want) tail_build(a, i, ba, eps, st);
             }
         }
