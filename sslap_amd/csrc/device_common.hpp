@@ -487,18 +487,18 @@ __device__ __forceinline__ PriceRec cand_gather1(const Slot &slot, const bool cl
 }
 template <class Slot, class Early, class S = NoStamp>
 __device__ __forceinline__ void cand_eval1_r(Slot &slot, const PriceRec r, const bool cls, const double eps, CandBid &out,
-                                             int &err, Early &&early, const S &stamp = S());
+                                             unsigned &bad_hi, Early &&early, const S &stamp = S());
 template <class Slot, class Src, class Early, class S = NoStamp>
 __device__ __forceinline__ void cand_eval1(Slot &slot, const bool cls, const Src &src, const double eps, CandBid &out,
-                                           int &err, Early &&early, const S &stamp = S()) {
+                                           unsigned &bad_hi, Early &&early, const S &stamp = S()) {
     stamp(1);  // (diagnostic builds: drains the memory counters) the line has landed
     const PriceRec r = cand_gather1(slot, cls, src);
     stamp(2);  // the records have landed
-    cand_eval1_r(slot, r, cls, eps, out, err, early, stamp);
+    cand_eval1_r(slot, r, cls, eps, out, bad_hi, early, stamp);
 }
 template <class Slot, class Early, class S>
 __device__ __forceinline__ void cand_eval1_r(Slot &slot, const PriceRec r, const bool cls, const double eps, CandBid &out,
-                                             int &err, Early &&early, const S &stamp) {
+                                             unsigned &bad_hi, Early &&early, const S &stamp) {
     const int lane = lane_id();
     const double ninf = -__builtin_huge_val();
     const bool is_cand = cls & (slot.x >= 0);
@@ -529,9 +529,13 @@ __device__ __forceinline__ void cand_eval1_r(Slot &slot, const PriceRec r, const
     const double W = readlane_f64(half_max_f64(lane == G ? ninf : v), 31);  // second best, counting multiplicity
     out.hit = (G >= 0) & (V > tau) & (W >= tau);
     const double bid = (c1 - W) + eps;  // bbest = costbest - wi + eps   (:360)
-    if (out.hit && bid_is_bad(bid)) err |= kErrNegativeBid;
+    // a bid that breaks the bits-as-integer order of the keys (negative: sign bit; NaN): the running maximum of the high
+    // words of the bids that count, tested once when the kernel ends (bad_hi_is_error) -- two instructions per bid
+    bad_hi = max(bad_hi, out.hit ? (unsigned)__double2hiint(bid) : 0u);
     out.key = bid_to_key(bid);
 }
+// (+inf = 0x7ff00000:00000000 is a legal bid; every NaN an operation produces and every negative value has a larger high word)
+__device__ __forceinline__ bool bad_hi_is_error(unsigned bad_hi) { return bad_hi > 0x7ff00000u; }
 struct NoEarly {
     __device__ __forceinline__ void operator()(const CandBid (&)[2]) const {}
     __device__ __forceinline__ void operator()(const CandBid &) const {}

@@ -114,6 +114,7 @@ struct F_k_sync_from_rec {  // (the body as a callable: what a batched launch ru
 struct TailStats {
     unsigned long long edges, miss_edges, builds;
     unsigned bids, misses;
+    unsigned bad_hi;  // largest high word of a bid made from a line (cand_eval1_r; bad_hi_is_error)
     int err;
     double hint;  // cand_build's search distance, carried from one build of this wavefront to the next
 };
@@ -259,7 +260,7 @@ __device__ __forceinline__ void tail_chain_mode(const TailArgs &a, const E &ed, 
         b.hit = false;
         int sp = -2;  // the person whose line was requested early (-2: nothing requested)
         if (E::kCand)
-            cand_eval1(slot, cls, src, eps, b, st.err, [&](const CandBid &w) {
+            cand_eval1(slot, cls, src, eps, b, st.bad_hi, [&](const CandBid &w) {
                 sp = w.prev;
                 request(sp, 0);
             }, stamp);
@@ -577,287 +578,6 @@ __device__ __forceinline__ void tail_team_mode(const TailArgs &a, const E &ed, i
     __syncthreads();
 }
 
-// ---- duo mode: K == 2 with one wavefront per bidder ------------------------------------------------------------------
-// The two-bidder rounds of solo mode, split over wavefronts 0 and 1 (the other wavefronts of the workgroup have ended
-// by then, so the barrier is between these two): each evaluates ONE line (cand_eval1, the shortest chain there is),
-// publishes its bid through LDS, and behind one LDS-only barrier both resolve / assign / push_all_left the two slots
-// identically in scalar code -- each stores BOTH winners' records, so that its own next gather follows them in program
-// order.  Runs while K == 2; hands the slots back through sU / sStart.  Lines only (8 B/edge layout).
-template <class E>
-__device__ __forceinline__ void tail_duo_mode(const TailArgs &a, const E &ed, int *sU, int *sStart, int &K,
-                                              long long &nits, const long long max_iter, const double eps,
-                                              TailStats &st) {
-    const int lane = lane_id(), l32 = lane & (kCandLanes - 1);
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // 0 or 1: my slot
-    __shared__ unsigned long long dKey[2][2];
-    __shared__ int dObj[2][2], dPrev[2][2], dPst[2][2];
-    const RecSource src{a.rec};
-    const bool cls = (lane >= 1) & (lane <= kCandMax);
-    int pi[2], ps[2];  // both slots, kept identically by both wavefronts
-#pragma unroll
-    for (int X = 0; X < 2; ++X) {
-        pi[X] = __builtin_amdgcn_readfirstlane(sU[X]);
-        ps[X] = __builtin_amdgcn_readfirstlane(sStart[X]);
-    }
-    typename E::Slot slot = cand_no_line<typename E::Slot>();
-    auto request = [&](int person) { slot = line_of<E>(a, person, l32); };
-    request(w ? pi[1] : pi[0]);
-    tail_barrier_lds();  // (sU / sStart have been read by both)
-#ifdef MISSLAP_TAIL_STAMP_DUO
-    // diagnostic build: cycles of wavefront 0 per segment of a duo round -> Ctl::dbg[6..11]: [6] wait for the line, [7]
-    // record gather, [8] winner known + next line requested, [9] rest of the evaluation (+ a missed person's scan),
-    // [10] bid to LDS + barrier (= the other wavefront), [11] exchange / resolve / both stores / re-request
-    unsigned long long sacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sprev = __builtin_amdgcn_s_memtime();
-    const CycleStamp stamp{sacc, &sprev, w == 0};
-#else
-    const NoStamp stamp;
-#endif
-    int par = 0;
-    for (;;) {
-        const int me = w ? pi[1] : pi[0], mys = w ? ps[1] : ps[0];
-        int sp = -2;  // the person whose line was requested early (-2: nothing requested)
-        CandBuildArgs bd;
-        int bd_person = -1;
-        CandBid b;
-        b.hit = false;
-        cand_eval1(slot, cls, src, eps, b, st.err, [&](const CandBid &x) {
-            sp = x.prev;
-            request(sp);  // the owner my bidder evicts if it wins
-        }, stamp);
-        if (!b.hit) {
-            const typename E::Raw none[4] = {};
-            const int e = a.row_ptr[me + 1 + lane_zero()];
-            wave_bid_full<E, RecSource, true, false>(ed, src, mys, e, none, eps, b, bd, st.err);
-            bd_person = bd.want ? me : -1;
-            st.misses += 1;
-            st.miss_edges += (unsigned long long)b.len;
-        }
-        st.edges += (unsigned long long)b.len;
-        st.bids += 1;
-        stamp.light(4);
-        if (lane == 0) {
-            dKey[par][w] = b.key;
-            dObj[par][w] = b.obj;
-            dPrev[par][w] = b.prev;
-            dPst[par][w] = b.pstart;
-        }
-        tail_barrier_lds();  // both bids are in LDS and both gathers of the round are done
-        stamp.light(5);
-        const int o = w ^ 1;
-        const unsigned long long okey = readlane_u64(dKey[par][o], 0);
-        const int oobj = __builtin_amdgcn_readfirstlane(dObj[par][o]);
-        const int oprev = __builtin_amdgcn_readfirstlane(dPrev[par][o]);
-        const int opst = __builtin_amdgcn_readfirstlane(dPst[par][o]);
-        // the two bids by slot
-        const unsigned long long key0 = w ? okey : b.key, key1 = w ? b.key : okey;
-        const int obj0 = w ? oobj : b.obj, obj1 = w ? b.obj : oobj;
-        const int prev0 = w ? oprev : b.prev, prev1 = w ? b.prev : oprev;
-        const int pst0 = w ? opst : b.pstart, pst1 = w ? b.pstart : opst;
-        nits += 1;
-        // RESOLVE (:375-385): strict ">" -- the earlier list position keeps an object on equal bids
-        bool win0 = true, win1 = true;
-        if (obj0 == obj1) {
-            if (key1 > key0) win0 = false;
-            else win1 = false;
-        }
-        // ASSIGN (:396-418), by both wavefronts alike: a winner's slot goes to the evicted owner (or becomes a hole)
-        if (lane == 0) {
-            if (win0) apply_winner(a, pi[0], ps[0], obj0, prev0, key0);
-            if (win1) apply_winner(a, pi[1], ps[1], obj1, prev1, key1);
-        }
-        if (win0) {
-            pi[0] = prev0;
-            ps[0] = pst0;
-        }
-        if (win1) {
-            pi[1] = prev1;
-            ps[1] = pst1;
-        }
-        // push_all_left (:137-162) on two slots
-        if (pi[0] == -1 && pi[1] != -1) {
-            pi[0] = pi[1];
-            ps[0] = ps[1];
-            pi[1] = -1;
-        }
-        K = (pi[0] != -1) + (pi[1] != -1);
-        par ^= 1;
-        const bool done = K <= 1 || nits >= max_iter;
-        // the early request assumed "my bidder wins, nobody moves"; otherwise request again
-        if (!done && sp != (w ? pi[1] : pi[0])) request(w ? pi[1] : pi[0]);
-        if (bd_person >= 0) tail_build(a, bd_person, bd, eps, st);
-        stamp.light(6);
-        if (done) break;
-    }
-#ifdef MISSLAP_TAIL_STAMP_DUO
-    if (w == 0 && lane == 0)
-        for (int k = 1; k <= 6; ++k) a.ctl->dbg[5 + k] += sacc[k];
-#endif
-    if (w == 0 && lane == 0) {  // (both wavefronts hold the same list)
-        sU[0] = pi[0];
-        sU[1] = pi[1];
-        sStart[0] = ps[0];
-        sStart[1] = ps[1];
-    }
-    tail_barrier_lds();
-}
-
-// ---- team mode with ONE list slot per wavefront (the 16-wavefront "team only" instance of the kernel) ------------------
-// The same round as tail_team_mode -- one LDS-only barrier, every serving wavefront finishes the round for the whole
-// list on lanes = slots and stores all winners' records itself -- but wavefront w serves slot w alone: a round is a
-// serial ALU chain per wavefront, and the one-person evaluation (cand_eval1) is the shortest there is.  Lines only
-// (8 B/edge layout).  Runs until K <= 2 (or max_iter); the 512-thread kernel takes the rest.
-template <class E>
-__device__ __forceinline__ void tail_team1_mode(const TailArgs &a, const E &ed, int *sU, int *sStart, int &K,
-                                                long long &nits, const long long max_iter, const double eps,
-                                                TailStats &st) {
-    const int lane = lane_id(), l32 = lane & (kCandLanes - 1);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    __shared__ unsigned long long uKey[2][kTeamMax];
-    __shared__ int uObj[2][kTeamMax], uPrev[2][kTeamMax], uPst[2][kTeamMax], uU[2][kTeamMax], uS[2][kTeamMax];
-    __shared__ int vTab[kTeamMax][kTeamTab];
-    const RecSource src{a.rec};
-    const bool cls = (lane >= 1) & (lane <= kCandMax);
-    const int n0 = wave;  // my slot
-    int pi = n0 < K ? __builtin_amdgcn_readfirstlane(sU[min(n0, kTailMax - 1)]) : -1;
-    int ps = n0 < K ? __builtin_amdgcn_readfirstlane(sStart[min(n0, kTailMax - 1)]) : 0;
-    vTab[wave][lane & (kTeamTab - 1)] = -1;
-    typename E::Slot slot = cand_no_line<typename E::Slot>();
-    auto request = [&](int person) { slot = line_of<E>(a, person, l32); };
-    if (n0 < K) request(pi);
-    __syncthreads();  // (sU / sStart have been read by everybody)
-#ifdef MISSLAP_TAIL_STAMP_TEAM
-    // diagnostic build: cycles of wavefront 0 per segment of a team round -> Ctl::dbg[6..9]: [6] bid of my slot,
-    // [7] barrier, [8] clean test / resolve / assign, [9] re-request, line rebuild
-    unsigned long long sacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sprev = __builtin_amdgcn_s_memtime();
-    const CycleStamp stamp{sacc, &sprev, wave == 0};
-#else
-    const NoStamp stamp;
-#endif
-    int par = 0;
-    for (;;) {
-        stamp.light(0);
-        int sp = -2;  // the person whose line was requested early (-2: nothing requested)
-        CandBuildArgs bd;
-        int bd_person = -1;
-        if (n0 < K) {  // wave-uniform: BID for my slot (slots < K are always occupied: the list is compact)
-            CandBid b;
-            b.hit = false;
-            cand_eval1(slot, cls, src, eps, b, st.err, [&](const CandBid &w) {
-                sp = w.prev;
-                request(sp);  // the owner my bidder evicts if it wins
-            });
-            if (!b.hit) {
-                const typename E::Raw none[4] = {};
-                const int e = a.row_ptr[pi + 1 + lane_zero()];
-                wave_bid_full<E, RecSource, true, false>(ed, src, ps, e, none, eps, b, bd, st.err);
-                bd_person = bd.want ? pi : -1;
-                st.misses += 1;
-                st.miss_edges += (unsigned long long)b.len;
-            }
-            st.edges += (unsigned long long)b.len;
-            st.bids += 1;
-            if (lane == 0) {
-                uKey[par][n0] = b.key;
-                uObj[par][n0] = b.obj;
-                uPrev[par][n0] = b.prev;
-                uPst[par][n0] = b.pstart;
-                uU[par][n0] = pi;
-                uS[par][n0] = ps;
-            }
-        }
-        stamp.light(1);
-        tail_barrier_lds();  // the bids are in LDS and every gather of the round is done; requests stay in flight
-        stamp.light(2);
-        {
-            const bool act = lane < K;
-            const int ls = min(lane, kTeamMax - 1);
-            const unsigned long long lkey = act ? uKey[par][ls] : 0ull;
-            const int lobj = act ? uObj[par][ls] : (-2 - lane);
-            const int lprev = act ? uPrev[par][ls] : 0, lpst = act ? uPst[par][ls] : 0;
-            int u = act ? uU[par][ls] : -1;  // the list: lane l holds slot l
-            int sx = act ? uS[par][ls] : 0;
-            // clean round?  (a) no object bid on twice: one compare-and-swap per slot into my private table
-            int hs = 0;
-            bool dup = false;
-            if (act) {
-                hs = (int)(((unsigned)lobj * 2654435761u) >> 26) & (kTeamTab - 1);
-                for (;;) {
-                    const int old = atomicCAS(&vTab[wave][hs], -1, lobj);
-                    if (old == -1) break;
-                    if (old == lobj) {
-                        dup = true;
-                        break;
-                    }
-                    hs = (hs + 1) & (kTeamTab - 1);
-                }
-            }
-            const bool contested = __any(dup);
-            if (act && !dup) vTab[wave][hs] = -1;  // (LDS operations of a wavefront complete in order)
-            const bool ends = __any(act && lprev == -1);  // (b) no chain ends
-            if (!contested && !ends) {
-                // every bidder wins (:375-385 has nothing to resolve); ASSIGN (:396-418); the list keeps its shape
-                if (act && n0 < K) apply_winner(a, u, sx, lobj, lprev, lkey);
-                pi = n0 < K ? __builtin_amdgcn_readlane(lprev, min(n0, kWave - 1)) : -1;
-                ps = n0 < K ? __builtin_amdgcn_readlane(lpst, min(n0, kWave - 1)) : 0;
-            } else {
-                // RESOLVE / ASSIGN / push_all_left in full, on lanes = slots
-                bool lose = false;
-                for (int m = 0; m < K; ++m) {  // :375-385, all pairs via readlane
-                    const int om = __builtin_amdgcn_readlane(lobj, m);
-                    const bool same = (om == lobj) && (m != lane);
-                    if (__any(same)) {  // wave-uniform
-                        const unsigned long long km = readlane_u64(lkey, m);
-                        lose |= same && (km > lkey || (km == lkey && m < lane));
-                    }
-                }
-                const bool won = act && !lose;
-                if (won && n0 < K) apply_winner(a, u, sx, lobj, lprev, lkey);  // :396-418 (serving wavefronts only)
-                u = won ? lprev : u;  // the evicted owner inherits the slot (:409) / hole (:412) / a loser stays
-                sx = won ? lpst : sx;
-                const unsigned long long kmask = (1ull << K) - 1ull;
-                const unsigned long long holes = __ballot(act && u == -1) & kmask;
-                const int Kn = K - __popcll(holes);
-                const unsigned long long lmask = (1ull << Kn) - 1ull;
-                unsigned long long hl = holes & lmask;            // empty slots left of K'
-                unsigned long long mv = ~holes & ~lmask & kmask;  // persons right of K'
-                while (hl) {  // wave-uniform: k-th hole <- k-th mover (:137-162)
-                    const int hk = __ffsll((long long)hl) - 1, mk = __ffsll((long long)mv) - 1;
-                    const int mu = __builtin_amdgcn_readlane(u, mk), ms = __builtin_amdgcn_readlane(sx, mk);
-                    if (lane == hk) {
-                        u = mu;
-                        sx = ms;
-                    }
-                    hl &= hl - 1;
-                    mv &= mv - 1;
-                }
-                K = Kn;
-                pi = n0 < K ? __builtin_amdgcn_readlane(u, min(n0, kWave - 1)) : -1;
-                ps = n0 < K ? __builtin_amdgcn_readlane(sx, min(n0, kWave - 1)) : 0;
-            }
-        }
-        stamp.light(3);
-        par ^= 1;
-        nits += 1;
-        const bool done = K <= 2 || nits >= max_iter;
-        // my slot's new occupant is usually exactly the person whose line was requested early; otherwise (a scanned
-        // row, a lost bid, a moved person) request now
-        if (!done && n0 < K && sp != pi) request(pi);
-        if (bd_person >= 0) tail_build(a, bd_person, bd, eps, st);
-        stamp.light(4);
-        if (done) break;
-    }
-#ifdef MISSLAP_TAIL_STAMP_TEAM
-    if (threadIdx.x == 0)
-        for (int k = 1; k <= 4; ++k) a.ctl->dbg[5 + k] += sacc[k];
-#endif
-    // hand the list back: every wavefront writes its own slot
-    if (lane == 0 && n0 < kTeamMax) {
-        sU[n0] = pi;
-        sStart[n0] = ps;
-    }
-    __syncthreads();
-}
-
 // ---- the team and duo rounds of handles with lines: few instructions, one barrier, the next gather issued ahead ---------
 // A wavefront of the tail issues one instruction every ~8 cycles whatever the instruction is (tools/micro/
 // exec_mask_bench.hip: dependent VALU 8.2 cycles, independent 6.1; profiles/r06_tail_overheads.txt), so a round is as long
@@ -885,9 +605,6 @@ __device__ __forceinline__ void tail_team1_mode(const TailArgs &a, const E &ed, 
 //     statistics that can be derived (line hits = bids - misses) are not counted;
 //   * wavefronts whose slot lies beyond K (K never grows) END after one more barrier: the barrier is then between the
 //     serving wavefronts only.
-#ifndef MISSLAP_TAIL_PIPE
-#define MISSLAP_TAIL_PIPE 3  // bit 0: the team rounds, bit 1: the duo rounds (0: the rounds as they were before round 6)
-#endif
 constexpr int kPipeTab = 4096;  // (K = 16: 3 % false positives of the clean test, K = 6: 0.4 %)
 __device__ __forceinline__ int pipe_hash(int obj) { return (int)(((unsigned)obj * 2654435761u) >> 20); }
 static_assert((1 << 12) == kPipeTab, "pipe_hash keeps the top 12 bits");
@@ -941,6 +658,19 @@ __device__ __forceinline__ bool tail_team1_pipe(const TailArgs &a, const E &ed, 
     bool have_g = false;  // grec = the (exact) records of my slot's line, gathered ahead
     int par = 0;
     const int ls = min(lane, kTeamMax - 1);
+    // The winners' stores of a clean round are ISSUED in the next round, behind its evaluation: a store right in front of
+    // the loop's back edge has the compiler's wait for the line / the gathered records (landed long ago, but loaded in the
+    // previous iteration) wait for the store's round trip too.  Nothing reads a record before that point -- a gather
+    // behind the barrier (no records gathered ahead) and a row scan issue the pending stores first.
+    bool pend = false;
+    PriceRec prec = PriceRec{0.0, -1, 0};
+    int pobj = 0;
+    auto flush_store = [&]() {
+        if (pend) {  // wave-uniform
+            if (lane < K) a.rec[pobj] = prec;  // ASSIGN (:396-418) of every slot, lanes = slots
+            pend = false;
+        }
+    };
     for (;;) {
         if (n0 >= K) {  // wave-uniform: my slot fell away (slots < K are always occupied: the list is compact)
             if (lane == 0) {
@@ -956,12 +686,16 @@ __device__ __forceinline__ bool tail_team1_pipe(const TailArgs &a, const E &ed, 
         b.hit = false;
         stamp.light(0);
         // BID for my slot (auction_.pyx:339-365)
-        if (!have_g) grec = cand_gather1(slot, cls, src);
-        cand_eval1_r(slot, grec, cls, eps, b, st.err, [&](const CandBid &w) {
+        if (!have_g) {
+            flush_store();
+            grec = cand_gather1(slot, cls, src);
+        }
+        cand_eval1_r(slot, grec, cls, eps, b, st.bad_hi, [&](const CandBid &w) {
             sp = w.prev;
             request(sp);  // the owner my bidder evicts if it wins
         });
         if (!b.hit) {  // (rare behind the maintenance pass: the scan and the line's rebuild stay inside this block)
+            flush_store();
             CandBuildArgs bd;
             const typename E::Raw none[4] = {};
             const int e = a.row_ptr[pi + 1 + lane_zero()];
@@ -971,6 +705,7 @@ __device__ __forceinline__ bool tail_team1_pipe(const TailArgs &a, const E &ed, 
             if (bd.want) tail_build(a, pi, bd, eps, st);
             b.hit = false;
         }
+        flush_store();  // (the common case: the previous round's stores, behind this round's evaluation)
         st.edges += (unsigned long long)b.len;
         st.bids += 1;
         stamp.light(1);
@@ -986,11 +721,12 @@ __device__ __forceinline__ bool tail_team1_pipe(const TailArgs &a, const E &ed, 
         }
         // the gather of the NEXT round, ahead of the barrier (a scanned row may have decided differently from its
         // line: then nothing was requested for the right person, and the next round gathers behind the barrier)
-        const bool have_n = b.hit && b.prev >= 0;
-        PriceRec nrec = PriceRec{0.0, -1, 0};
+        // (into grec itself -- its old contents are dead: a second variable is a copy at the loop's back edge, and the wait
+        // the compiler puts in front of that copy also waits for the round trip of the winners' stores)
+        have_g = b.hit && b.prev >= 0;
         int hc = 0;
-        if (have_n) {
-            nrec = cand_gather1(slot, cls, src);
+        if (have_g) {
+            grec = cand_gather1(slot, cls, src);
             hc = pipe_hash(slot.x);
         }
         stamp.light(2);
@@ -1012,10 +748,10 @@ __device__ __forceinline__ bool tail_team1_pipe(const TailArgs &a, const E &ed, 
                 // CLEAN: every bidder wins (:375-385 has nothing to resolve); the list keeps its shape.  The records
                 // gathered ahead are made exact FIRST and the winners' stores (ASSIGN, :396-418) are issued behind that:
                 // a wait for the gather that has a store behind it in the queue would wait for the store's round trip too
-                if (have_n) {
+                if (have_g) {
                     const int c = slot.x;
                     const bool own = c == b.obj;
-                    patch_rec(nrec, own, mine);
+                    patch_rec(grec, own, mine);
                     if (__any((tb >= r) & !own & cls & (c >= 0))) {  // rare: another slot bid on a candidate of my next bidder
                         for (int m = 0; m < K; ++m) {
                             const int om = __builtin_amdgcn_readlane(lobj, m);
@@ -1023,15 +759,15 @@ __device__ __forceinline__ bool tail_team1_pipe(const TailArgs &a, const E &ed, 
                             rm.price = readlane_f64(lrec.price, m);
                             rm.owner = __builtin_amdgcn_readlane(lrec.owner, m);
                             rm.ostart = __builtin_amdgcn_readlane(lrec.ostart, m);
-                            patch_rec(nrec, c == om, rm);
+                            patch_rec(grec, c == om, rm);
                         }
                     }
                 }
-                if (lane < K) a.rec[lobj] = lrec;
+                pend = true;
+                prec = lrec;
+                pobj = lobj;
                 pi = b.prev;
                 ps = b.pstart;
-                grec = nrec;
-                have_g = have_n;
             } else {
                 // RESOLVE / ASSIGN / push_all_left in full, on lanes = slots
                 const bool act = lane < K;
@@ -1085,6 +821,7 @@ __device__ __forceinline__ bool tail_team1_pipe(const TailArgs &a, const E &ed, 
         stamp.light(6);
         if (done) break;
     }
+    flush_store();
     nits += r;
 #ifdef MISSLAP_TAIL_STAMP_TEAM
     if (threadIdx.x == 0)
@@ -1129,17 +866,31 @@ __device__ __forceinline__ void tail_duo_pipe(const TailArgs &a, const E &ed, in
     PriceRec grec = PriceRec{0.0, -1, 0};
     bool have_g = false;
     int par = 0;
+    // (the two stores of a clean round are issued in the NEXT round, behind its evaluation: see tail_team1_pipe)
+    bool pend = false;
+    PriceRec prec = PriceRec{0.0, -1, 0};
+    int pobj = 0;
+    auto flush_store = [&]() {
+        if (pend) {  // wave-uniform
+            if (lane < 2) a.rec[pobj] = prec;  // ASSIGN (:396-418): lane 0 my record, lane 1 the other's
+            pend = false;
+        }
+    };
     for (;;) {
         int sp = -2;  // the person whose line was requested early (-2: nothing requested)
         CandBid b;
         b.hit = false;
         stamp.light(0);
-        if (!have_g) grec = cand_gather1(slot, cls, src);
-        cand_eval1_r(slot, grec, cls, eps, b, st.err, [&](const CandBid &x) {
+        if (!have_g) {
+            flush_store();
+            grec = cand_gather1(slot, cls, src);
+        }
+        cand_eval1_r(slot, grec, cls, eps, b, st.bad_hi, [&](const CandBid &x) {
             sp = x.prev;
             request(sp);  // the owner my bidder evicts if it wins
         });
         if (!b.hit) {  // (rare behind the maintenance pass: the scan and the line's rebuild stay inside this block)
+            flush_store();
             CandBuildArgs bd;
             const typename E::Raw none[4] = {};
             const int e = a.row_ptr[me + 1 + lane_zero()];
@@ -1149,6 +900,7 @@ __device__ __forceinline__ void tail_duo_pipe(const TailArgs &a, const E &ed, in
             if (bd.want) tail_build(a, me, bd, eps, st);
             b.hit = false;
         }
+        flush_store();  // (the common case: the previous round's stores, behind this round's evaluation)
         st.edges += (unsigned long long)b.len;
         st.bids += 1;
         stamp.light(1);
@@ -1160,9 +912,10 @@ __device__ __forceinline__ void tail_duo_pipe(const TailArgs &a, const E &ed, in
             D[par][w].rec = mine;
             D[par][w].aux = make_int4(b.obj, b.prev, b.pstart, 0);
         }
-        const bool have_n = b.hit && b.prev >= 0;
-        PriceRec nrec = PriceRec{0.0, -1, 0};
-        if (have_n) nrec = cand_gather1(slot, cls, src);  // the gather of the NEXT round, ahead of the barrier
+        // the gather of the NEXT round, ahead of the barrier (into grec itself: its old contents are dead, and a second
+        // variable is a copy at the loop's back edge with a wait for every outstanding store in front of it)
+        have_g = b.hit && b.prev >= 0;
+        if (have_g) grec = cand_gather1(slot, cls, src);
         stamp.light(2);
         tail_barrier_lds();  // both bids are in LDS and both gathers of the round have been issued against the old records
         stamp.light(3);
@@ -1174,20 +927,17 @@ __device__ __forceinline__ void tail_duo_pipe(const TailArgs &a, const E &ed, in
             // both bidders win different owned objects (:375-385 has nothing to resolve) and both slots pass to the
             // evicted owners.  The records gathered ahead are made exact FIRST, the stores (ASSIGN, :396-418, by both
             // wavefronts alike: lane 0 my record, lane 1 the other's) are issued behind that
-            if (have_n) {
+            if (have_g) {
                 const int c = slot.x;
-                patch_rec(nrec, c == b.obj, mine);
-                patch_rec(nrec, c == oaux.x, orec);
+                patch_rec(grec, c == b.obj, mine);
+                patch_rec(grec, c == oaux.x, orec);
             }
-            if (lane < 2) {
-                PriceRec rr = mine;
-                patch_rec(rr, lane == 1, orec);
-                a.rec[lane == 1 ? oaux.x : b.obj] = rr;
-            }
+            pend = true;
+            prec = mine;
+            patch_rec(prec, lane == 1, orec);
+            pobj = lane == 1 ? oaux.x : b.obj;
             me = b.prev;
             mys = b.pstart;
-            grec = nrec;
-            have_g = have_n;
         } else {
             // the two bids by slot, RESOLVE (:375-385: strict ">", the earlier list position keeps an object on equal
             // bids), ASSIGN (:396-418) by both wavefronts alike, push_all_left (:137-162) on two slots
@@ -1237,6 +987,7 @@ __device__ __forceinline__ void tail_duo_pipe(const TailArgs &a, const E &ed, in
         stamp.light(5);
         if (done) break;
     }
+    flush_store();
     nits += r;
 #ifdef MISSLAP_TAIL_STAMP_DUO
     if (w == 0 && lane == 0)
@@ -1253,7 +1004,7 @@ __device__ __forceinline__ void tail_duo_pipe(const TailArgs &a, const E &ed, in
 // with SIXTEEN wavefronts -- half the sweeps per wavefront in pass A, which is where a block round spends its time --
 // and nothing else: the solo / team code needs more than the 128 registers a 1024-thread workgroup leaves a
 // wavefront.  The host launches it ahead of the 512-thread kernel, which then finds K <= kTeamMax.
-// kTeamOnly (1024 threads as well): the rounds with 3..kTeamMax bidders, one slot per wavefront (tail_team1_mode).
+// kTeamOnly (1024 threads as well): the rounds with 3..kTeamMax bidders, one slot per wavefront (tail_team1_pipe).
 // kThreads = 128 ("duo / chain only", handles with lines): the rounds with K <= 2 and nothing else -- two wavefronts
 // for duo mode, wavefront 0 alone for the chain; the instance that carries every mode needs 185 VGPRs and spills 14
 // SGPRs, each spill a v_writelane / v_readlane pair inside a chain that is bound by its instruction count.
@@ -1307,7 +1058,7 @@ __device__ __forceinline__ void k_tail_body(TailArgs a, E ed) {
     const double eps = (double)a.eps;
     TailStats st;
     st.edges = st.miss_edges = st.builds = 0ull;
-    st.bids = st.misses = 0u;
+    st.bids = st.misses = st.bad_hi = 0u;
     st.err = 0;
     st.hint = 0.0;
     if (t == 0) sMissCnt = 0;
@@ -1343,6 +1094,7 @@ __device__ __forceinline__ void k_tail_body(TailArgs a, E ed) {
                 atomicAdd(&ctl->dbg[14], st.builds);
                 atomicAdd(&ctl->dbg[15], hit_edges);
             }
+            if (bad_hi_is_error(st.bad_hi)) st.err |= kErrNegativeBid;
             if (st.err) atomicOr(&ctl->err, st.err);
         }
     };
@@ -1352,10 +1104,7 @@ __device__ __forceinline__ void k_tail_body(TailArgs a, E ed) {
             // ---- K <= 2, lines: duo mode while two bidders are left (wavefronts 0 and 1, one bidder each), then
             // wavefront 0 runs the single-bidder chain alone
             mode_begin(0);
-            if (K == 2) {
-                if (MISSLAP_TAIL_PIPE & 2) tail_duo_pipe(a, ed, sU, sStart, K, nits, max_iter, eps, st);
-                else tail_duo_mode(a, ed, sU, sStart, K, nits, max_iter, eps, st);
-            }
+            if (K == 2) tail_duo_pipe(a, ed, sU, sStart, K, nits, max_iter, eps, st);
             if (wave == 1) {
                 flush_stats();
                 return;
@@ -1375,13 +1124,9 @@ __device__ __forceinline__ void k_tail_body(TailArgs a, E ed) {
         if (kTeamOnly) {
             if (K > 2 && nits < max_iter) {
                 mode_begin(1);
-                if (MISSLAP_TAIL_PIPE & 1) {
-                    if (tail_team1_pipe(a, ed, sU, sStart, K, nits, max_iter, eps, st)) {  // (this wavefront's slot fell away)
-                        flush_stats();
-                        return;
-                    }
-                } else {
-                    tail_team1_mode(a, ed, sU, sStart, K, nits, max_iter, eps, st);
+                if (tail_team1_pipe(a, ed, sU, sStart, K, nits, max_iter, eps, st)) {  // (this wavefront's slot fell away)
+                    flush_stats();
+                    return;
                 }
                 mode_end(1);
             }
@@ -1396,8 +1141,7 @@ __device__ __forceinline__ void k_tail_body(TailArgs a, E ed) {
                 return;
             }
             mode_begin(0);
-            if (MISSLAP_TAIL_PIPE & 2) tail_duo_pipe(a, ed, sU, sStart, K, nits, max_iter, eps, st);
-            else tail_duo_mode(a, ed, sU, sStart, K, nits, max_iter, eps, st);
+            tail_duo_pipe(a, ed, sU, sStart, K, nits, max_iter, eps, st);
             if (wave == 1) {
                 flush_stats();
                 return;
