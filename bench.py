@@ -37,6 +37,7 @@ def cpu_baseline(cfg, budget_rounds, whole, args=None):
     """Oracle (port of the reference, single thread like the reference, faithful O(M) assignment walk) on the same
     workload: the first `budget_rounds` rounds as the bounded sample, and -- `whole` -- the complete solve in the
     same run (about 30-50 s at C3; the sample over-weights the big bandwidth-bound rounds of the first phase)."""
+    import numpy as np
     from oracle import oracle as orc
     from sslap_amd import synth
     loc, val = workload(args, synth) if args is not None else synth.gen_config(cfg)
@@ -70,6 +71,21 @@ def cpu_baseline(cfg, budget_rounds, whole, args=None):
         m = s.raw_meta()
         out.update(whole_solve_medges_s=round(int(m.edges_scanned) / dt / 1e6, 2), whole_solve_s=round(dt, 2),
                    whole_solve_rounds=int(m.its), whole_solve_edges=int(m.edges_scanned))
+        # BASELINE.md section 3's second CPU figure: the same port with the assignment phase visiting only the objects that
+        # received a bid (O(#bids) per round) instead of the reference's walk over all M objects (auction_.pyx:394) --
+        # what a maintainer's first optimisation of the CPU path would give; same assignment (checked below and in
+        # tests/test_oracle_golden.py), never the parity oracle
+        sol_faithful = np.ctypeslib.as_array(orc.lib().oracle_person_to_object(s._h), (s.N,)).copy()
+        loc2, val2 = workload(args, synth) if args is not None else synth.gen_config(cfg)
+        s2 = orc.from_sparse(loc2, val2, problem="max", max_iter=10**8, cardinality_check=False)
+        s2.set_assign_by_bidders(True)
+        t2 = time.perf_counter()
+        sol2 = s2.solve()
+        dt2 = time.perf_counter() - t2
+        out.update(optimised_whole_solve_s=round(dt2, 2),
+                   optimised_whole_solve_medges_s=round(int(s2.raw_meta().edges_scanned) / dt2 / 1e6, 2),
+                   optimised_kind="port, assignment phase through the round's bidders (O(#bids)) instead of the O(M) walk",
+                   optimised_same_assignment=bool(np.array_equal(sol2, sol_faithful)))
     return out
 
 
@@ -512,28 +528,33 @@ def run_rank(args, rank, world, local_rank, ranks, comm, shared, backend):
             tj = json.load(open(tpath))
             traffic_meta = dict(traffic_commit=tj.get("commit"), traffic_source_sha256=tj.get("source_sha256"),
                                 traffic_file=os.path.relpath(tpath, ROOT))
-            # (the bid instance of the full-scan engine: template argument 10 of <..., MODE, kFmt, kP32> is MODE = 0; MODE 1 is the
-            # eCE pass.  The gather engine: the instance with the most bytes, i.e. the one that does the full scans)
+            # (the bid instance of the full-scan engine: template argument 10 of <..., MODE, kFmt> is MODE = 0; MODE 1 is the
+            # eCE pass.  The gather engine: the instance whose launches the events of this run bracketed -- profile level 1
+            # times the K = N launches only, and those are k_bid<E, PriceSource, kLines = 1> (lines in use: any line that
+            # still answers is used, nothing is built) or <..., 0> (no lines); never the instance with the most bytes x
+            # launches, which at C5 is the small-round instance kLines = 2)
             def is_bid_instance(k):
                 if (rk_name + "<") not in k:
                     return False
+                targs = [t.strip() for t in k[k.index("<") + 1:k.rindex(">")].split(",")]
                 if rk_name != "k_bid_tiled":
-                    return True
-                targs = k[k.index("<") + 1:k.rindex(">")].split(",")
-                return len(targs) >= 10 and targs[9].strip() == "0"  # <threads, rows, batch, depth, cols, loaders, ABL, lanes, split, MODE, ...>
+                    return len(targs) == 3 and targs[1].endswith("PriceSource") and targs[2] in ("0", "1")
+                return len(targs) >= 10 and targs[9] == "0"  # <threads, rows, batch, depth, cols, loaders, ABL, lanes, split, MODE, ...>
             tk = sorted(((k, v) for k, v in tj["kernels"].items() if is_bid_instance(k)),
-                        key=lambda kv: -(kv[1]["read_avg"] + kv[1]["write_avg"]) * kv[1]["launches"])
+                        key=lambda kv: -kv[1]["launches"])
             if tk and tj.get("source_sha256") == source_digest():
-                if rk_name == "k_bid_tiled":
-                    # the bid scans of the engine are TWO instances since the launches of a phase alternate their walking
-                    # direction (kRev): bytes per launch = the launch-weighted mean over both, like avg_launch_us
-                    n_l = sum(v["launches"] for _, v in tk)
-                    traffic = round(sum((v["read_avg"] + v["write_avg"]) * v["launches"] for _, v in tk) / max(n_l, 1))
-                    traffic_meta["traffic_kernel"] = " + ".join(k for k, _ in tk)
-                    traffic_meta["traffic_launches_measured"] = n_l
-                else:
-                    traffic = round(tk[0][1]["read_avg"] + tk[0][1]["write_avg"])
-                    traffic_meta["traffic_kernel"] = tk[0][0]
+                # the timed launches may be TWO instances (the engine: the launches of a phase alternate their walking
+                # direction, kRev; the gather kernel: a handle that takes its lines into use during the solve): bytes per
+                # launch = the launch-weighted mean over them, like avg_launch_us
+                n_l = sum(v["launches"] for _, v in tk)
+                traffic = round(sum((v["read_avg"] + v["write_avg"]) * v["launches"] for _, v in tk) / max(n_l, 1))
+                traffic_meta["traffic_kernel"] = " + ".join(k for k, _ in tk)
+                traffic_meta["traffic_launches_measured"] = n_l
+                traffic_meta["traffic_max_launch"] = round(max(v["read_max"] + v["write_max"] for _, v in tk))
+            elif tj.get("source_sha256") == source_digest():
+                # (small problems: the K = N launches are k_bid<..., 2>, the instance of every untimed mid round as well --
+                # the per-kernel averages of the PMC pass cannot be attributed to the timed launches)
+                traffic_meta["traffic_note"] = "the timed launches share their kernel instance with untimed rounds: not attributable"
             else:
                 traffic_meta["traffic_stale"] = True
         # metric (ii) of SURVEY 8(d): throughput over ALL grid-kernel bid launches (full-scan engine + k_bid), from
@@ -674,9 +695,30 @@ def run_rank(args, rank, world, local_rank, ranks, comm, shared, backend):
                 "fullscan_frac_of_measured": round(fs_achieved / read_peak, 5),
                 "timing": "HIP events handed to the launch (hipExtLaunchKernel): begin / end of the kernel itself",
                 "traffic": traffic,
+                "traffic_over_algorithmic": (round(traffic / max(rk_edges * bpe / max(rk_launches, 1), 1.0), 3)
+                                             if traffic else None),
                 "traffic_source": "rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction calibrated on known-size "
                                   "kernels + WRITE_SIZE), bytes per launch" if traffic else None,
                 **traffic_meta,
+                # N ranks: the one figure of this path that is expected to scale -- the full scans (K = N launches) of all
+                # ranks together, every rank scanning its shard at the same time: (sum of the shards' edges) / (slowest
+                # rank's kernel time), against N x 8 TB/s -- and who took part.  DESIGN.md section 7 /
+                # profiles/r06_scale_expectation.json say what to expect per N.
+                "all_ranks": {
+                    "n_ranks": world,
+                    "fullscan_medges_s": (round(fs_all_edges / (fs_max_ms * 1e-3) / 1e6, 1) if fs_all_edges and fs_max_ms
+                                          else round(fs_edges / (fs_ms * 1e-3) / 1e6, 1) if fs_ms else None),
+                    "fullscan_frac_of_hbm_peak": (round(fs_all_edges * bpe / (fs_max_ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), 4)
+                                                  if fs_all_edges and fs_max_ms else round(fs_achieved / HBM_PEAK_GBS, 4)),
+                    "sharded_rounds_per_solve": rank_list[0]["sharded_rounds_per_solve"],
+                    "exchanges_per_solve": 2 * rank_list[0]["sharded_rounds_per_solve"],
+                    "rccl_nranks": (rank_list[0]["comm"]["transport_ranks"]
+                                    if rank_list[0]["comm"] and rank_list[0]["comm"]["kind"] == "rccl" else None),
+                    "comm_kind": rank_list[0]["comm"]["kind"] if rank_list[0]["comm"] else None,
+                    "comm_ranks_seen_by_every_rank": [r["comm"]["transport_ranks"] if r["comm"] else None for r in rank_list],
+                    "distinct_gpus": len({r["device_uuid"] for r in rank_list}),
+                    "mode": "replicas" if replicas else "sharded" if world > 1 else "single",
+                },
                 # (gather engine only) what the same launches come to when the rows that candidate lines answered are
                 # counted as well -- the reference-equivalent count, NOT bytes moved; never to be read as a bandwidth
                 "edges_counted_incl_rows_answered_from_lines": rk_edges_counted,

@@ -67,8 +67,8 @@ typedef struct misslap_options {
                                 sharded round, < 0 = shard every grid round */
     int32_t cand_mode;       /* candidate lines: 0 = on, 1 = off (every bid scans its whole row; A/B timing, parity
                                 tests), 2 = on, but no maintenance pass ahead of the tail kernels (k_refresh_lines) */
-    int32_t partial_in_list_order; /* 1 = partial rounds of the full-scan engine take their bidders in list order
-                                instead of person order (A/B timing, parity tests) */
+    int32_t partial_in_list_order; /* ignored since round 6 (partial rounds of the full-scan engine always take their bidders
+                                in person order: the list-order form lost every A/B); the slot keeps the layout */
     int32_t nnz_limit;       /* > 0 lowers the entry limit of a handle (default 2^31 - 1: int32 row pointers), for
                                 tests of that guard */
     int32_t cand_build_max_K;/* > 0: k_bid (re)builds lines only in rounds with at most so many bidders */
@@ -152,10 +152,8 @@ typedef struct misslap_meta {
     int32_t phases_with_lines;   /* eps-phases of the solve that ran WITH candidate lines (all of them unless eps fell below
                                     the rounding error of a price update on the way: see misslap_create) */
     int32_t eps_phases;          /* eps-phases of the solve (nreductions + 1 when it ran to its end) */
-    int32_t filter_undecided;    /* -1: the full-scan engine's scans are exact.  >= 0: they run as fp32-tile FILTER scans
-                                    (opt-in, MISSLAP_TILED_P32=1: price tiles in single precision, the two best edges of a
-                                    row confirmed exactly) and this many bids of the solve were handed to the exact scan
-                                    because the rounding margin could not separate a row's second and third value */
+    int32_t filter_undecided;    /* reserved, always -1 (the counter of round 5's opt-in fp32-tile filter scans, which were
+                                    measured slower than the exact scans and removed in round 6; the slot keeps the layout) */
 } misslap_meta;
 
 /* Snapshot of the round state (tests / multi-GPU driver). */

@@ -48,6 +48,7 @@ typedef struct oracle_solver {
     uint64_t edges_scanned, bids_made;
     double t_bid, t_total;
     int time_phases;
+    int assign_by_bidders; /* 0 (default): the reference's O(M) walk; 1: the same assignments, O(#bids) -- see bid_and_assign */
 } oracle_solver;
 
 static double now_s(void) {
@@ -219,10 +220,17 @@ static void bid_and_assign(oracle_solver *s) {
         }
     }
 
-    /* ASSIGNMENT PHASE :388-427: walk over ALL objects with early break */
+    /* ASSIGNMENT PHASE :388-427: walk over ALL objects with early break.
+     * assign_by_bidders (bench.py's "optimised" CPU figure; never the parity oracle): the same
+     * loop body for the objects that received a bid, found through the round's bidders instead of a walk over all M
+     * objects.  Every write below touches only the winner i, its object j and j's previous owner, all distinct between
+     * winners, so the visiting order does not change the result (tests/test_oracle_golden.py checks every fixture). */
     size_t people_to_unassign_ctr = 0, people_to_assign_ctr = 0;
     int bid_ctr = 0;
-    for (int j = 0; j < (int)s->num_cols; ++j) {
+    const int by_bidders = s->assign_by_bidders;
+    const int walk_n = by_bidders ? (int)num_bidders : (int)s->num_cols;
+    for (int w = 0; w < walk_n; ++w) {
+        const int j = by_bidders ? objects_bidded[w] : w;
         int i = best_bidders[j];
         if (i != -1) {
             p[j] = best_bids[j];
@@ -374,6 +382,7 @@ ORACLE_API void oracle_get_meta(const oracle_solver *s, oracle_meta *m) {
 }
 
 ORACLE_API void oracle_set_timing(oracle_solver *s, int on) { s->time_phases = on; }
+ORACLE_API void oracle_set_assign_by_bidders(oracle_solver *s, int on) { s->assign_by_bidders = on; }
 ORACLE_API const int *oracle_person_to_object(const oracle_solver *s) { return s->person_to_object; }
 ORACLE_API const int *oracle_object_to_person(const oracle_solver *s) { return s->object_to_person; }
 ORACLE_API const double *oracle_prices(const oracle_solver *s) { return s->p; }

@@ -48,6 +48,7 @@ def lib():
         L.oracle_get_meta.argtypes = [C.c_void_p, C.POINTER(OracleMeta)]
         L.oracle_destroy.argtypes = [C.c_void_p]
         L.oracle_set_timing.argtypes = [C.c_void_p, C.c_int]
+        L.oracle_set_assign_by_bidders.argtypes = [C.c_void_p, C.c_int]
         L.oracle_objective.argtypes = [C.c_void_p]
         L.oracle_objective.restype = C.c_double
         for name, typ in (("oracle_person_to_object", C.c_int), ("oracle_object_to_person", C.c_int),
@@ -91,6 +92,11 @@ class OracleSolver:
 
     def set_timing(self, on=True):
         lib().oracle_set_timing(self._h, int(on))
+
+    def set_assign_by_bidders(self, on=True):
+        """The assignment phase through the round's bidders, O(#bids), instead of the reference's O(M) walk over all
+        objects (auction_.pyx:394): same result, used only for bench.py's `optimised` CPU figure."""
+        lib().oracle_set_assign_by_bidders(self._h, int(on))
 
     def step(self):
         return lib().oracle_step(self._h)

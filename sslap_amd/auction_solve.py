@@ -18,16 +18,15 @@ import numpy as np
 
 from . import _lib
 
+# environment defaults of the keyword options (everything else is a keyword only): the device, the tail threshold
+# (__graft_entry__.smoke and the parity suite switch it), the launch shape of the engine (tools/ab_shapes*.sh)
 _ENV_DEVICE = "MISSLAP_DEVICE"
 _ENV_TAIL = "MISSLAP_TAIL_THRESHOLD"
-_ENV_PROFILE = "MISSLAP_PROFILE"
-_ENV_RPS = "MISSLAP_ROUNDS_PER_SYNC"
-_ENV_TILED = "MISSLAP_TILED_MIN_K"  # 0 default, < 0 never use the LDS-tiled bid kernel, > 0 minimum K
 
 
 def _options(problem, eps_start, max_iter, device=None, tail_threshold=None, profile=None, force_f64=False,
              input_on_device=False, shard=None, rounds_per_sync=None, tiled_min_k=None, tiled_shape=None, shard_min_k=None,
-             engine=None, cand=None, nnz_limit=None, order_partial=None, cand_build_max_k=None, cand_refresh=None,
+             engine=None, cand=None, nnz_limit=None, cand_build_max_k=None, cand_refresh=None,
              input_stream=None):
     if problem not in ("min", "max"):
         # the reference treats every string other than 'min' as 'max' (auction_.pyx:236, :502)
@@ -43,28 +42,24 @@ def _options(problem, eps_start, max_iter, device=None, tail_threshold=None, pro
     o.input_stream = None if input_stream is None else C.c_void_p(int(input_stream))
     o.tail_threshold = int(os.environ.get(_ENV_TAIL, -1)) if tail_threshold is None else int(tail_threshold)
     o.force_f64_values = 1 if force_f64 else 0
-    o.profile = int(os.environ.get(_ENV_PROFILE, 0)) if profile is None else int(profile)
-    o.rounds_per_sync = int(os.environ.get(_ENV_RPS, 0)) if rounds_per_sync is None else int(rounds_per_sync)
+    o.profile = 0 if profile is None else int(profile)
+    o.rounds_per_sync = 0 if rounds_per_sync is None else int(rounds_per_sync)
     if shard is not None:
         o.shard_rank, o.shard_world = int(shard[0]), int(shard[1])
-    o.tiled_min_K = int(os.environ.get(_ENV_TILED, 0)) if tiled_min_k is None else int(tiled_min_k)
+    o.tiled_min_K = 0 if tiled_min_k is None else int(tiled_min_k)  # 0 default, < 0 never the LDS-tiled engine, > 0 minimum K
     # launch shape of k_bid_tiled: None / env unset = chosen by the library; k = shape k of misslap.hip:kTiledShapes
     shape = os.environ.get("MISSLAP_TILED_SHAPE") if tiled_shape is None else tiled_shape
     o.tiled_shape = 0 if shape is None else int(shape) + 1
-    o.tiled_force = int(os.environ.get("MISSLAP_ENGINE", 0)) if engine is None else int(engine)
-    o.shard_min_K = int(os.environ.get("MISSLAP_SHARD_MIN_K", 0)) if shard_min_k is None else int(shard_min_k)
-    # candidate lines (per-person exact bid shortcut, csrc/device_common.hpp): on by default, 0 = off (A/B runs)
-    # (cand=2 / MISSLAP_CAND=2: lines without the maintenance pass ahead of the tail kernels)
-    c = int(os.environ.get("MISSLAP_CAND", 1)) if cand is None else int(cand)
+    o.tiled_force = 0 if engine is None else int(engine)
+    o.shard_min_K = 0 if shard_min_k is None else int(shard_min_k)
+    # candidate lines (per-person exact bid shortcut, csrc/device_common.hpp): on by default, 0 = off (A/B runs),
+    # 2 = lines without the maintenance pass ahead of the tail kernels
+    c = 1 if cand is None else int(cand)
     o.cand_mode = 1 if c == 0 else (2 if c == 2 else 0)
-    # partial rounds of the full-scan engine in person order (kernels_tiled.hpp, k_order_*): on by default, 0 = list order
-    o.partial_in_list_order = ((1 - int(os.environ.get("MISSLAP_ORDER_PARTIAL", 1))) if order_partial is None
-                               else (0 if order_partial else 1))
-    o.cand_build_max_K = (int(os.environ.get("MISSLAP_CAND_BUILD_MAX_K", 0)) if cand_build_max_k is None
-                          else int(cand_build_max_k))
-    # k_bid rebuilds a line that hits with fewer live candidates than this (None / env unset = library default)
-    refresh = os.environ.get("MISSLAP_CAND_REFRESH") if cand_refresh is None else cand_refresh
-    o.cand_refresh_min = 0 if refresh is None else int(refresh) + 1
+    o.partial_in_list_order = 0  # (ignored by the library since round 6)
+    o.cand_build_max_K = 0 if cand_build_max_k is None else int(cand_build_max_k)
+    # k_bid rebuilds a line that hits with fewer live candidates than this (None = library default)
+    o.cand_refresh_min = 0 if cand_refresh is None else int(cand_refresh) + 1
     o.nnz_limit = 0 if nnz_limit is None else int(nnz_limit)  # tests of the int32 row-pointer guard
     return o
 

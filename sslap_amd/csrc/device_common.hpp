@@ -58,11 +58,9 @@ struct Ctl {
     int obj_minexp;        // smallest binary exponent of a lowest set bit among the contributions
     int n_need;            // entries of RoundArgs::need_list (long rows whose lines the maintenance pass found spent)
     int arrive;            // k_round_fused: workgroups of the launch that have handed their bids over (0 between launches)
-    int n_und;             // persons an fp32-tile filter scan could not decide (TiledArgs::und; zeroed in front of the scan)
     unsigned long long dbg[16]; // tail accounting: [0..2] rounds per mode, [3..5] 10-ns ticks, [12..15] bids / line hits /
                                 // builds / hit edges; [6..11] cycles per segment in -DMISSLAP_TAIL_STAMP* builds
     unsigned long long val_cnt[4]; // k_validity: distinct owned objects, sol < 0, sol >= n_rows, invalid selected entries
-    unsigned long long und_total;  // persons the fp32-tile filter scans of the solve handed to the exact scan (sum of n_und)
 };
 
 // ---- live status ---------------------------------------------------------------------------------

@@ -28,15 +28,19 @@ double now_ms() {
     using clk = std::chrono::steady_clock;
     return std::chrono::duration<double, std::milli>(clk::now().time_since_epoch()).count();
 }
-// MISSLAP_TRACE_CREATE=1: where a handle's setup time goes (stderr, one line per stage; the stream is drained at every
-// stage, so the sum is a little above an untraced create)
+// Diagnostics build (-DMISSLAP_DIAG), MISSLAP_TRACE_CREATE=1: where a handle's setup time goes (stderr, one line per stage;
+// the stream is drained at every stage, so the sum is a little above an untraced create)
 struct CreateTrace {
     bool on;
     double t0;
     hipStream_t st;
     explicit CreateTrace(hipStream_t s) : st(s) {
+#ifdef MISSLAP_DIAG
         const char *e = std::getenv("MISSLAP_TRACE_CREATE");
         on = e && e[0] == '1';
+#else
+        on = false;
+#endif
         t0 = now_ms();
     }
     void stage(const char *name) {
@@ -111,10 +115,8 @@ const int kTiledShapes[kNumTiledShapes][8] = {
 // ... and for the record formats 1..3 of the tile-major copy (fp64 values, rows with unsorted columns): the shapes 0 / 8 /
 // 9, i.e. {1024 threads, 4 persons per lane group, 2 in flight, 2 loads per segment, half tiles, 3 loaders} x lanes
 #define MISSLAP_BID_KERNEL_FMT(GL, FMT) k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 3, 0, GL, 1, 0, FMT>
-// ... and the fp32-tile filter scan (kP32) of format 0 in the same three shapes
 // ... and the backward walk (kRev) of the column-keyed formats 0 / 1 in the same three shapes
-#define MISSLAP_BID_KERNEL_REV(GL, FMT) k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 3, 0, GL, 1, 0, FMT, 0, 1>
-#define MISSLAP_BID_KERNEL_P32(GL) k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 3, 0, GL, 1, 0, 0, 1>
+#define MISSLAP_BID_KERNEL_REV(GL, FMT) k_bid_tiled<1024, 4, 2, 2, kTileColsHalf, 3, 0, GL, 1, 0, FMT, 1>
 #define MISSLAP_FOR_FMT_LANES(X) X(1, 4) X(1, 8) X(1, 16) X(2, 4) X(2, 8) X(2, 16) X(3, 4) X(3, 8) X(3, 16)
 inline size_t tiled_lds_bytes(int tile_cols) {  // see the LDS map in k_bid_tiled; + statistics scratch
     const size_t doubles = tile_cols == kTileColsBig ? (size_t)tile_cols + 2 : 2 * (size_t)tile_cols + 128;
@@ -124,17 +126,9 @@ inline size_t tiled_lds_bytes(int tile_cols) {  // see the LDS map in k_bid_tile
 // Profiled launches (options.profile): the two events are handed to the launch itself (hipExtLaunchKernel), so they
 // carry the begin / end timestamps of the KERNEL -- what a rocprofv3 kernel trace reports.  Events recorded around a
 // launch on the stream bracket the dispatch gap as well (~7 us per launch at C3: 92.4 against 85.6 us in round 2).
-// MISSLAP_PROFILE_PLAIN_EVENTS=1 selects the bracketing form (A/B of the two clocks).
-inline bool plain_events() {
-    static const bool v = [] {
-        const char *e = std::getenv("MISSLAP_PROFILE_PLAIN_EVENTS");
-        return e && e[0] == '1';
-    }();
-    return v;
-}
 #define MISSLAP_LAUNCH_TIMED(PR, KERNEL, GRID, BLOCK, LDS, STREAM, ...)                              \
     do {                                                                                            \
-        if ((PR) && !plain_events()) {                                                              \
+        if (PR) {                                                              \
             hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, (PR)->start, (PR)->stop, 0, __VA_ARGS__); \
         } else {                                                                                    \
             if (PR) (void)hipEventRecord((PR)->start, STREAM);                                      \
@@ -274,8 +268,7 @@ struct misslap_solver {
     bool line_maintenance = true;  // k_refresh_lines ahead of the tail kernels (options.reserved[4] = 2: off)
     int cand_refresh_min = kDefaultCandRefresh;
     bool round_ordered = false;  // the current round's bidders were taken in person order (k_order_*, partial tiled rounds)
-    bool order_partial = true;   // ... which options.reserved[5] = 1 turns off (A/B, parity tests)
-    int apply_bidders_ratio = 2;  // k_apply_bidders while K * ratio <= M (env MISSLAP_APPLY_BIDDERS_RATIO: A/B; huge = never)
+    int apply_bidders_ratio = 2;  // k_apply_bidders while K * ratio <= M
     bool profile_all = false;  // profile >= 2: events around every k_bid launch, not only the full scans
     int rounds_per_sync = kDefaultRoundsPerSync;
     bool rounds_per_sync_auto = true;  // not set by the caller: kRoundsPerSyncLive while the live status is in use
@@ -286,11 +279,7 @@ struct misslap_solver {
     bool profile = false;
     int K_ub = 0;  // host-side upper bound of K (K never grows inside a phase)
     bool K_exact = false;  // K_ub was read from the device and no round has been enqueued since
-    // fp32-tile filter scans of the full-scan engine (opt-in, MISSLAP_TILED_P32=1; kernels_tiled.hpp, kP32)
-    float *tprice32 = nullptr;   // fp32 mirror of the prices, T * kTileCols + 256 entries (the fills run past a tile's end)
-    int2 *und_list = nullptr;    // [n_rows] persons a filter scan could not decide
     bool walk_rev_next = false;  // the next engine launch of this eps-phase walks the column tiles backwards (walk_backwards)
-    bool tmirror_valid = true;   // no kernel that does not keep the mirror (tail kernels, small rounds) has written a price since its last rebuild
     bool ece_flag_clear = false;  // Ctl::ece_fail is 0 on the device (k_init_state, k_reset_phase) and no test has run since
     int ctl_fresh = 0;  // nothing enqueued since the last read and the pinned mirror h_ctl holds: 2 = the device's whole
                         // control block (read_ctl), 1 = its K / nits / error bits (a live status read), 0 = neither

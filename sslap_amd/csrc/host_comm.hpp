@@ -79,18 +79,10 @@ inline RcclApi &rccl_api() {
 
 constexpr int kNcclInt32 = 2, kNcclInt64 = 4, kNcclMax = 2, kNcclMin = 3;
 
-// The rounds of the full-scan regime are issued one at a time behind a status read, K known exactly, also WITHOUT a
-// communicator.  MISSLAP_BIG_ROUNDS_BATCHED=1 sends them through the batched path instead (status read trailing by
-// one round, no queue drain in front of each): measured in round 4 -- C4 7.99 -> 7.71 ms per solve, C3 unchanged -- and
-// NOT the default: on the stale upper bound of K the two or three rounds behind the end of the regime launch the scan
-// engine for nothing, and those no-op launches are launches of the roofline kernel (C3: all-launch fraction 0.419 -> 0.404).
-inline bool big_rounds_exact_env() {
-    static const bool v = [] {
-        const char *e = std::getenv("MISSLAP_BIG_ROUNDS_BATCHED");
-        return !(e && e[0] == '1');
-    }();
-    return v;
-}
+// (The rounds of the full-scan regime are issued one at a time behind a status read, K known exactly, also WITHOUT a
+// communicator.  Sending them through the batched path -- status read trailing by one round -- was measured in round 4:
+// C4 7.99 -> 7.71 ms per solve, C3 unchanged, but on the stale upper bound of K the two or three rounds behind the end of
+// the regime launch the scan engine for nothing: C3 all-launch fraction 0.419 -> 0.404.  Not kept.)
 
 // The solve loop of AuctionSolver.solve() (auction_.pyx:268-306) over the ranks of a communicator, written against the
 // round operations of misslap_round_ops (the GPU handle's, or a test's stand-ins).  Control decisions are taken from
@@ -119,12 +111,10 @@ int drive_sharded(const misslap_round_ops *o, misslap_comm *c, Fail &&fail) {
             int64_t K = 0, its = 0;
             if ((rc = o->status(o->ctx, &K, &its))) return rc;
             if (K == 0 || its >= o->max_iter) break;
-            if ((c || big_rounds_exact_env()) && K >= o->shard_min_K && K > o->tail_threshold) {
+            if (K >= o->shard_min_K && K > o->tail_threshold) {
                 // a big round: bidders sharded over the ranks, per-object arg-max exchanged.  K is exact here, so
                 // the device-side decision "K >= shard_min_K" is the same on every rank.  No host read until the
-                // round is complete.  (Without a communicator there is nothing to exchange and nothing that needs K
-                // exactly: the big rounds then go through the batched path below, whose status read trails the
-                // rounds instead of draining the queue in front of every one of them.)
+                // round is complete.  (The same without a communicator: nothing is exchanged.)
                 if (c) c->sharded_rounds += 1;
                 if ((rc = o->round_bid(o->ctx))) return rc;
                 if ((rc = exchange(true))) return rc;

@@ -83,21 +83,13 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
     const long long avg_row = nnz / h->n_rows;
     h->avg_row_len = avg_row;
     h->max_row_len = st.max_row_len;
-    static const long long long_from_env = [] {
-        const char *e = std::getenv("MISSLAP_LONG_ROWS_FROM");
-        return e ? std::atoll(e) : (long long)kLongRowsFrom;
-    }();
-    h->long_rows = st.max_row_len > kCandRowMax && avg_row >= long_from_env && avg_row <= kCandLongMax;
+    h->long_rows = st.max_row_len > kCandRowMax && avg_row >= (long long)kLongRowsFrom && avg_row <= kCandLongMax;
     // ... below that (C4's 300 edges per row, a dense 600^2) only once the solve has shown that its tail is long:
     // launch_tail switches the builder on after max(100, n_rows / 64) tail rounds
     // (... and so do the long rows of a handle whose AVERAGE row keeps a line, where they are many: 40 000 rows of 256
     // edges on average, half of them longer: 208 -> 119 ms per solve; a few stragglers -- C3 has rows of 260 edges -- are left
     // to their scans, a pass over all rows every few hundred tail rounds costs more than they do)
-    static const int mixed_pct_env = [] {
-        const char *e = std::getenv("MISSLAP_LONG_MIXED_PCT");
-        return e ? std::atoi(e) : kLongRowsMixedPercent;
-    }();
-    const bool many_long = (long long)st.long_rows * 100 >= (long long)mixed_pct_env * h->n_rows;
+    const bool many_long = (long long)st.long_rows * 100 >= (long long)kLongRowsMixedPercent * h->n_rows;
     h->long_rows_later = !h->long_rows && (avg_row > kCandRowMax || (st.max_row_len > kCandRowMax && many_long)) &&
                          avg_row <= kCandLongMax && cand_mode != 1;
     if (h->thr < 0) {  // library default: by whether the persons will have candidate lines (rows of <= 256 edges)
@@ -207,16 +199,11 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
                 HIP_TRY(hipStreamSynchronize(h->stream));
                 return MISSLAP_OK;
             };
-            // MISSLAP_TILED_CARRY_INDEX=1 (A/B timing, tests): the stored-index formats also for column-sorted rows
-            static const bool carry_env = [] {
-                const char *e = std::getenv("MISSLAP_TILED_CARRY_INDEX");
-                return e && e[0] == '1';
-            }();
             if ((rc = count_and_scan(false))) return rc;
             // A row that stores an entry more than once (legal: the last one is the choice, auction_.pyx:467-471) is
             // ascending but not strictly: it takes the stored-index formats too -- formats 0 / 1 order equal values by
             // the COLUMN (k_bid_tiled, kKeyCol), which must then be unique within a row.
-            bool carry = carry_env || (unsorted & 2) != 0;
+            bool carry = (unsorted & 2) != 0;
             bool usable = true;
             if (carry) usable = st.max_row_len <= 65536;
             if (unsorted & 1) {
@@ -307,9 +294,6 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
                     HIP_TRY(hipFuncSetAttribute((const void *)MISSLAP_BID_KERNEL_REV(4, 0), at, (int)tiled_lds_bytes(kTileColsHalf)));
                     HIP_TRY(hipFuncSetAttribute((const void *)MISSLAP_BID_KERNEL_REV(8, 0), at, (int)tiled_lds_bytes(kTileColsHalf)));
                     HIP_TRY(hipFuncSetAttribute((const void *)MISSLAP_BID_KERNEL_REV(16, 0), at, (int)tiled_lds_bytes(kTileColsHalf)));
-                    HIP_TRY(hipFuncSetAttribute((const void *)MISSLAP_BID_KERNEL_P32(4), at, (int)tiled_lds_bytes(kTileColsHalf)));
-                    HIP_TRY(hipFuncSetAttribute((const void *)MISSLAP_BID_KERNEL_P32(8), at, (int)tiled_lds_bytes(kTileColsHalf)));
-                    HIP_TRY(hipFuncSetAttribute((const void *)MISSLAP_BID_KERNEL_P32(16), at, (int)tiled_lds_bytes(kTileColsHalf)));
                     switch (check_lanes(h)) {  // the check pass on the same engine (launch_rows_all)
 #define X(GL)                                                                                                        \
     case GL:                                                                                                         \
@@ -357,15 +341,6 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
                 blk.want(&h->pmax_bits, 1);
                 h->cmax32 = (float)max_abs_d;
             }
-            // the fp32-tile filter scans of the full-scan engine (kernels_tiled.hpp, kP32; opt-in): format 0 in the
-            // production shapes, costs of ordinary magnitude
-            const char *pe = std::getenv("MISSLAP_TILED_P32");
-            const bool p32_shape = h->tiled_shape == 0 || h->tiled_shape == 8 || h->tiled_shape == 9;
-            if (pe && pe[0] == '1' && h->tiled_ok && h->tiled_fmt == 0 && p32_shape && range_ok) {
-                blk.want(&h->tprice32, Mpad + 256);
-                blk.want(&h->und_list, N);
-                h->cmax32 = (float)max_abs_d;
-            }
         }
         h->line_maintenance = cand_mode != 2;
         if (cand_mode != 1) {  // candidate lines (cand_mode 1: off -- A/B timing, parity tests, the precision guard)
@@ -407,7 +382,6 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
         if ((rc = blk.commit(&h->blocks.back()))) return rc;
     }
     HIP_TRY(hipMemsetAsync(h->price, 0, sizeof(double) * Mpad, h->stream));
-    if (h->tprice32) HIP_TRY(hipMemsetAsync(h->tprice32, 0, sizeof(float) * (Mpad + 256), h->stream));  // = the prices: all zero
     HIP_TRY(hipMemsetAsync(h->bid_rec, 0, sizeof(int4) * kRoundSmallMax, h->stream));
     HIP_TRY(hipMemsetAsync(h->wg_stats, 0, sizeof(unsigned long long) * kStatWords * (size_t)h->wg_stats_slots, h->stream));
     if (h->split_cnt) HIP_TRY(hipMemsetAsync(h->split_cnt, 0, sizeof(int) * ((size_t)N / 256 + 1024), h->stream));
@@ -560,8 +534,6 @@ int new_handle(misslap_solver **out, const misslap_options *opt, int abi, missla
     }
     h->maximize = opt->maximize ? 1 : 0;
     h->thr = opt->tail_threshold >= 0 ? opt->tail_threshold : -1;  // -1: resolved in build_from_device_coo
-    h->order_partial = opt->partial_in_list_order == 0;
-    if (const char *e = std::getenv("MISSLAP_APPLY_BIDDERS_RATIO")) h->apply_bidders_ratio = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("MISSLAP_TAIL_LAUNCH_ROUNDS")) h->tail_launch_rounds = std::max(1, std::atoi(e));  // (read per create)
     if (opt->cand_build_max_K > 0) h->cand_build_max_K = opt->cand_build_max_K;
     if (opt->cand_refresh_min > 0) h->cand_refresh_min = opt->cand_refresh_min - 1;

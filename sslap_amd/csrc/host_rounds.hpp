@@ -45,16 +45,13 @@ RoundArgs round_args(misslap_solver *h) {
     a.cand = h->lines_live() ? h->cand : nullptr;
     a.cand64 = h->lines_live() ? h->cand64 : nullptr;
     a.cand_build_max_K = h->cand_build_max_K;
-    static const int build_min_env = [] {
-        const char *e = std::getenv("MISSLAP_BUILD_MIN_K");
-        return e ? std::atoi(e) : kRoundSmallMax;  // (same box, 2048 vs 0: C3 400.1 vs 401.4 ms, C2 132.0 vs 132.5, C1 9.69 vs 9.85)
-    }();
-    a.cand_build_min_K = (h->thr > 0 && h->line_maintenance) ? build_min_env : 0;  // (no maintenance pass: nobody else rebuilds)
+    // (small rounds leave the rebuild of a spent line to the maintenance pass: same box, 2048 vs 0: C3 400.1 vs 401.4 ms,
+    // C2 132.0 vs 132.5, C1 9.69 vs 9.85; without that pass nobody else rebuilds)
+    a.cand_build_min_K = (h->thr > 0 && h->line_maintenance) ? kRoundSmallMax : 0;
     a.cand_refresh_min = h->cand_refresh_min;
     a.price32 = nullptr;  // (set by launch_bid for the launches that scan through the filter)
     a.pmax_bits = h->pmax_bits;
     a.cmax = h->cmax32;
-    a.tprice32 = h->tprice32;
     return a;
 }
 
@@ -209,13 +206,9 @@ int status_wait(misslap_solver *h, int slot) {
 
 // Does this engine launch walk the column tiles backwards?  The first scan of an eps-phase (K = N: tail kernels lie in
 // front of it, the cache holds nothing of the copy) walks forwards, every further launch of the phase in the direction
-// opposite to the one before it.  Column-keyed formats 0 / 1 in the production shapes; MISSLAP_TILED_ALTERNATE=0: never.
+// opposite to the one before it.  Column-keyed formats 0 / 1 in the production shapes.
 bool walk_backwards(misslap_solver *h, const int *shp) {
-    static const bool alternate = [] {
-        const char *e = std::getenv("MISSLAP_TILED_ALTERNATE");
-        return !(e && e[0] == '0');
-    }();
-    const bool can = alternate && MISSLAP_TILED_KEYCOL_ON && h->tiled_fmt <= 1 && shp[7] == 1 &&
+    const bool can = MISSLAP_TILED_KEYCOL_ON && h->tiled_fmt <= 1 && shp[7] == 1 &&
                      (h->tiled_shape == 0 || h->tiled_shape == 8 || h->tiled_shape == 9);
     if (h->phase_fresh) h->walk_rev_next = false;
     const bool rev = can && h->walk_rev_next;
@@ -246,7 +239,7 @@ int launch_bid_tiled(misslap_solver *h) {
     // the chunk counters, the objective's match counters.
     // (K < N in every round of a phase but the first: every winner of the first round takes an unowned object.  The
     // ordering kernels and the scan take K from the device, so the host need not know it exactly.)
-    h->round_ordered = h->order_partial && !h->phase_fresh;
+    h->round_ordered = !h->phase_fresh;
     if (h->round_ordered) {
         int *pos_of = h->nmatch, *order_person = h->hole_list, *order_pos = h->mover_list, *sums = h->cnt;
         const int nchunks = (h->n_rows + kScanChunk - 1) / kScanChunk;
@@ -270,29 +263,7 @@ int launch_bid_tiled(misslap_solver *h) {
     }
     const size_t lds = tiled_lds_bytes(shp[4]);
     const dim3 g((unsigned)grid);
-    if (h->tprice32 && h->tiled_fmt == 0) {
-        // fp32-tile filter scan (kernels_tiled.hpp, kP32): the mirror is current (rebuilt here if a kernel that does not
-        // keep it has written prices since), the scan decides what the rounding margin lets it decide, the exact scan of
-        // the persons it hands over follows in the same stream -- and inside the same pair of events
-        if (!h->tmirror_valid) {
-            MISSLAP_LAUNCH_PLAIN(h, k_tile_mirror, dim3(std::min(blocks_for(h->n_cols, 1024), 4 * h->n_cus)), dim3(1024), 0,
-                                 (const double *)h->price, h->tprice32, h->n_cols);
-            h->tmirror_valid = true;
-        }
-        HIP_TRY(stream_memset(h, &h->ctl->n_und, 0, sizeof(int)));
-        ta.price32 = h->tprice32;
-        ta.und = h->und_list;
-        ta.cmax = h->cmax32;
-        if (pr) (void)hipEventRecord(pr->start, h->stream);
-        switch (shp[6]) {
-            case 4: MISSLAP_LAUNCH_PLAIN(h, (MISSLAP_BID_KERNEL_P32(4)), g, dim3(1024), lds, a, ta); break;
-            case 8: MISSLAP_LAUNCH_PLAIN(h, (MISSLAP_BID_KERNEL_P32(8)), g, dim3(1024), lds, a, ta); break;
-            default: MISSLAP_LAUNCH_PLAIN(h, (MISSLAP_BID_KERNEL_P32(16)), g, dim3(1024), lds, a, ta); break;
-        }
-        MISSLAP_LAUNCH_PLAIN(h, (k_bid_undecided<EdgesF32>), dim3(std::min(64, h->n_cus)), dim3(kBidBlock), 0, a, EdgesF32{h->edges32},
-                             (const int2 *)h->und_list);
-        if (pr) (void)hipEventRecord(pr->stop, h->stream);
-    } else if (walk_backwards(h, shp)) {
+    if (walk_backwards(h, shp)) {
         // the launches of an eps-phase alternate their direction over the column tiles (kernels_tiled.hpp, kRev): this one
         // reads first what the one before it touched last
         const int key = h->tiled_fmt * 100 + shp[6];
@@ -347,7 +318,6 @@ int launch_bid(misslap_solver *h) {
     h->ctl_fresh = false;
     // (not behind a full-scan engine launch: the engines always feed best_key, which k_round_small ignores)
     h->round_small = use_round_small(h) && !(h->tiled_ok && h->K_ub >= h->tiled_min_K);
-    if (h->round_small) h->tmirror_valid = false;  // (k_round_small / k_round_fused write prices without the engine's fp32 mirror)
     if (h->tiled_ok && h->K_ub >= h->tiled_min_K) {
         int rc = launch_bid_tiled(h);  // no-op on the device when K < tiled_min_K
         if (rc) return rc;
@@ -478,17 +448,12 @@ int launch_apply(misslap_solver *h) {
 int launch_tail(misslap_solver *h) {
     if (h->thr <= 0) return MISSLAP_OK;
     h->ctl_fresh = false;
-    h->tmirror_valid = false;  // (the tail kernels write prices without the engine's fp32 mirror)
     // Rows of a few hundred edges keep no lines until the solve has shown that its tail is long: that many tail rounds
     // (a tail round without a line is a row scan by one wavefront, 1.5-4 us at 300-1000 edges; the pass that builds the
     // lines of every row costs milliseconds at C4's 100 000 rows and pays for itself within a phase at a dense
     // 1000 x 1000).  The tail kernels of such a handle return after as many rounds, so that a first phase with thousands
     // of tail rounds does not run to its end without lines (dense 1000^2: 13 of 16 ms were its first two tail launches).
-    static const long long after_env = [] {
-        const char *e = std::getenv("MISSLAP_LONG_AFTER_TAIL_ROUNDS");
-        return e ? std::atoll(e) : -1ll;
-    }();
-    const long long long_after = after_env >= 0 ? after_env : std::max<long long>(kLongRowsAfterTailRoundsMin, h->n_rows / 64);
+    const long long long_after = std::max<long long>(kLongRowsAfterTailRoundsMin, h->n_rows / 64);
     if (h->long_rows_later && h->tail_rounds_host >= long_after) {  // (status read just before)
         h->long_rows = true;
         h->long_rows_later = false;
@@ -504,11 +469,7 @@ int launch_tail(misslap_solver *h) {
     const bool lines = h->lines_live();
     a.cand = lines ? h->cand : nullptr;
     a.cand64 = lines ? h->cand64 : nullptr;
-    static const int budget_env = [] {
-        const char *e = std::getenv("MISSLAP_LONG_TAIL_BUDGET");
-        return e ? std::atoi(e) : 0;
-    }();
-    a.round_budget = h->long_rows && lines && h->line_maintenance ? (budget_env > 0 ? budget_env : h->tail_round_budget)
+    a.round_budget = h->long_rows && lines && h->line_maintenance ? h->tail_round_budget
                      : h->long_rows_later                            ? (int)std::min<long long>(std::max<long long>(long_after, 1), 1 << 30)
                                                                      : 0;
     if (a.round_budget == 0 || a.round_budget > h->tail_launch_rounds) a.round_budget = h->tail_launch_rounds;
@@ -524,10 +485,7 @@ int launch_tail(misslap_solver *h) {
     const EdgesF64 e64{h->col, h->val64};
     // rows the long-row builder takes (it runs right behind the pass over all lines, on the list that pass leaves)
     const int long_max = !(lines && h->line_maintenance && h->long_rows) ? 0 : (h->max_row_len <= 256 * kLongPer ? 256 : 512) * kLongPer;
-    static const int min_alive_long = [] {
-        const char *e = std::getenv("MISSLAP_LONG_MIN_ALIVE");
-        return e ? std::atoi(e) : kLongRowMinAlive;
-    }();
+    const int min_alive_long = kLongRowMinAlive;
     // every line checked at today's prices (kernels_round.hpp); then the rounds with more than kTeamMax bidders, with
     // sixteen wavefronts (kernels_tail.hpp); then -- lines only -- the rounds with 3..kTeamMax bidders, one list slot
     // per wavefront; then the rest: with lines the two-wavefront duo / chain instance, without them the 512-thread

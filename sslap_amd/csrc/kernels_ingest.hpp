@@ -142,8 +142,6 @@ __global__ __launch_bounds__(256) void k_init_state(Ctl *ctl, double *price, Pri
         ctl->obj_minexp = 1 << 20;
         ctl->n_need = 0;
         ctl->arrive = 0;
-        ctl->n_und = 0;
-        ctl->und_total = 0;
         ctl->obj = 0.0;
         for (int k = 0; k < 16; ++k) ctl->dbg[k] = 0;
     }

@@ -61,8 +61,6 @@ struct RoundArgs {
     const float *price32;
     const int *pmax_bits;
     float cmax;
-    float *tprice32;  // the fp32 mirror the engine's fp32-tile filter scans fill their tiles from (nullptr: none): kept
-                      // by every kernel that writes a price in a GRID round (k_apply*), rebuilt by k_reset_phase
 };
 constexpr int kStatEdges = 0, kStatBids = 1, kStatHits = 2, kStatHitEdges = 3, kStatShardEdges = 4, kStatLaunchEdges = 5,
               kStatLaunchHitEdges = 6,  // of kStatLaunchEdges: rows a candidate line answered (counted, never read)
@@ -262,39 +260,6 @@ struct F_k_bid {  // (the body as a callable: what a batched launch runs per pro
     static __device__ __forceinline__ void run(RoundArgs a, E ed) { k_bid_body<E, Src, kLines>(a, ed); }
 };
 
-
-// Behind an fp32-tile filter scan of the full-scan engine (k_bid_tiled, kP32): the persons it could not decide -- ties
-// or near-ties among a row's best three values, fewer than two finite values -- get their bid from the exact scan, one
-// wavefront per person.  (Counted by the engine launch already; nothing is tallied here.)
-template <class E>
-__device__ __forceinline__ void k_bid_undecided_body(RoundArgs a, E ed, const int2 *und) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int n = a.ctl->n_und;
-    const double eps = (double)a.eps;
-    int err = 0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) a.ctl->und_total += (unsigned long long)n;  // (one writer per launch, stream order)
-    for (int idx = blockIdx.x * (kBidBlock / kWave) + wave; idx < n; idx += gridDim.x * (kBidBlock / kWave)) {
-        const int2 pp = und[idx];
-        const int s = a.row_ptr[pp.x], e = a.row_ptr[pp.x + 1];
-        CandBid b;
-        wave_bid_lean(ed, PriceSource{a.price}, s, e, eps, b, err);
-        if (lane == 0) {
-            a.bid_key[pp.y] = b.key;
-            a.bid_obj[pp.y] = b.obj;
-            atomicMax(&a.best_key[b.obj], b.key);
-        }
-    }
-    if (lane == 0 && err) atomicOr(&a.ctl->err, err);
-}
-template <class E>
-__global__ __launch_bounds__(kBidBlock) void k_bid_undecided(RoundArgs a, E ed, const int2 *und) { k_bid_undecided_body<E>(a, ed, und); }
-
-// the fp32 mirror the fp32-tile filter scans fill their price tiles from: rebuilt whenever a kernel that does not keep
-// it (the tail kernels, the small rounds) has written prices since (host flag), kept by k_reset_phase and the apply
-// kernels otherwise
-__global__ __launch_bounds__(1024) void k_tile_mirror(const double *price, float *price32, int n_cols) {
-    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n_cols; j += gridDim.x * blockDim.x) price32[j] = (float)price[j];
-}
 
 // The fp32 mirror of the prices for wave_bid_filter, and the largest price (bit pattern: prices are >= 0, so the patterns
 // order like integers; *pmax_bits is zeroed by the host in front of the launch).  Only in a live round that k_bid serves.
@@ -636,7 +601,6 @@ __device__ __forceinline__ int apply_winner_of(const RoundArgs &a, Ctl *ctl, int
     if (a.cand != nullptr && r.price < a.price[j]) atomicOr(&ctl->err, kErrPriceFell);
     a.rec[j] = r;
     a.price[j] = r.price;
-    if (a.tprice32) a.tprice32[j] = (float)r.price;  // (the fp32-tile mirror of the full-scan engine, when the handle keeps one)
     const int prev = a.o2p[j];               // :401
     a.p2o[i] = j;                            // :417
     a.o2p[j] = i;                            // :418
@@ -1199,7 +1163,7 @@ struct F_k_post_ece {  // (the body as a callable: what a batched launch runs pe
 
 // eps-phase restart (auction_.pyx:286-290): forget assignments, keep prices.
 __device__ __forceinline__ void k_reset_phase_body(Ctl *ctl, int *p2o, int *o2p, PriceRec *rec, int *U,
-                                                     int n_rows, int n_cols, const double *price, float *tprice32) {
+                                                     int n_rows, int n_cols) {
     const int stride = gridDim.x * blockDim.x;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     for (int i = t; i < n_rows; i += stride) {
@@ -1209,7 +1173,6 @@ __device__ __forceinline__ void k_reset_phase_body(Ctl *ctl, int *p2o, int *o2p,
     for (int j = t; j < n_cols; j += stride) {
         o2p[j] = -1;
         rec[j].owner = -1;  // the price stays
-        if (tprice32) tprice32[j] = (float)price[j];  // ... and its fp32 mirror (fp32-tile filter scans) is rebuilt for the phase
     }
     if (t == 0) {
         ctl->K = n_rows;
@@ -1220,9 +1183,9 @@ __device__ __forceinline__ void k_reset_phase_body(Ctl *ctl, int *p2o, int *o2p,
     }
 }
 __global__ __launch_bounds__(256) void k_reset_phase(Ctl *ctl, int *p2o, int *o2p, PriceRec *rec, int *U,
-                                                     int n_rows, int n_cols, const double *price, float *tprice32) { k_reset_phase_body(ctl, p2o, o2p, rec, U, n_rows, n_cols, price, tprice32); }
+                                                     int n_rows, int n_cols) { k_reset_phase_body(ctl, p2o, o2p, rec, U, n_rows, n_cols); }
 struct F_k_reset_phase {  // (the body as a callable: what a batched launch runs per problem, csrc/host_batch.hpp)
-    static __device__ __forceinline__ void run(Ctl *ctl, int *p2o, int *o2p, PriceRec *rec, int *U, int n_rows, int n_cols, const double *price, float *tprice32) { k_reset_phase_body(ctl, p2o, o2p, rec, U, n_rows, n_cols, price, tprice32); }
+    static __device__ __forceinline__ void run(Ctl *ctl, int *p2o, int *o2p, PriceRec *rec, int *U, int n_rows, int n_cols) { k_reset_phase_body(ctl, p2o, o2p, rec, U, n_rows, n_cols); }
 };
 
 

@@ -527,10 +527,6 @@ struct TiledArgs {
     int part_stride;
     int *split_cnt;           // [slices] workgroups of the slice that have published their partial result (0 between launches)
     FinalOut fo;              // MODE 1 (the eCE / objective / validity pass, kernels_check.hpp): where its results go
-    // kP32 instances (the fp32-tile filter scan):
-    const float *price32 = nullptr;  // fp32 mirror of the prices, padded to T * kTileCols + 256 entries
-    int2 *und = nullptr;             // {person, list position} of the persons the filter could not decide (Ctl::n_und of them)
-    float cmax = 0.f;                // max |cost|
 };
 
 // hand-over of a column-split shape's partial results between workgroups (see the epilogue of k_bid_tiled)
@@ -576,17 +572,7 @@ __device__ __forceinline__ T split_load(const T *p) {
 #define MISSLAP_TILED_KEYCOL 1  // (0: positions in every format -- A/B builds)
 #endif
 #define MISSLAP_TILED_KEYCOL_ON (MISSLAP_TILED_KEYCOL != 0)
-// kP32 = 1 (round 5, opt-in: MISSLAP_TILED_P32): the price tiles are SINGLE precision -- filled from the fp32 mirror
-// of the prices (TiledArgs::price32: half the L2 -> LDS fill bytes, which are more than the edge bytes of a scan) -- and
-// the scan is a FILTER: a lane keeps the three largest a = fl32(cost - p32) it meets and the column / cost of the first
-// two; after the last tile the group's three largest M1 >= M2 >= M3 are formed, and if M2 - M3 exceeds the rounding
-// margin 2^-22 (|M2| + |M3|) + 2^-20 max|cost| the two edges holding M1, M2 ARE the row's two best, strictly: the bid is
-// formed from their exact values (two fp64 price gathers; equal values: the larger column = the later stored index,
-// :351).  |a - v| <= 2^-24 (2 |a| + |cost|) (1 + 2^-20) for v = fl64(cost - p): p32 = fl32(p) is within 2^-24 |p|, the
-// fp32 subtraction within 2^-24 |a|, and |p| <= |a| + |cost| + ...; the margin is twice that on both sides.  Otherwise
-// (ties / near-ties, fewer than two finite values) the person goes to TiledArgs::und and a wave-per-row exact scan
-// (k_bid_undecided) forms its bid.  Only for format 0, the unsplit shapes, bid scans.
-template <int kTileThreads, int kTileRows, int kTileBatch, int kTileDepth, int kTileCols, int kLoaders, int ABL = 0, int kGL = 4, int kCS = 1, int MODE = 0, int kFmt = 0, int kP32 = 0, int kRev = 0>
+template <int kTileThreads, int kTileRows, int kTileBatch, int kTileDepth, int kTileCols, int kLoaders, int ABL = 0, int kGL = 4, int kCS = 1, int MODE = 0, int kFmt = 0, int kRev = 0>
 __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledArgs ta) {
     typedef TileFmt<kFmt> F;
     typedef typename F::VT VT;
@@ -597,10 +583,8 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
     // the host alternates the direction from one engine launch of a phase to the next.  A lane of a format-0 / 1 scan
     // then meets its tiles in DESCENDING column order while ">=" orders equal values in ascending order: a step whose
     // best merely TIES the best of the tiles walked before it (larger columns: later stored) is undone (`tie_only`).
-    static_assert(kRev == 0 || (MODE == 0 && kCS == 1 && ABL == 0 && kP32 == 0 && !F::kG && kTileCols != kTileColsBig && kLoaders > 0 && MISSLAP_TILED_KEYCOL_ON),
+    static_assert(kRev == 0 || (MODE == 0 && kCS == 1 && ABL == 0 && !F::kG && kTileCols != kTileColsBig && kLoaders > 0 && MISSLAP_TILED_KEYCOL_ON),
                   "the backward walk: column-keyed bid scans (formats 0 / 1) of the unsplit double-buffered shapes");
-    static_assert(kP32 == 0 || (MODE == 0 && kCS == 1 && kFmt == 0 && ABL == 0 && kTileCols != kTileColsBig && kLoaders > 0),
-                  "the fp32-tile filter: format 0 bid scans of the unsplit double-buffered shapes");
     static_assert(kFmt == 0 || (kCS == 1 && ABL == 0), "column split and ablations exist for the 6 B/edge format only");
     static_assert(kCS == 1 || kCS == 2 || kCS == 4, "column split: none, halves or quarters of the tiles");
     static_assert(MODE == 0 || (MODE == 1 && kCS == 1 && ABL == 0), "the check pass runs on the unsplit shapes");
@@ -666,16 +650,6 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
     // value bits; and per person the tile of the wanted column, its price slot there as an LDS byte offset, the number
     // of matches
     int wtile[kTileRows], wslot8[kTileRows], mcnt[kTileRows];
-    // kP32: the lane's three largest fp32 values, and column / cost bits of the first two
-    float ft1[kTileRows], ft2[kTileRows], ft3[kTileRows];
-    int fk1[kTileRows], fk2[kTileRows];
-    int fc1[kTileRows], fc2[kTileRows];
-#pragma unroll
-    for (int j = 0; j < kTileRows; ++j) {
-        ft1[j] = ft2[j] = ft3[j] = -__builtin_huge_valf();
-        fk1[j] = fk2[j] = -1;
-        fc1[j] = fc2[j] = 0;
-    }
 #pragma unroll
     for (int j = 0; j < kTileRows; ++j) {
         const int pos = p0 + j * kTileGroups + group;
@@ -701,36 +675,19 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
             wslot8[j] = ((cc - tj * kTileCols) + (kDouble ? (tj & 1) * kBufDoubles : 0)) << 3;  // as k_tile_scatter forms it
         }
     }
-    // (kP32: the buffers hold FLOATS at the same slot numbers -- buffer b at float offset b * kBufDoubles; a fill's last
-    // 1 KB piece runs 128 floats past the tile, into the gap in front of the next buffer; the +inf slot sits behind both)
-    if (t == 0) {
-        if (kP32) reinterpret_cast<float *>(s_price)[2 * kBufDoubles] = __builtin_huge_valf();
-        else s_price[kTileCols] = __builtin_huge_val();
-    }
+    if (t == 0) s_price[kTileCols] = __builtin_huge_val();
     // an edge carries the slot of its price inside s_price (tile parity included, see k_tile_scatter)
-    constexpr int kInfOff = kP32 ? 2 * kBufDoubles * 4 : kTileCols * 8;  // the +inf slot (behind buffer 0; kP32: behind both)
-    constexpr int kSlotShift = kP32 ? 2 : 3;                             // slot -> LDS byte address
+    constexpr int kInfOff = kTileCols * 8;  // the +inf slot (behind buffer 0)
+    constexpr int kSlotShift = 3;           // slot -> LDS byte address
     // ... as an ABSOLUTE LDS address: s_price is the kernel's only LDS object and therefore starts at LDS address 0
     // (checked below); going through the s_price symbol would cost a v_add of its link-time address per look-up
     typedef const __attribute__((address_space(3))) double *lds_cdp;
     if (t == 0 && (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) void *)s_price != 0u)
         atomicOr(&a.ctl->err, kErrLdsBase);
     auto lds_price = [&](int off) { return *(lds_cdp)(__UINTPTR_TYPE__)(unsigned)off; };
-    typedef const __attribute__((address_space(3))) float *lds_cfp;
-    auto lds_price32 = [&](int off) { return *(lds_cfp)(__UINTPTR_TYPE__)(unsigned)off; };
 
     // pieces first, first + stride, ... of `tile` -> buffer tile & 1; one piece = 64 lanes x 16 B = 128 prices
     auto dma_fill = [&](int tile, int first, int stride) {
-        if constexpr (kP32 != 0) {  // one piece = 64 lanes x 16 B = 256 floats
-            constexpr int kPieces32 = (kTileCols + 255) / 256;
-            const float *gsrc32 = ta.price32 + (size_t)tile * kTileCols + 4 * lane;
-            float *dst32 = reinterpret_cast<float *>(s_price) + (tile & 1) * kBufDoubles;
-#pragma unroll 4
-            for (int piece = first; piece < kPieces32; piece += stride)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc32 + piece * 256),
-                                                 (__attribute__((address_space(3))) void *)(dst32 + piece * 256), 16, 0, 0);
-            return;
-        }
         constexpr int kPieces = kTileCols / 128;
         const double *gsrc = a.price + (size_t)tile * kTileCols + 2 * lane;
         double *dst = s_price + (kDouble ? (tile & 1) : 0) * kBufDoubles;
@@ -757,7 +714,7 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
         // the lines of tile t + MISSLAP_TILED_TOUCH (one 4-byte load per 128-byte line, 1 / 32 of the tile per
         // workgroup of the XCD under round-robin dispatch) behind the fill of tile t + 1; the fill waits with
         // vmcnt(1) -- loads return in order, the touch is the youngest and may stay in flight.
-        constexpr int kTileLines = kTileCols * (kP32 ? 4 : 8) / 128;
+        constexpr int kTileLines = kTileCols * 8 / 128;
         const int nx = max(1, (int)gridDim.x / 8), xr = ((int)blockIdx.x / 8) % nx;
         const int lines_per_wg = (kTileLines + nx - 1) / nx, lines_per_wave = (lines_per_wg + kLoaders - 1) / (kLoaders > 0 ? kLoaders : 1);
         // (always ONE load per call, all lanes active, addresses clamped into the table: the vmcnt(1) below relies on
@@ -768,8 +725,7 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
         char *touch_dst = reinterpret_cast<char *>(s_price + (kDouble ? kBufDoubles + kTileCols : kTileCols + 2)) + kTileStatBytes;
         auto touch = [&](int tile) {
             const int line = min(xr * lines_per_wg + me * lines_per_wave + min(lane, lines_per_wave - 1), kTileLines - 1);
-            const char *src = (kP32 ? reinterpret_cast<const char *>(ta.price32 + (size_t)min(tile, T - 1) * kTileCols)
-                                    : reinterpret_cast<const char *>(a.price + (size_t)min(tile, T - 1) * kTileCols)) + (size_t)line * 128;
+            const char *src = reinterpret_cast<const char *>(a.price + (size_t)min(tile, T - 1) * kTileCols) + (size_t)line * 128;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)touch_dst, 1, 0, 0);
         };
@@ -944,18 +900,12 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
                 const int col0 = tile * kTileCols - (kDouble ? (tile & 1) * kBufDoubles : 0);  // column of slot 0 of this tile's buffer
                 auto consume = [&](const int dlo, const int dhi) {
                     double prs[kTileBatch][kTileDepth][2];
-                    float prf[kTileBatch][kTileDepth][2];  // (kP32)
 #pragma unroll
                     for (int jj = 0; jj < kTileBatch; ++jj) {
 #pragma unroll
                         for (int d = dlo; d < dhi; ++d) {
                             const unsigned c = e_cur.c[jj][d];
                             const int a0 = (int)((c & 0xffffu) << kSlotShift), a1 = (int)((c >> 16) << kSlotShift);  // slot -> LDS byte address
-                            if constexpr (kP32 != 0) {
-                                prf[jj][d][0] = lds_price32((2 * kGL * d < rem[jj]) ? a0 : kInfOff);  // masked-off: +inf
-                                prf[jj][d][1] = lds_price32((2 * kGL * d + 1 < rem[jj]) ? a1 : kInfOff);
-                                continue;
-                            }
                             if (ABL == 6) {  // no LDS look-ups: the "price" is made from the slot bits
                                 prs[jj][d][0] = (double)a0;
                                 prs[jj][d][1] = (double)a1;
@@ -987,23 +937,6 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
 #pragma unroll
                             for (int h = 0; h < 2; ++h) {
                                 const VT vb = h ? e_cur.v1[jj][d] : e_cur.v0[jj][d];
-                                if constexpr (kP32 != 0) {
-                                    // the lane's running top-3 of a = fl32(cost - p32): a masked-off element reads the
-                                    // +inf slot, a = -inf, no comparison holds (an element whose price IS infinite is
-                                    // never a candidate either: a person without two finite values goes to the exact scan)
-                                    const int vbi = (int)vb;
-                                    const float av = __int_as_float(vbi) - prf[jj][d][h];
-                                    const int colx = col0 + (int)(h ? e_cur.c[jj][d] >> 16 : e_cur.c[jj][d] & 0xffffu);
-                                    const bool b1 = av > ft1[j], b2 = av > ft2[j];
-                                    ft3[j] = __builtin_amdgcn_fmed3f(ft2[j], ft3[j], av);  // (ft2 >= ft3: the median is the new third)
-                                    fk2[j] = b1 ? fk1[j] : (b2 ? colx : fk2[j]);
-                                    fc2[j] = b1 ? fc1[j] : (b2 ? vbi : fc2[j]);
-                                    ft2[j] = __builtin_amdgcn_fmed3f(ft1[j], ft2[j], av);
-                                    fk1[j] = b1 ? colx : fk1[j];
-                                    fc1[j] = b1 ? vbi : fc1[j];
-                                    ft1[j] = __builtin_fmaxf(ft1[j], av);
-                                    continue;
-                                }
                                 // a masked-off element has v = -inf and changes neither sv nor sw; `ok` keeps it from
                                 // taking sg when sv is still -inf (rows whose objects all have an infinite price)
                                 const double v = F::val(vb) - prs[jj][d][h];  // vi = cost - p[j]   (:350)
@@ -1165,29 +1098,13 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
                     q[jj] = kKeyCol ? en[jj].y : en[jj].x;  // the key that orders equal values: position (kKeyCol: column)
                     if constexpr (F::kF64) vb[jj] = __hiloint2double(en[jj].w, en[jj].z);
                     else vb[jj] = en[jj].z;
-                    pr[jj] = kP32 ? (double)ta.price32[en[jj].y] : a.price[en[jj].y];  // (kP32: exactly the float)
+                    pr[jj] = a.price[en[jj].y];
                 }
                 more = false;
 #pragma unroll
                 for (int jj = 0; jj < kOB; ++jj) {
                     const int j = j0 + jj;
                     const bool ok = (oi[jj] < oe[jj]) & (kCS == 1 || ((q[jj] >= ql[jj]) & (q[jj] < qh[jj])));
-                    if constexpr (kP32 != 0) {  // the same top-3 update as in the tile loop
-                        const int vbi = (int)vb[jj];
-                        const float av = ok ? __int_as_float(vbi) - (float)pr[jj] : -__builtin_huge_valf();
-                        const int colx = en[jj].y;
-                        const bool b1 = av > ft1[j], b2 = av > ft2[j];
-                        ft3[j] = __builtin_amdgcn_fmed3f(ft2[j], ft3[j], av);
-                        fk2[j] = b1 ? fk1[j] : (b2 ? colx : fk2[j]);
-                        fc2[j] = b1 ? fc1[j] : (b2 ? vbi : fc2[j]);
-                        ft2[j] = __builtin_amdgcn_fmed3f(ft1[j], ft2[j], av);
-                        fk1[j] = b1 ? colx : fk1[j];
-                        fc1[j] = b1 ? vbi : fc1[j];
-                        ft1[j] = __builtin_fmaxf(ft1[j], av);
-                        oi[jj] += kGL;
-                        more |= oi[jj] < oe[jj];
-                        continue;
-                    }
                     const double v = ok ? F::val(vb[jj]) - pr[jj] : ninf;  // vi = cost - p[j]   (:350)
                     if (MODE == 1) {  // these edges are met out of stored order: the later stored POSITION is the last match
                         const int wcol = wtile[j] * kTileCols + (wslot8[j] >> 3) - (kDouble ? (wtile[j] & 1) * kBufDoubles : 0);
@@ -1255,61 +1172,7 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
     // edges carry absolute LDS offsets)
     unsigned long long *s_e = reinterpret_cast<unsigned long long *>(s_price + (kDouble ? kBufDoubles + kTileCols : kTileCols + 2));
     int *s_n = reinterpret_cast<int *>(s_e + kTileThreads / kWave);
-    bool und[kTileRows];  // (kP32) persons the filter could not decide: lane 0 of the group hands them over
-#pragma unroll
-    for (int j = 0; j < kTileRows; ++j) und[j] = false;
-    if constexpr (kP32 != 0) {
-        // the group's three largest fp32 values M1 >= M2 >= M3: M1 in lane L1, M2 in lane L2 (possibly the same lane)
-        auto gmax = [](float v) {
-#pragma unroll
-            for (int off = 1; off < kGL; off <<= 1) v = __builtin_fmaxf(v, __shfl_xor(v, off));
-            return v;
-        };
-        auto gmin = [](int v) {
-#pragma unroll
-            for (int off = 1; off < kGL; off <<= 1) v = min(v, __shfl_xor(v, off));
-            return v;
-        };
-        const int gbase = lane & ~(kGL - 1);
-        const float fninf = -__builtin_huge_valf();
-        int col1[kTileRows], col2[kTileRows], cst1[kTileRows], cst2[kTileRows];
-        bool decided[kTileRows];
-        double p1[kTileRows], p2[kTileRows];
-#pragma unroll
-        for (int j = 0; j < kTileRows; ++j) {
-            const float M1 = gmax(ft1[j]);
-            const int L1 = gmin(ft1[j] == M1 ? gl : kGL);
-            const float x2 = gl == L1 ? ft2[j] : ft1[j];
-            const float M2 = gmax(x2);
-            const int L2 = gmin(x2 == M2 ? gl : kGL);
-            const float x3 = gl == L1 ? (L2 == L1 ? ft3[j] : ft2[j]) : (gl == L2 ? ft2[j] : ft1[j]);
-            const float M3 = gmax(x3);
-            // (in double: the difference of two floats and the margin are exact / rounded once)
-            const double margin = 0x1p-22 * ((double)__builtin_fabsf(M2) + (double)__builtin_fabsf(M3)) + 0x1p-20 * (double)ta.cmax;
-            decided[j] = (M2 > fninf) && ((M3 == fninf) || ((double)M2 - (double)M3 > margin));
-            const int k1a = __shfl(fk1[j], gbase + L1), c1a = __shfl(fc1[j], gbase + L1);
-            const int k2a = __shfl(fk2[j], gbase + L1), c2a = __shfl(fc2[j], gbase + L1);
-            const int k1b = __shfl(fk1[j], gbase + min(L2, kGL - 1)), c1b = __shfl(fc1[j], gbase + min(L2, kGL - 1));
-            col1[j] = k1a;
-            cst1[j] = c1a;
-            col2[j] = L2 == L1 ? k2a : k1b;
-            cst2[j] = L2 == L1 ? c2a : c1b;
-            // the two exact prices (requested for all persons of the lane group before the first is used)
-            p1[j] = a.price[max(col1[j], 0)];
-            p2[j] = a.price[max(col2[j], 0)];
-        }
-#pragma unroll
-        for (int j = 0; j < kTileRows; ++j) {
-            const double v1 = (double)__int_as_float(cst1[j]) - p1[j], v2 = (double)__int_as_float(cst2[j]) - p2[j];  // vi = cost - p[j]   (:350), exact
-            const bool second = (v2 > v1) | ((v2 == v1) & (col2[j] > col1[j]));  // :351: the later stored index (= the larger column) among equals
-            bcol[j] = second ? col2[j] : col1[j];
-            bcost[j] = second ? cst2[j] : cst1[j];
-            W[j] = second ? v1 : v2;  // :357: the other one IS the second-best value
-            G[j] = 0;
-            mine[j] = person[j] >= 0 && gl == 0 && decided[j];
-            und[j] = person[j] >= 0 && gl == 0 && !decided[j];
-        }
-    } else if (kCS == 1) {
+    if (kCS == 1) {
 #pragma unroll
         for (int j = 0; j < kTileRows; ++j) {
             const double V = group_max_f64<kGL>(sv[j]);
@@ -1386,8 +1249,7 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
 #pragma unroll
     for (int j = 0; j < kTileRows; ++j) {
         const int pj = max(person[j], 0);
-        if constexpr (kP32 != 0) {  // (formed above)
-        } else if constexpr (kCS == 1) {  // `mine` is the lane that met the best edge
+        if constexpr (kCS == 1) {  // `mine` is the lane that met the best edge
             bcol[j] = ABL == 0 ? scol[j] : pj % a.n_cols;  // (ablations carry no column: spread the atomics like real bids)
             bcost[j] = scost[j];
         } else {         // any workgroup of the slice may hold it: through its position (unconditional loads, used under `mine`)
@@ -1409,12 +1271,6 @@ __global__ __launch_bounds__(kTileThreads) void k_bid_tiled(RoundArgs a, TiledAr
             a.bid_key[pos] = key;
             a.bid_obj[pos] = bcol[j];
             atomicMax(&a.best_key[bcol[j]], key);
-            edges += (unsigned long long)rlen[j];
-            nb += 1;
-        } else if (kP32 != 0 && und[j]) {  // its bid comes from k_bid_undecided (the exact scan); counted here
-            const int slot = p0 + j * kTileGroups + group;
-            const int pos = ta.order_pos ? ta.order_pos[slot] : slot;
-            ta.und[atomicAdd(&a.ctl->n_und, 1)] = make_int2(person[j], pos);
             edges += (unsigned long long)rlen[j];
             nb += 1;
         }

@@ -274,9 +274,8 @@ MISSLAP_API int misslap_phase_end(misslap_solver *h, int32_t *finished) {
         } else {
             h->eps = h->eps * h->theta;  // :283 (fp32 product)
             MISSLAP_LAUNCH(h, k_reset_phase, (F_k_reset_phase), 256, dim3(blocks_for(h->n_rows > h->n_cols ? h->n_rows : h->n_cols, 256)),
-                           dim3(256), h->ctl, h->p2o, h->o2p, h->rec, h->U, h->n_rows, h->n_cols, (const double *)h->price, h->tprice32);
+                           dim3(256), h->ctl, h->p2o, h->o2p, h->rec, h->U, h->n_rows, h->n_cols);
             HIP_TRY(hipGetLastError());
-            h->tmirror_valid = true;  // (k_reset_phase has rebuilt the fp32 mirror of the prices, if the handle keeps one)
             h->live_valid = false;  // (K was changed by a launch without a ticket; the mirror below is current)
             h->nreductions += 1;  // :292
             h->K_ub = h->n_rows;
@@ -386,7 +385,7 @@ MISSLAP_API int misslap_finish(misslap_solver *h, int32_t *person_to_object_out,
     meta->tiled_format = h->tiled_ok ? h->tiled_fmt : 0;
     meta->phases_with_lines = h->phases_with_lines;
     meta->eps_phases = h->phases_run;
-    meta->filter_undecided = h->tprice32 ? (int32_t)std::min<unsigned long long>(c.und_total, 0x7fffffffull) : -1;
+    meta->filter_undecided = -1;  // (reserved: the slot of round 5's fp32-tile filter scans, removed in round 6)
     if (h->profile && h->prof_used) {
         std::vector<unsigned long long> le(2 * (size_t)h->launch_idx);
         if (h->launch_idx)
@@ -444,9 +443,6 @@ misslap_round_ops handle_round_ops(misslap_solver *h) {
     o.rounds_per_sync = h->rounds_per_sync_auto && !h->live_off ? kRoundsPerSyncLive : h->rounds_per_sync;
     o.large_round_K = kRoundSmallMax;
     o.rounds_per_sync_large = kRoundsPerSyncLargeK;
-    // (MISSLAP_BIG_ROUNDS_BATCHED=1, host_comm.hpp: the rounds of the full-scan regime through the batched path, one per
-    // batch, so that the host's upper bound of K is at most two rounds old when the regime ends)
-    if (h->world == 1 && !big_rounds_exact_env()) o.rounds_per_sync_large = 1;
     o.max_iter = h->max_iter;
     o.ctx = h;
     o.status = [](void *x, int64_t *K, int64_t *its) {

@@ -78,6 +78,9 @@ def test_latest_bench_line_has_the_contract_fields_and_this_rounds_additions():
     assert abs(d["value"] - d["edges_scanned_per_solve"] * d["steps"] / (d["ms_per_step"] * d["steps"] * 1e-3) / 1e6) < 0.01 * d["value"]
     g = json.load(open(os.path.join(ROOT, "tests", "golden", "large_cases.json")))["cases"]["C3"]
     assert d["sol_sha256"] == g["sol_sha256"] and d["rounds"] == g["meta"]["its"] and d["obj_f64"] == g["obj_f64"]
+    if name >= "r06":  # round 6: BASELINE.md section 3's second CPU figure, the N-rank figures inside the roofline block
+        assert c["optimised_same_assignment"] is True and 0 < c["optimised_whole_solve_s"] <= c["whole_solve_s"]
+        assert r["all_ranks"]["n_ranks"] == 1 and r["all_ranks"]["mode"] == "single"
     if name >= "r03":  # SURVEY 8(d) additions of round 3: the second solve figure and the second peak
         # (round 4: the library's own read-only streaming pass is the measured peak the read-only scan is held against)
         peak = r["peak_measured_read"] if name >= "r04" else r["peak_measured_copy"]
@@ -85,6 +88,42 @@ def test_latest_bench_line_has_the_contract_fields_and_this_rounds_additions():
         h = d["solve_incl_h2d"]
         assert h["solve_ms_incl_h2d"] > d["solve_ms"] and h["h2d_bytes"] == 16 * d["config"]["nnz"]
         assert d["complete_assignment"] == [True, True, True] and d["valid_assignment"] is True
+
+
+def _template_args(kernel):
+    return [t.strip() for t in kernel[kernel.index("<") + 1:kernel.rindex(">")].split(",")]
+
+
+def test_every_committed_roofline_block_of_this_round_follows_from_its_pmc_file():
+    """profiles/r06_bench_*.json: `traffic` (HBM bytes per launch from the PMC passes) must belong to the kernel
+    instance(s) whose time is in `avg_launch_us` -- the engine's MODE 0 instances, or the gather kernel's K = N instances
+    k_bid<E, PriceSource, 0 | 1> -- equal the launch-weighted mean of those instances in the committed PMC file, and never
+    lie below the bytes the launches claim to have read."""
+    import glob
+    names = sorted(glob.glob(os.path.join(ROOT, "profiles", "r06_bench_*.json")))
+    if not names:
+        pytest.skip("no bench lines of this round committed yet")
+    for path in names:
+        d = _line(os.path.basename(path))
+        r = d["roofline"]
+        assert "all_ranks" in r and r["all_ranks"]["n_ranks"] == d["n_gpus"], path
+        if r["traffic"] is None:
+            assert r.get("traffic_note") or r.get("traffic_stale") or "traffic_file" not in r, path
+            continue
+        kernels = r["traffic_kernel"].split(" + ")
+        for k in kernels:
+            ta = _template_args(k)
+            if r["kernel"] == "k_bid_tiled":
+                assert "k_bid_tiled<" in k and ta[9] == "0", (path, k)  # MODE 0: the bid scans
+            else:
+                assert "k_bid<" in k and ta[1].endswith("PriceSource") and ta[2] in ("0", "1"), (path, k)
+        tj = json.load(open(os.path.join(ROOT, r["traffic_file"])))
+        sel = [tj["kernels"][k] for k in kernels]
+        n_l = sum(v["launches"] for v in sel)
+        want = sum((v["read_avg"] + v["write_avg"]) * v["launches"] for v in sel) / n_l
+        assert abs(r["traffic"] - want) <= 1.0 + 1e-9 * want, path
+        assert r["traffic"] >= 0.9 * r["algorithmic_bytes_per_launch"], (path, "traffic below the bytes the launches read")
+        assert abs(r["traffic_over_algorithmic"] - r["traffic"] / r["algorithmic_bytes_per_launch"]) < 2e-3, path
 
 
 def test_bench_gpus_n_without_a_launcher_spawns_the_ranks_before_touching_the_gpu():
@@ -161,6 +200,13 @@ def test_bench_line_of_the_many_rank_run_is_well_formed_on_one_gpu(backend, n, c
     assert d["sharded_rounds_per_solve"] > 0 and d["exchanges_per_solve"] == 2 * d["sharded_rounds_per_solve"]
     assert d["distinct_gpus"] == 1 and ("THREAD" in d["rank_transport"]) == (backend == "threads")
     assert d["value"] > 0 and d["roofline"]["frac"] <= 1.0 and d["cpu_baseline"] is None
+    # the scaling-relevant figures sit inside the `roofline` block (what a SCALE_rNN record keeps of the line)
+    ar = d["roofline"]["all_ranks"]
+    assert ar["n_ranks"] == n and ar["mode"] == "sharded" and ar["comm_kind"] == "custom" and ar["rccl_nranks"] is None
+    assert ar["comm_ranks_seen_by_every_rank"] == [n] * n and ar["distinct_gpus"] == 1
+    assert ar["sharded_rounds_per_solve"] == d["sharded_rounds_per_solve"] and ar["exchanges_per_solve"] == 2 * ar["sharded_rounds_per_solve"]
+    assert ar["fullscan_medges_s"] == d["bid_phase"]["fullscan_all_ranks_medges_s"] and ar["fullscan_medges_s"] > 0
+    assert 0 < ar["fullscan_frac_of_hbm_peak"] <= 1.0
     # unique work: the ranks' shares of the sharded rounds + the replicated rounds once = the single-GPU edge count
     assert round(d["value"] * d["ms_per_step"] * 1e3) == pytest.approx(g["edges_scanned"], rel=1e-3)
 

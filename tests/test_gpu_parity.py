@@ -403,8 +403,8 @@ def test_fuzz_random_instances_vs_oracle(seed, gpu_lib):
     dict(cand_refresh=30),                                  # every line hit of a grid round is rescanned and rebuilt
     dict(cand_refresh=12, cand_build_max_k=300),            # lines used / built in small rounds only (lean scan above)
     dict(cand_build_max_k=5),                               # lines practically only in the tail kernels
-    dict(order_partial=False, tiled_min_k=1, engine=1),     # full-scan engine everywhere, partial rounds in list order
-    dict(order_partial=True, tiled_min_k=1, engine=1, tail_threshold=0),
+    dict(tiled_min_k=1, engine=1),                          # full-scan engine everywhere (partial rounds in person order)
+    dict(tiled_min_k=1, engine=1, tail_threshold=0),
     dict(cand=False, tail_threshold=300),                   # no lines: the 512-thread tail kernel takes every mode
     dict(cand=2),                                           # lines without the maintenance pass ahead of the tail
     dict(rounds_per_sync=1), dict(rounds_per_sync=37),      # batch length of the trailing status reads
@@ -435,8 +435,6 @@ def test_tuning_knobs_do_not_change_the_result(knobs, gpu_lib):
     dict(MISSLAP_LIVE_STATUS="0"),                          # status reads by copy + stream wait
     dict(MISSLAP_LIVE_STATUS="2"),                          # every round-closing kernel posts its status
     dict(MISSLAP_LIVE_STATUS="0", MISSLAP_ROUND_FUSED="0"),
-    dict(MISSLAP_BUILD_MIN_K="0"),                          # small rounds rebuild the lines that missed
-    dict(MISSLAP_BIG_ROUNDS_BATCHED="1"),                   # big rounds enqueued without reading K in between
 ])
 def test_environment_switches_do_not_change_the_result(env, gpu_lib, monkeypatch):
     """The A/B switches of README.md (read when a handle is created) select how a round is LAUNCHED and how the host
@@ -1237,56 +1235,6 @@ def test_repeated_entries_on_the_engine_round_by_round(shape, f64, gpu_lib):
         assert np.array_equal(sg["U"], so["U"]), r
         assert np.array_equal(sg["p"].view(np.uint64), so["p"].view(np.uint64)), r
         assert np.array_equal(sg["p2o"], so["p2o"]) and np.array_equal(sg["o2p"], so["o2p"]), r
-
-
-@pytest.mark.parametrize("shape", [None, 8, 9])
-@pytest.mark.parametrize("spec,prob,few_undecided", [
-    (dict(kind="sparse", n=6000, m=40000, density=0.001), "max", True),           # 3 column tiles, rectangular, float costs
-    (dict(kind="sparse", n=4200, m=12000, density=0.01), "min", True),            # long segments: overflow lists
-    (dict(kind="sparse", n=5000, m=5000, density=0.01, ints=6), "max", False),    # ties at the top everywhere: the exact scan decides
-    (dict(kind="sparse", n=4500, m=33000, density=0.0012, ints=3), "min", False), # ties across tiles
-    (dict(kind="single", n=3000, density=0.01, n_single=60), "max", True),        # one-entry rows: +inf bids, infinite prices
-])
-def test_fp32_tile_filter_scan_round_by_round(spec, prob, few_undecided, shape, gpu_lib, monkeypatch):
-    """The full-scan engine as a FILTER scan (MISSLAP_TILED_P32=1, kernels_tiled.hpp kP32: price tiles in single
-    precision from an fp32 mirror of the prices; a lane group keeps its three largest fp32 values, the two best edges are
-    confirmed with exact prices when the rounding margin separates the second from the third, everybody else goes to
-    the exact wave-per-row scan behind it), forced for every grid round: full state vs the oracle."""
-    monkeypatch.setenv("MISSLAP_TILED_P32", "1")
-    loc, val = cases.synth_inputs(spec)
-    kw = dict(tiled_shape=shape) if shape else {}
-    for r in [1, 2, 3, 5, 8, 13, 21, 40, 80, 200]:
-        o = orc.from_sparse(loc, val.copy(), problem=prob, max_iter=r, cardinality_check=False)
-        o.solve()
-        so = o.state()
-        g = from_sparse(loc, val.copy(), problem=prob, max_iter=r, cardinality_check=False, tail_threshold=0,
-                        tiled_min_k=1, engine=1, **kw)
-        g.solve()
-        assert g.gpu["tiled_active"] == 1 and g.gpu["tiled_format"] == 0 and g.gpu["filter_undecided"] >= 0
-        sg = g.state()
-        assert sg["its"] == so["its"] and sg["K"] == so["K"], r
-        assert np.array_equal(sg["U"], so["U"]), r
-        assert np.array_equal(sg["p"].view(np.uint64), so["p"].view(np.uint64)), r
-        assert np.array_equal(sg["p2o"], so["p2o"]) and np.array_equal(sg["o2p"], so["o2p"]), r
-    frac = g.gpu["filter_undecided"] / g.gpu["bids_made"]  # (of the last, longest run)
-    assert (frac < 0.05) if few_undecided else (frac > 0.01), (frac, g.gpu["filter_undecided"], g.gpu["bids_made"])
-
-
-@pytest.mark.parametrize("cfg", ["C2", "C3", "C4"])
-def test_fp32_tile_filter_at_baseline_sizes(cfg, golden_large, gpu_lib, monkeypatch):
-    """... and whole solves at the BASELINE sizes (tail kernels, partial rounds, phase resets: every path that keeps or
-    rebuilds the fp32 mirror): the reference's assignment hash, round count and objective."""
-    monkeypatch.setenv("MISSLAP_TILED_P32", "1")
-    g = golden_large["cases"][cfg]
-    spec, kw = cases_mod.LARGE_CASES[cfg]
-    loc, val = _config_arrays(cfg)[:2]
-    s = from_sparse(loc, val, cardinality_check=False, **kw)
-    sol = s.solve()
-    assert s.gpu["tiled_active"] == 1 and s.gpu["tiled_format"] == 0
-    assert 0 <= s.gpu["filter_undecided"] < 0.02 * s.gpu["bids_made"]
-    assert synth.sol_digest(sol) == g["sol_sha256"]
-    assert s.meta["its"] == g["meta"]["its"] and s.gpu["obj_f64"] == g["obj_f64"]
-    assert s.gpu["edges_scanned"] == g["edges_scanned"]
 
 
 @pytest.mark.parametrize("rounds", [1, 7, 300])

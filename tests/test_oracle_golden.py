@@ -153,3 +153,23 @@ def test_oracle_solution_properties():
     dense[loc[:, 0], loc[:, 1]] = val
     r, c = linear_sum_assignment(dense, maximize=True)
     assert abs(dense[r, c].sum() - res["extra"]["obj_f64"]) <= 1e-6 * abs(dense[r, c].sum())
+
+
+@pytest.mark.parametrize("name", sorted(cases.SMALL_CASES))
+def test_assignment_through_the_bidders_equals_the_walk_over_all_objects(name, golden_small):
+    """bench.py's `optimised` CPU figure runs the oracle with the assignment phase visiting the objects through the
+    round's bidders (O(#bids)) instead of the reference's walk over all M objects (auction_.pyx:394): every write of the
+    phase is disjoint between winners, so the result -- assignment, prices, list order, round count -- must not change."""
+    manifest, arrays = golden_small
+    spec, kw, entry = cases.SMALL_CASES[name]
+    if entry not in ("locval", "locval_size"):
+        pytest.skip("the loc / val entry points are enough: the mode only changes the assignment phase")
+    loc, val = cases.synth_inputs(spec)
+    call = cases.call_kwargs(entry, loc, val.copy(), spec)
+    s = orc.from_sparse(cardinality_check=False, **call, **kw)
+    s.set_assign_by_bidders(True)
+    sol = s.solve()
+    assert np.array_equal(sol, arrays[name + "/sol"])
+    g = manifest["cases"][name]
+    for k in ("its", "nreductions", "obj", "final_eps"):
+        assert s.meta[k] == g["meta"][k], k

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Solve time of dense random matrices (the reference's `mat=` shape: every row holds every object) by size, on the
-GPU box; environment knobs (MISSLAP_LONG_MIN_ALIVE, MISSLAP_LONG_TAIL_BUDGET) select maintenance-pass variants.
+GPU box.
 usage: dense_sizes.py [n ...]"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,5 +13,4 @@ for n in [int(x) for x in sys.argv[1:]] or [1500, 3000, 8000]:
         s = from_matrix(mat, problem="max", max_iter=10**8, cardinality_check=False)
         s.solve()
         best = s.gpu["solve_ms"] if best is None else min(best, s.gpu["solve_ms"])
-    print(json.dumps(dict(n=n, solve_ms=round(best, 2), its=s.meta["its"], obj=s.meta["obj"],
-                          env={k: v for k, v in os.environ.items() if k.startswith("MISSLAP_LONG")})), flush=True)
+    print(json.dumps(dict(n=n, solve_ms=round(best, 2), its=s.meta["its"], obj=s.meta["obj"])), flush=True)

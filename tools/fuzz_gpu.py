@@ -43,7 +43,7 @@ for seed in range(first, first + count):
         kw["max_iter"] = min(kw["max_iter"], 200000)  # the reference would run to max_iter as well -- compare the state there
     gpu = dict(tail_threshold=[None, 0, 3, 17, 40, 200, 512][seed % 7], tiled_min_k=[None, None, 1, -1][seed % 4],
                rounds_per_sync=[None, 1, 5][seed % 3], cand_refresh=[None, None, 0, 30, 9][seed % 5],
-               cand_build_max_k=[None, None, None, 50, 900][(seed // 3) % 5], order_partial=[None, False][(seed // 2) % 2],
+               cand_build_max_k=[None, None, None, 50, 900][(seed // 3) % 5],
                cand=[None, None, None, False][(seed // 5) % 4])
     if gpu["tiled_min_k"] == 1:
         gpu["engine"] = 1  # build the tile-major copy whatever the size

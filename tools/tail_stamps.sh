@@ -1,7 +1,7 @@
 #!/bin/bash
 # Stamped cycles of the SHIPPING tail instances (diagnostic builds: s_memtime around the segments of a round, wavefront 0):
-#   bash tools/r5_tail_stamps.sh build      (build container: build_ab/lib_stamp_{chain,duo,team,block}.so)
-#   bash tools/r5_tail_stamps.sh run [cfg]  (GPU box: one solve per build, cycles per round and segment)
+#   bash tools/tail_stamps.sh build      (build container: build_ab/lib_stamp_{chain,duo,team,block}.so)
+#   bash tools/tail_stamps.sh run [cfg]  (GPU box: one solve per build, cycles per round and segment)
 R=$(cd "$(dirname "$0")/.." && pwd); cd "$R"
 if [ "$1" = build ]; then
   bash tools/build_ab.sh stamp_chain "-DMISSLAP_TAIL_STAMP" stamp_duo "-DMISSLAP_TAIL_STAMP_DUO" stamp_team "-DMISSLAP_TAIL_STAMP_TEAM" stamp_block "-DMISSLAP_TAIL_STAMP_BLOCK"
@@ -14,9 +14,9 @@ for m in chain duo team block; do
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r = d["tail_raw"]; m = sys.argv[2]
 tm = d["tail_modes"]
-names = {"chain": ["wait for the line", "record gather", "winner known + next line requested", "rest of the evaluation", "full scan of a missed person", "store / re-request / line rebuild"],
-         "duo": ["wait for the line", "record gather", "winner known + next line requested", "rest of the evaluation (+ scans)", "bid to LDS + barrier", "exchange / resolve / stores / re-request"],
-         "team": ["bid of my slot", "barrier", "clean test / resolve / assign", "re-request, line rebuild", "-", "-"],
+names = {"chain": ["wait for the line", "record gather", "winner known + next line requested", "rest of the evaluation", "full scan of a missed person", "store / re-request"],
+         "duo": ["evaluation up to the bid", "publish + wait for the next line + next gather issued", "barrier (= the other wavefront)", "exchange / patch of the records gathered ahead", "re-request", "-"],
+         "team": ["evaluation of my slot up to the bid", "publish + wait for the next line + next gather issued", "barrier", "LDS reads landed", "the gather issued ahead has landed", "patch / re-request / loop"],
          "block": ["lines landed", "records landed", "evaluation + barrier", "scan pass + barrier", "resolve / assign / compaction (wavefront 0)", "closing barrier"]}[m]
 # rounds the stamped code ran: chain = K = 1 rounds are not counted separately by the kernel: use the simulator's histogram share
 print(f"{sys.argv[3]} {m}: solve {d['solve_ms']} ms, sha {d['sol_sha256']}, tail modes {json.dumps(tm)}")
