@@ -168,6 +168,7 @@ MISSLAP_API int misslap_solve_batch(misslap_solver *const *handles, int32_t n, i
                                     misslap_meta *const *meta_out, int32_t group_size, misslap_batch_info *info) {
     if (!handles || n <= 0) return fail(MISSLAP_ERR_INVALID, "bad argument");
     if (group_size <= 0) group_size = 12;  // (what one kernel-argument block carries of the widest launch, host_batch.hpp)
+    if (!handles[0]) return fail(MISSLAP_ERR_INVALID, "null handle in the batch");
     const int device = handles[0]->device;
     for (int k = 0; k < n; ++k) {
         const misslap_solver *h = handles[k];

@@ -139,6 +139,10 @@ struct BlockCache {
         kMaxHeld = std::min(kMaxHeld, device_bytes / 64);
         kMaxEach = std::min(kMaxEach, kMaxHeld / 4);
     }
+    bool needs_sizing() {
+        std::lock_guard<std::mutex> g(m);
+        return !sized && !explicit_limits;
+    }
     void *take(int device, size_t bytes, size_t *got) {
         std::lock_guard<std::mutex> g(m);
         size_t best = idle.size();
@@ -154,8 +158,8 @@ struct BlockCache {
         return p;
     }
     bool give(int device, void *p, size_t bytes) {
+        std::lock_guard<std::mutex> g(m);  // (the limits are read under the lock: size_default / misslap_set_cache_limits write them)
         if (bytes == 0 || bytes > kMaxEach) return false;
-        std::lock_guard<std::mutex> g(m);
         if (idle.size() >= kMaxEntries || held + bytes > kMaxHeld) return false;
         idle.push_back({device, bytes, p});
         held += bytes;
@@ -178,7 +182,27 @@ int block_alloc(void **p, size_t bytes, size_t *got) {
     }();
     *p = block_cache().take(dev, bytes, got);
     if (!*p) {
-        HIP_TRY(hipMalloc(p, bytes));
+        hipError_t e = hipMalloc(p, bytes);
+        if (e == hipErrorOutOfMemory) {
+            // the parked blocks are memory no other allocator of the process can see as free: give them back and retry once
+            (void)hipGetLastError();
+            std::vector<BlockCache::Ent> take;
+            {
+                BlockCache &bc = block_cache();
+                std::lock_guard<std::mutex> g(bc.m);
+                take.swap(bc.idle);
+                bc.held = 0;
+            }
+            for (const BlockCache::Ent &en : take) {
+                if (hipSetDevice(en.device) == hipSuccess) {
+                    (void)hipDeviceSynchronize();  // nothing may still be running on a parked block
+                    (void)hipFree(en.p);
+                }
+            }
+            (void)hipSetDevice(dev);
+            e = hipMalloc(p, bytes);
+        }
+        HIP_TRY(e);
         *got = bytes;
     }
     if (poison >= 0) {
@@ -189,7 +213,7 @@ int block_alloc(void **p, size_t bytes, size_t *got) {
 }
 void block_free(int device, void *p, size_t bytes) {
     BlockCache &bc = block_cache();
-    if (p && !bc.sized && !bc.explicit_limits) {
+    if (p && bc.needs_sizing()) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) bc.size_default(total_b);
     }

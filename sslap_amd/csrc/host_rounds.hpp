@@ -106,7 +106,7 @@ int read_ctl(misslap_solver *h) {
 // ticket at or behind it.  Returns false on a timeout (the caller falls back to a copy + drain and stops using the words).
 bool live_poll(misslap_solver *h, unsigned want, bool exact, int *K, int *err, long long *nits) {
     volatile unsigned long long *w = h->live;
-    const double t_end = now_ms() + 20000.0;
+    double t_end = now_ms() + 20000.0;
     for (unsigned spins = 0;; ++spins) {
         const unsigned long long a = w[0], b = w[1], c = w[2], d = w[3];
         const unsigned t = (unsigned)(a >> 32);
@@ -119,7 +119,11 @@ bool live_poll(misslap_solver *h, unsigned want, bool exact, int *K, int *err, l
         }
         if (h->batch) {  // (a fiber of a batch: let the other problems run; the scheduler comes back to this poll)
             batch_yield(h, BatchFiber::kPolling);
-            if ((spins & 255) == 255 && now_ms() > t_end) return false;
+            // The deadline bounds a DEVICE stall.  While calls this fiber has recorded are still unissued -- the head of
+            // its tail sequence is held until every problem of the group has reached its own -- the wait is the
+            // scheduler's, however long the other problems' big rounds take: the clock starts when the last call is out.
+            if (h->batch->at < h->batch->pending.size()) t_end = now_ms() + 20000.0;
+            else if ((spins & 255) == 255 && now_ms() > t_end) return false;
         } else if (spins < 4000) {
             __builtin_ia32_pause();
         } else {
