@@ -1511,6 +1511,48 @@ def test_batched_solve_equals_the_single_solves(label, spec, prob, count, group,
     assert solvers[0].status().finished == 1
 
 
+def test_batched_solve_of_problems_that_differ_in_objects_entries_layout_and_engine(gpu_lib):
+    """The header's promise for a batch: same number of PERSONS; objects, entries, value layout and engine may differ.
+    Merged launches run on the largest grid of the calls they merge, so a handle sees grids sized for ANOTHER problem's
+    objects and entries in every kernel sized by them (k_apply, k_sync_from_rec, k_reset_phase, the eCE passes): each
+    handle must still end exactly where its own misslap_solve leaves it.  One group holds a square sparse problem, a
+    rectangular one with three times the objects, a dense one, a 12 B/edge one, one on the full-scan engine with shuffled
+    rows, one without lines, and one problem that reaches its tail long before the others (tiny, eps_start = small)."""
+    from sslap_amd import solve_batch
+    n = 3000
+    specs = [
+        (dict(kind="sparse", n=n, m=n, density=0.01, seed=11), "max", dict()),
+        (dict(kind="sparse", n=n, m=3 * n, density=0.004, seed=12), "min", dict()),
+        (dict(kind="sparse", n=n, m=n + 700, density=0.08, seed=13), "max", dict()),                      # 300 edges per row
+        (dict(kind="f64", n=n, density=0.01, seed=14), "max", dict()),                                   # 12 B/edge layout
+        (dict(kind="shuffled", n=n, m=4 * n, density=0.004, ints=5, seed=15), "min", dict(tiled_min_k=1, engine=1)),
+        (dict(kind="sparse", n=n, m=n, density=0.01, seed=16), "max", dict(cand=False)),
+        (dict(kind="sparse", n=n, m=2 * n, density=0.003, seed=17), "max", dict(eps_start=1e-3)),          # one phase: at its tail at once
+    ]
+    probs = [cases.synth_inputs(sp) for sp, _, _ in specs]
+    mk = lambda k: from_sparse(probs[k][0], probs[k][1].copy(), problem=specs[k][1], cardinality_check=False,  # noqa: E731
+                               max_iter=10**8, **specs[k][2])
+    singles = []
+    for k in range(len(specs)):
+        s1 = mk(k)
+        sol = s1.solve()
+        singles.append((sol, dict(s1.meta), dict(s1.gpu)))
+    solvers = [mk(k) for k in range(len(specs))]
+    sols, info = solve_batch(solvers, 12)  # one group
+    assert info["groups"] == 1 and info["launches_issued"] < info["calls_recorded"]
+    for k in range(len(specs)):
+        sol1, meta1, gpu1 = singles[k]
+        assert np.array_equal(sols[k], sol1), k
+        for key in cases.META_KEYS:
+            assert solvers[k].meta[key] == meta1[key], (k, key)
+        for key in ("obj_f64", "edges_scanned", "bids_made", "grid_rounds", "tail_rounds", "complete_assignment",
+                    "valid_assignment", "tiled_active", "tiled_format", "eps_phases", "phases_with_lines"):
+            assert solvers[k].gpu[key] == gpu1[key], (k, key)
+        ref = orc.auction_solve(loc=probs[k][0], val=probs[k][1].copy(), problem=specs[k][1], cardinality_check=False,
+                                max_iter=10**8, **{a: b for a, b in specs[k][2].items() if a == "eps_start"})
+        assert np.array_equal(sols[k], ref["sol"]) and solvers[k].meta["its"] == ref["meta"]["its"], k
+
+
 def test_batched_solve_argument_checks(gpu_lib):
     from sslap_amd import solve_batch
     a = from_sparse(*synth.gen_sparse(500, 500, 0.03, seed=1), problem="max", cardinality_check=False)

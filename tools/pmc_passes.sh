@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 --pmc passes on tools/pmc_scan.py (full-scan bid launches only); one counter group per pass.
-# usage (on the GPU box, from the repo root): [PMC_CONFIG=C5] bash tools/pmc_passes.sh <outdir> <group>...
+# usage (on the GPU box, from the repo root): [PMC_CONFIG=C5] [PMC_ROUNDS=2] [PMC_SHUFFLE=shuffle] bash tools/pmc_passes.sh <outdir> <group>...
 set -u
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/$1; shift
@@ -17,6 +17,6 @@ G[sq2]="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM 
 G[tcc3]="TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum"
 G[fetch]="FETCH_SIZE"
 for g in "$@"; do
-  timeout -k 10 200 rocprofv3 --kernel-trace --pmc ${G[$g]} -d "$O/$g" -o "$g" --output-format csv -- python3 "$R/tools/pmc_scan.py" ${PMC_CONFIG:-C3} 2 > "$O/$g.log" 2>&1 || { echo "pass $g failed"; tail -5 "$O/$g.log"; exit 1; }
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc ${G[$g]} -d "$O/$g" -o "$g" --output-format csv -- python3 "$R/tools/pmc_scan.py" ${PMC_CONFIG:-C3} 2 ${PMC_ROUNDS:-1} ${PMC_SHUFFLE:-} > "$O/$g.log" 2>&1 || { echo "pass $g failed"; tail -5 "$O/$g.log"; exit 1; }
 done
 echo done
