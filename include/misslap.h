@@ -368,7 +368,8 @@ int misslap_set_cache_limits(int64_t max_total_bytes, int64_t max_block_bytes, i
  * groups of `group_size` problems (0 = default, 12) share one HIP stream and every launch of the solve loop that several of
  * them issue at the same point is ONE launch (csrc/host_batch.hpp).  Each handle goes through exactly the sequence of
  * kernels misslap_solve would have launched for it: person_to_object_out[k] / meta_out[k] are what misslap_solve(handles[k])
- * returns, bit for bit.  The handles must be unsolved, unsharded, unprofiled, on one device, and have the same number of
+ * returns, bit for bit -- except the TIMING fields of the meta (solve_ms and the per-kernel times): inside a batch they are
+ * wall time of the handle's fiber, which includes the other problems of its group.  The handles must be unsolved, unsharded, unprofiled, on one device, and have the same number of
  * persons (rows; objects and entries may differ).  meta_out: n pointers to structs with struct_size set (the array and
  * any of its entries may be NULL, like the output pointers); *info (may be NULL) says how many launches went out for how many recorded. */
 typedef struct misslap_batch_info {

@@ -10,15 +10,30 @@ constexpr size_t kBatchFiberStack = 512 * 1024;
 // misslap_finish), with every launch recorded instead of issued
 void batch_fiber_main(unsigned lo, unsigned hi) {
     BatchFiber *f = reinterpret_cast<BatchFiber *>(((uintptr_t)hi << 32) | (uintptr_t)lo);
-    f->rc = misslap_solve_sharded(f->h, nullptr, f->sol, f->meta);
-    if (f->rc) f->err = g_err;
+    try {  // (an exception must not unwind out of a makecontext entry: e.g. bad_alloc of the list of recorded calls)
+        f->rc = misslap_solve_sharded(f->h, nullptr, f->sol, f->meta);
+        if (f->rc) f->err = g_err;
+    } catch (const std::exception &e) {
+        f->rc = MISSLAP_ERR_STATE;
+        f->err = std::string("exception inside a batched solve: ") + e.what();
+    } catch (...) {
+        f->rc = MISSLAP_ERR_STATE;
+        f->err = "exception inside a batched solve";
+    }
     f->state = BatchFiber::kDone;
     swapcontext(&f->ctx, &f->grp->sched);  // (never resumed)
 }
 
 // issue what the fibers of the group have recorded: the heads of all pending lists at a time, equal kernels as one
 // launch.  A held head (the start of a tail sequence) stops its list unless `release` says that everybody is there.
-void batch_flush(BatchGroup &g, bool release) {
+// Returns the first HIP error an issued launch / copy / fill raised (the fibers checked theirs at RECORD time, when
+// nothing had been issued yet): the caller aborts the group with it instead of running into a poll timeout.
+hipError_t batch_flush(BatchGroup &g, bool release) {
+    hipError_t first = hipSuccess;
+    auto note = [&]() {
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess && first == hipSuccess) first = e;
+    };
     std::vector<BatchCall *> heads, same;
     for (;;) {
         heads.clear();
@@ -39,6 +54,7 @@ void batch_flush(BatchGroup &g, bool release) {
             BatchCall *c = heads[a];
             if (!c->merge) {
                 c->single(g.stream);
+                note();
                 g.launches_issued += 1;
                 continue;
             }
@@ -49,6 +65,7 @@ void batch_flush(BatchGroup &g, bool release) {
                     done[b] = true;
                 }
             c->merge(g, same.data(), (int)same.size());
+            note();
             g.launches_issued += 1;
         }
     }
@@ -57,6 +74,7 @@ void batch_flush(BatchGroup &g, bool release) {
             fp->pending.clear();
             fp->at = 0;
         }
+    return first;
 }
 
 // one group: its handles' solves on fibers of this thread, one stream
@@ -124,7 +142,11 @@ int batch_run_group(BatchGroup &g, int device) {
         }
         const bool release = n_hold > 0 && n_ready == 0 && n_wait == 0 && n_sync == 0;
         if (release || (n_ready > 0 && (n_wait == 0 || ++idle > kPatience))) {
-            batch_flush(g, release);
+            const hipError_t fe = batch_flush(g, release);
+            if (fe != hipSuccess) {
+                rc = fail(MISSLAP_ERR_HIP, "a launch of a batched solve failed: %s", hipGetErrorString(fe));
+                break;
+            }
             lap(g.ms_flush);
             idle = 0;
             continue;  // (fibers whose calls just went out may have asked for a drained stream: next pass)
