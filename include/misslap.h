@@ -58,7 +58,8 @@ typedef struct misslap_options {
     int32_t shard_world;     /* number of shards (1 = single GPU) */
     int32_t rounds_per_sync; /* grid rounds enqueued between host status reads; <= 0 = default */
     /* ---- tuning knobs (all 0 = library default; none of them changes a single bit of the result) ---- */
-    int32_t tiled_min_K;     /* LDS-tiled full-scan bid kernel: 0 = default threshold (0.3 N), < 0 = never, > 0 = minimum K */
+    int32_t tiled_min_K;     /* LDS-tiled full-scan bid kernel: 0 = default threshold (0.7 N where the rows keep candidate
+                                lines, 0.3 N otherwise), < 0 = never, > 0 = minimum K */
     int32_t tiled_shape;     /* its launch shape: 0 = chosen from the average (person, tile) segment length, k + 1 =
                                 shape k of misslap.hip:kTiledShapes */
     int32_t tiled_force;     /* != 0 together with tiled_min_K > 0: build the tile-major copy whatever the size and

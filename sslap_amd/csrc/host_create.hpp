@@ -275,8 +275,14 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
                 trace.stage("tile-major copy");
                 h->tiled_ok = true;
                 // break-even against k_bid (cost ~ K) measured at C3: the full-scan engines have a fixed cost
-                // (price fills, barriers / the merge pass) of about a fifth of a full k_bid scan
-                h->tiled_min_K = tiled_opt > 0 ? tiled_opt : (int)std::max<size_t>((N * 3) / 10, 8192);
+                // (price fills, barriers / the merge pass) of about a fifth of a full k_bid scan: 0.3 N.  Where the rows
+                // keep candidate lines (<= 256 edges) the engine takes the rounds from 0.7 N on only (round 6): a partial
+                // round reads nearly the whole tile-major copy whoever bids (a (person, tile) segment is half a fabric line:
+                // C3, 55 % of the persons bidding: 237 of 241 MB), while k_bid answers most of those bids from lines --
+                // same box, threshold 0.3 / 0.7 N: C3 solve 359.3 / 357.8 ms, C2 123.4 / 122.2, all launches of the engine
+                // 42.8 / 48.4 % and 41.6 / 51.6 % of 8 TB/s; C4 (300 edges per row: no lines) 5.88 / 6.09 ms: stays at 0.3 N
+                const bool rows_keep_lines = cand_mode != 1 && avg_row <= (long long)kCandRowMax;
+                h->tiled_min_K = tiled_opt > 0 ? tiled_opt : (int)std::max<size_t>((N * (rows_keep_lines ? 7 : 3)) / 10, 8192);
                 Mpad = (size_t)T * tcols;  // whole tiles: the LDS fills need no bounds test
                 const hipFuncAttribute at = hipFuncAttributeMaxDynamicSharedMemorySize;
                 // per create, i.e. per device: the > 64 KB dynamic-LDS opt-in is a property of the function ON
@@ -409,7 +415,8 @@ int build_from_device_coo(misslap_solver *h, const int *d_loc, const double *d_v
     }
     for (hipEvent_t &e : h->stat_ev)
         if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    h->shard_min_K = h->tiled_ok ? h->tiled_min_K : (int)std::max<size_t>((N * 3) / 10, 8192);
+    h->shard_min_K = (int)std::max<size_t>((N * 3) / 10, 8192);  // (multi-GPU: the rounds that are sharded and exchanged)
+    if (h->tiled_ok && tiled_opt > 0) h->shard_min_K = h->tiled_min_K;  // (a caller's engine threshold moves it along)
     if (opt->shard_min_K > 0) h->shard_min_K = opt->shard_min_K;
     if (opt->shard_min_K < 0) h->shard_min_K = 0;  // every grid round sharded + exchanged
     // candidate lines are used and built below the full-scan regime (0.3 N): C5 with lines built in every round

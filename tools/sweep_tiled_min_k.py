@@ -17,12 +17,15 @@ for f in fracs:
     best = None
     for rep in range(reps):
         s = AuctionSolver.from_device_pointers(dl.data_ptr(), dv.data_ptr(), nnz, problem="max", max_iter=10**8,
-                                               tiled_min_k=max(1, int(f * n)))
+                                               tiled_min_k=max(1, int(f * n)), profile=1)
         sol = s.solve()
         d = synth.sol_digest(sol)
         want = want or d
         assert d == want, "the threshold changed the assignment"
         ms = s.gpu["solve_ms"]
         best = ms if best is None else min(best, ms)
-    print(json.dumps(dict(config=cfg, frac=f, tiled_min_K=int(f * n), solve_ms=round(best, 3), grid_rounds=s.gpu["grid_rounds"],
-                          tail_rounds=s.gpu["tail_rounds"], sha=d[:8])), flush=True)
+    g = s.gpu
+    print(json.dumps(dict(config=cfg, frac=f, tiled_min_K=int(f * n), solve_ms=round(best, 3), grid_rounds=g["grid_rounds"],
+                          tail_rounds=g["tail_rounds"], sha=d[:8], engine_launches=g.get("tiled_launches"),
+                          engine_us_per_launch=round(1e3 * g.get("tiled_ms", 0) / max(g.get("tiled_launches", 0), 1), 2),
+                          engine_frac_of_8TBs=round(g.get("tiled_edges", 0) * 8 / max(g.get("tiled_ms", 0), 1e-9) / 1e6 / 8000, 4))), flush=True)
