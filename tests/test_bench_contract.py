@@ -122,7 +122,9 @@ def test_every_committed_roofline_block_of_this_round_follows_from_its_pmc_file(
         n_l = sum(v["launches"] for v in sel)
         want = sum((v["read_avg"] + v["write_avg"]) * v["launches"] for v in sel) / n_l
         assert abs(r["traffic"] - want) <= 1.0 + 1e-9 * want, path
-        assert r["traffic"] >= 0.9 * r["algorithmic_bytes_per_launch"], (path, "traffic below the bytes the launches read")
+        # (the engine's packed records are 6 / 10 bytes per edge against the 8 / 12 the metric counts: a K = N scan may read
+        # as little as 0.75x the algorithmic bytes + segment table; anything below that cannot be the bytes of these launches)
+        assert r["traffic"] >= 0.75 * r["algorithmic_bytes_per_launch"], (path, "traffic below the bytes the launches read")
         assert abs(r["traffic_over_algorithmic"] - r["traffic"] / r["algorithmic_bytes_per_launch"]) < 2e-3, path
 
 
