@@ -624,6 +624,11 @@ struct __attribute__((aligned(16))) PipeLds {
     int tab[kPipeTab];           // hash of an object -> number of the last round in which it was bid on
 };
 
+// (a line's registers are "used" here so that the compiler's wait for the line load sits AT this point: what is issued
+// behind it -- the winners' stores -- is then not in front of any later wait for the line)
+__device__ __forceinline__ void touch_slot(const int2 &s) { asm volatile("" ::"v"(s.x), "v"(s.y)); }
+__device__ __forceinline__ void touch_slot(const Slot64 &s) { asm volatile("" ::"v"(s.x), "v"(s.y), "v"(s.c)); }
+
 // returns true when this wavefront has LEFT (its slot lies beyond K): the caller flushes its statistics and ends
 template <class E>
 __device__ __forceinline__ bool tail_team1_pipe(const TailArgs &a, const E &ed, int *sU, int *sStart, int &K,
@@ -644,9 +649,9 @@ __device__ __forceinline__ bool tail_team1_pipe(const TailArgs &a, const E &ed, 
     if (n0 < K) request(pi);
     __syncthreads();  // (sU / sStart have been read by everybody, the tables are set)
 #ifdef MISSLAP_TAIL_STAMP_TEAM
-    // diagnostic build: cycles of wavefront 0 per segment of a team round -> Ctl::dbg[6..11]: [6] evaluation of my slot up
-    // to the bid, [7] publish + wait for the next line + next gather issued, [8] barrier, [9] LDS reads landed, [10] the
-    // gather issued ahead has landed, [11] patch / winners' stores / re-request / line rebuild
+    // diagnostic build: cycles of wavefront 0 per segment of a team round -> Ctl::dbg[6..11]: [6] wait for the line + record
+    // gather, [7] evaluation of my slot up to the bid, [8] publish, [9] barrier, [10] LDS reads landed, [11] dirty word /
+    // stores / re-request / loop
     unsigned long long sacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sprev = __builtin_amdgcn_s_memtime();
     const CycleStamp stamp{sacc, &sprev, wave == 0};
 #else
@@ -654,23 +659,10 @@ __device__ __forceinline__ bool tail_team1_pipe(const TailArgs &a, const E &ed, 
 #endif
     const int rmax = round_limit(nits, max_iter);
     int r = 0;  // rounds done here = the round's number
-    PriceRec grec = PriceRec{0.0, -1, 0};
-    bool have_g = false;  // grec = the (exact) records of my slot's line, gathered ahead
     int par = 0;
     const int ls = min(lane, kTeamMax - 1);
-    // The winners' stores of a clean round are ISSUED in the next round, behind its evaluation: a store right in front of
-    // the loop's back edge has the compiler's wait for the line / the gathered records (landed long ago, but loaded in the
-    // previous iteration) wait for the store's round trip too.  Nothing reads a record before that point -- a gather
-    // behind the barrier (no records gathered ahead) and a row scan issue the pending stores first.
-    bool pend = false;
-    PriceRec prec = PriceRec{0.0, -1, 0};
-    int pobj = 0;
-    auto flush_store = [&]() {
-        if (pend) {  // wave-uniform
-            if (lane < K) a.rec[pobj] = prec;  // ASSIGN (:396-418) of every slot, lanes = slots
-            pend = false;
-        }
-    };
+    PriceRec grec = PriceRec{0.0, -1, 0};
+    bool have_g = false;  // the records of my slot's line have been requested (behind the previous round's stores)
     for (;;) {
         if (n0 >= K) {  // wave-uniform: my slot fell away (slots < K are always occupied: the list is compact)
             if (lane == 0) {
@@ -685,17 +677,17 @@ __device__ __forceinline__ bool tail_team1_pipe(const TailArgs &a, const E &ed, 
         CandBid b;
         b.hit = false;
         stamp.light(0);
-        // BID for my slot (auction_.pyx:339-365)
-        if (!have_g) {
-            flush_store();
-            grec = cand_gather1(slot, cls, src);
-        }
+        // BID for my slot (auction_.pyx:339-365).  The gather follows the previous round's stores in program order.
+        if (!have_g) grec = cand_gather1(slot, cls, src);
+#ifdef MISSLAP_TAIL_STAMP_TEAM
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp.light(1);
+#endif
         cand_eval1_r(slot, grec, cls, eps, b, st.bad_hi, [&](const CandBid &w) {
             sp = w.prev;
             request(sp);  // the owner my bidder evicts if it wins
         });
         if (!b.hit) {  // (rare behind the maintenance pass: the scan and the line's rebuild stay inside this block)
-            flush_store();
             CandBuildArgs bd;
             const typename E::Raw none[4] = {};
             const int e = a.row_ptr[pi + 1 + lane_zero()];
@@ -703,73 +695,51 @@ __device__ __forceinline__ bool tail_team1_pipe(const TailArgs &a, const E &ed, 
             st.misses += 1;
             st.miss_edges += (unsigned long long)b.len;
             if (bd.want) tail_build(a, pi, bd, eps, st);
-            b.hit = false;
         }
-        flush_store();  // (the common case: the previous round's stores, behind this round's evaluation)
         st.edges += (unsigned long long)b.len;
         st.bids += 1;
-        stamp.light(1);
-        PriceRec mine;
-        mine.price = key_to_bid(b.key);
-        mine.owner = pi;
-        mine.ostart = ps;
+        stamp.light(2);
         if (lane == 0) {
             const int old = atomicExch(&L.tab[pipe_hash(b.obj)], r);
+            PriceRec mine;
+            mine.price = key_to_bid(b.key);
+            mine.owner = pi;
+            mine.ostart = ps;
             L.slot[par][n0].rec = mine;
             L.slot[par][n0].aux = make_int4(b.obj, b.prev, b.pstart, 0);
             if (old == r || b.prev < 0) L.dirty[par] = r;
         }
-        // the gather of the NEXT round, ahead of the barrier (a scanned row may have decided differently from its
-        // line: then nothing was requested for the right person, and the next round gathers behind the barrier)
-        // (into grec itself -- its old contents are dead: a second variable is a copy at the loop's back edge, and the wait
-        // the compiler puts in front of that copy also waits for the round trip of the winners' stores)
-        have_g = b.hit && b.prev >= 0;
-        int hc = 0;
-        if (have_g) {
-            grec = cand_gather1(slot, cls, src);
-            hc = pipe_hash(slot.x);
-        }
-        stamp.light(2);
-        tail_barrier_lds();  // the bids are in LDS and every gather of the round has been ISSUED against the old records
         stamp.light(3);
+        tail_barrier_lds();  // the bids are in LDS and every gather of the round has landed
+        stamp.light(4);
         {
             const int dflag = L.dirty[par];
             const PriceRec lrec = L.slot[par][ls].rec;  // lanes = slots
             const int lobj = L.slot[par][ls].aux.x;
-            int tb = L.tab[hc];  // (>= r: bid on in this round -- or, if a fast wavefront is already publishing, the next)
-            asm volatile("" : "+v"(tb));  // (read with the others, not behind the test of the dirty word)
 #ifdef MISSLAP_TAIL_STAMP_TEAM
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            stamp.light(4);  // the LDS reads have landed
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            stamp.light(5);  // the gather issued ahead of the barrier has landed
+            stamp.light(5);
 #endif
             if (__builtin_amdgcn_readfirstlane(dflag) != r) {
-                // CLEAN: every bidder wins (:375-385 has nothing to resolve); the list keeps its shape.  The records
-                // gathered ahead are made exact FIRST and the winners' stores (ASSIGN, :396-418) are issued behind that:
-                // a wait for the gather that has a store behind it in the queue would wait for the store's round trip too
+                // CLEAN: every bidder wins (:375-385 has nothing to resolve); ASSIGN (:396-418) of every slot on lanes =
+                // slots; the list keeps its shape and my slot passes to the owner my bidder evicts (:409), whose line was
+                // requested when the winner was known: it has been in flight behind the rest of the evaluation, the
+                // publish, the barrier and these reads
+                // (the next gather is issued right here, behind the stores and inside the block that has waited for the line:
+                // at the loop's back edge the compiler would put a wait for EVERYTHING in front of it, the stores included)
+                have_g = sp == b.prev;  // (wave-uniform; false only behind a scanned row that decided differently from its line)
                 if (have_g) {
-                    const int c = slot.x;
-                    const bool own = c == b.obj;
-                    patch_rec(grec, own, mine);
-                    if (__any((tb >= r) & !own & cls & (c >= 0))) {  // rare: another slot bid on a candidate of my next bidder
-                        for (int m = 0; m < K; ++m) {
-                            const int om = __builtin_amdgcn_readlane(lobj, m);
-                            PriceRec rm;
-                            rm.price = readlane_f64(lrec.price, m);
-                            rm.owner = __builtin_amdgcn_readlane(lrec.owner, m);
-                            rm.ostart = __builtin_amdgcn_readlane(lrec.ostart, m);
-                            patch_rec(grec, c == om, rm);
-                        }
-                    }
+                    touch_slot(slot);
+                    if (lane < K) a.rec[lobj] = lrec;
+                    grec = cand_gather1(slot, cls, src);
+                } else {
+                    if (lane < K) a.rec[lobj] = lrec;
                 }
-                pend = true;
-                prec = lrec;
-                pobj = lobj;
                 pi = b.prev;
                 ps = b.pstart;
             } else {
                 // RESOLVE / ASSIGN / push_all_left in full, on lanes = slots
+                have_g = false;
                 const bool act = lane < K;
                 const int4 laux = L.slot[par][ls].aux;
                 const unsigned long long lkey = act ? bid_to_key(lrec.price) : 0ull;
@@ -809,7 +779,6 @@ __device__ __forceinline__ bool tail_team1_pipe(const TailArgs &a, const E &ed, 
                 K = Kn;
                 pi = n0 < K ? __builtin_amdgcn_readlane(u, min(n0, kWave - 1)) : -1;
                 ps = n0 < K ? __builtin_amdgcn_readlane(sx, min(n0, kWave - 1)) : 0;
-                have_g = false;
             }
         }
         par ^= 1;
@@ -821,7 +790,6 @@ __device__ __forceinline__ bool tail_team1_pipe(const TailArgs &a, const E &ed, 
         stamp.light(6);
         if (done) break;
     }
-    flush_store();
     nits += r;
 #ifdef MISSLAP_TAIL_STAMP_TEAM
     if (threadIdx.x == 0)

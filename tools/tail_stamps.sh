@@ -16,7 +16,7 @@ d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r = d["tail_r
 tm = d["tail_modes"]
 names = {"chain": ["wait for the line", "record gather", "winner known + next line requested", "rest of the evaluation", "full scan of a missed person", "store / re-request"],
          "duo": ["evaluation up to the bid", "publish + wait for the next line + next gather issued", "barrier (= the other wavefront)", "exchange / patch of the records gathered ahead", "re-request", "-"],
-         "team": ["evaluation of my slot up to the bid", "publish + wait for the next line + next gather issued", "barrier", "LDS reads landed", "the gather issued ahead has landed", "patch / re-request / loop"],
+         "team": ["wait for the line + record gather", "evaluation of my slot up to the bid", "publish", "barrier", "LDS reads landed", "dirty word / wait for the next line / stores / next gather issued / loop"],
          "block": ["lines landed", "records landed", "evaluation + barrier", "scan pass + barrier", "resolve / assign / compaction (wavefront 0)", "closing barrier"]}[m]
 # rounds the stamped code ran: chain = K = 1 rounds are not counted separately by the kernel: use the simulator's histogram share
 print(f"{sys.argv[3]} {m}: solve {d['solve_ms']} ms, sha {d['sol_sha256']}, tail modes {json.dumps(tm)}")
