@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Randomized parity run of misslap_solve_batch on the GPU box: batches of random instances of one shape with random
-options, every problem compared with its own single solve (assignment, meta, counters) and problem 0 with the oracle.
+"""Randomized parity run of misslap_solve_batch on the GPU box: batches of random instances with random options -- of one
+shape, or (every third batch) of one number of persons but different objects, entries per row and value layouts -- every
+problem compared with its own single solve (assignment, meta, counters) and problem 0 with the oracle.
 usage: fuzz_batch.py [first_seed] [count]"""
 import os
 import sys
@@ -34,17 +35,27 @@ for seed in range(first, first + count):
         gpu["engine"] = 1
         gpu["tiled_shape"] = [None, 8, 9][(seed // 4) % 3]
     gpu = {k: v for k, v in gpu.items() if v is not None}
-    probs = []
+    # every third batch is MIXED: the problems keep the number of persons (what a batch requires) but differ in objects,
+    # entries per row and value layout -- merged launches then run on grids sized for another problem's objects / entries
+    mixed = seed % 3 == 1 and density < 1.0
+    probs, gpus = [], []
     for k in range(B):
-        loc, val = synth.gen_sparse(n, m, density, seed=4000 + 37 * seed + k, integer_values=ints)
+        mk, dk, gk = m, density, dict(gpu)
+        if mixed:
+            mk = n if r.random() < 0.4 else int(n * r.uniform(1.0, 3.0))
+            dk = float(r.choice([3.0, 8.0, 30.0, 120.0])) / mk
+            if r.random() < 0.3:
+                gk["force_f64"] = True
+        loc, val = synth.gen_sparse(n, mk, dk, seed=4000 + 37 * seed + k, integer_values=ints)
         if (seed // 2) % 3 == 1:
             loc, val = synth.shuffle_within_rows(loc, val, seed + k)
         probs.append((loc, val))
+        gpus.append(gk)
     singles = []
-    for loc, val in probs:
-        s = from_sparse(loc, val.copy(), **kw, **gpu)
+    for (loc, val), gk in zip(probs, gpus):
+        s = from_sparse(loc, val.copy(), **kw, **gk)
         singles.append((s.solve(), dict(s.meta), dict(s.gpu)))
-    solvers = [from_sparse(loc, val.copy(), **kw, **gpu) for loc, val in probs]
+    solvers = [from_sparse(loc, val.copy(), **kw, **gk) for (loc, val), gk in zip(probs, gpus)]
     sols, info = solve_batch(solvers, group)
     ok = True
     why = []
