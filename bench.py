@@ -397,7 +397,28 @@ def main():
         from sslap_amd import dist as mdist
         # RCCL communicator of the library (the 128-byte id travels through torch.distributed); with
         # MISSLAP_DIST_BACKEND=gloo several ranks share one GPU and the exchange is staged through the host
-        comm = mdist.Comm.from_torch_distributed(local_rank) if backend == "nccl" else mdist.Comm.gloo_staged()
+        # MISSLAP_BENCH_COMM=torch: the exchange through torch.distributed's own all-reduces on the device buffers instead
+        # (backend nccl: the RCCL inside torch) -- also what every rank falls back to when ANY rank cannot create the
+        # library's communicator, so that a node on which ncclCommInitRank fails still yields a line (which says so)
+        want = os.environ.get("MISSLAP_BENCH_COMM", "rccl" if backend == "nccl" else "staged")
+        if want == "rccl":
+            try:
+                comm, why = mdist.Comm.from_torch_distributed(local_rank), None
+            except Exception as e:  # noqa: BLE001
+                comm, why = None, repr(e)
+            ok = torch.tensor([0 if comm is None else 1], device="cuda")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                print(f"bench.py rank {rank}: the library's RCCL communicator could not be created on every rank "
+                      f"({why or 'another rank failed'}): falling back to torch.distributed's collectives", file=sys.stderr, flush=True)
+                comm = None
+                want = "torch"
+        if want == "torch":
+            comm = mdist.Comm.torch_collectives()
+            comm.transport_note = ("one process per rank, torch.distributed all-reduces (backend %s) on the device buffers" % backend
+                                   + ("" if os.environ.get("MISSLAP_BENCH_COMM") == "torch" else " -- FALLBACK: the library's own RCCL communicator failed"))
+        elif want == "staged":
+            comm = mdist.Comm.gloo_staged()
     run_rank(args, rank, world, local_rank, TorchRanks(rank, world, dist, torch), comm, None, backend)
     if world > 1:
         dist.destroy_process_group()
@@ -730,9 +751,10 @@ def run_rank(args, rank, world, local_rank, ranks, comm, shared, backend):
             # N > 1: proof that N ranks took part and agree -- what the transport itself reports (ncclCommCount), every
             # rank's device and assignment hash, the exchanges a solve issued
             "ranks": rank_list,
-            "rank_transport": ("one process per rank, RCCL" if backend == "nccl" else
-                               "one process per rank on a shared GPU, exchange staged through the host (gloo)" if backend == "gloo"
-                               else "one THREAD per rank on a shared GPU, exchange staged through the host") if world > 1 else None,
+            "rank_transport": (getattr(comm, "transport_note", None) or
+                               ("one process per rank, RCCL" if backend == "nccl" else
+                                "one process per rank on a shared GPU, exchange staged through the host (gloo)" if backend == "gloo"
+                                else "one THREAD per rank on a shared GPU, exchange staged through the host")) if world > 1 else None,
             "rccl_nranks": (rank_list[0]["comm"]["transport_ranks"] if rank_list[0]["comm"] and rank_list[0]["comm"]["kind"] == "rccl" else None),
             "comm_kind": rank_list[0]["comm"]["kind"] if rank_list[0]["comm"] else None,
             "comm_ranks_seen_by_every_rank": [r["comm"]["transport_ranks"] if r["comm"] else None for r in rank_list],

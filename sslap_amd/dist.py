@@ -23,6 +23,8 @@ Communicators:
                                                128-byte id to every rank (any transport the application has)
     Comm.from_torch_distributed(device)        the same, the id travels through torch.distributed
     Comm.custom(rank, world, max_cb, min_cb)   caller-provided all-reduces (ptr, count, stream) -- other transports
+    Comm.torch_collectives(group=None)         torch.distributed's own all-reduces on the device buffers (nccl backend =
+                                               the RCCL inside torch): the transport bench.py falls back to
     Comm.gloo_staged(group=None)               rehearsal on ONE GPU: several ranks share cuda:0, the exchange is
                                                staged through the host with gloo (RCCL needs a GPU per rank)
     Comm.in_process(rank, group)               rehearsal with the ranks as THREADS of one process (ThreadGroup): what a
@@ -125,6 +127,26 @@ class Comm:
                 torch.cuda.synchronize()  # ... and may read it again
             return fn
         return cls.custom(rank, world, staged(dist.ReduceOp.MAX, "<i8"), staged(dist.ReduceOp.MIN, "<i4"))
+
+    @classmethod
+    def torch_collectives(cls, group=None):
+        """The exchange through torch.distributed's OWN collectives on the device buffers, ordered on the solver's
+        stream (backend nccl = the RCCL inside torch, one GPU per rank; gloo takes CUDA tensors as well, which is how the
+        tests run it on one GPU).  Second transport for a node on which the library's own RCCL communicator cannot be
+        created (bench.py falls back to it and says so in its line); same two callbacks as every custom communicator."""
+        import torch
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+
+        def coll(op, typestr):
+            def fn(ptr, count, stream):
+                # (the collective is enqueued behind the bid kernel on the solver's stream and that stream waits for
+                # its result: torch orders a collective with the CURRENT stream)
+                with torch.cuda.stream(torch.cuda.ExternalStream(int(stream or 0))):
+                    t = torch.as_tensor(_DevArray(ptr, count, typestr), device=torch.device("cuda", torch.cuda.current_device()))
+                    dist.all_reduce(t, op=op, group=group)
+            return fn
+        return cls.custom(rank, world, coll(dist.ReduceOp.MAX, "<i8"), coll(dist.ReduceOp.MIN, "<i4"))
 
     @classmethod
     def in_process(cls, rank, group):

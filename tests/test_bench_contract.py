@@ -145,16 +145,22 @@ def test_bench_gpus_n_without_a_launcher_spawns_the_ranks_before_touching_the_gp
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode,cfg", [("sharded", "C2"), ("replicas", "C1")])
-def test_bench_gpus_2_launches_itself_on_one_gpu_under_gloo(mode, cfg, gpu_lib):
+@pytest.mark.parametrize("mode,cfg,transport", [("sharded", "C2", None), ("replicas", "C1", None), ("sharded", "C2", "torch"),
+                                                ("sharded", "C2", "rccl")])
+def test_bench_gpus_2_launches_itself_on_one_gpu_under_gloo(mode, cfg, transport, gpu_lib):
     """The driver's form of the N > 1 run -- `python bench.py --gpus 2`, no launcher -- rehearsed on a one-GPU box:
     MISSLAP_DIST_BACKEND=gloo lets the two ranks share cuda:0 (the exchange of the sharded mode is then staged through
     the host).  One JSON line, the reference's assignment, and the proof-of-participation fields: every rank's device
-    and assignment hash, what the communicator reports about itself, the exchanges a solve issued."""
+    and assignment hash, what the communicator reports about itself, the exchanges a solve issued.
+    transport 'torch': MISSLAP_BENCH_COMM=torch -- the exchange through torch.distributed's own all-reduces on the device
+    buffers; 'rccl': the library's RCCL communicator is ASKED for with both ranks on one GPU, which RCCL refuses -- the
+    fallback a node with a broken ncclCommInitRank would take: every rank agrees to switch, the line says so."""
     import subprocess
     import sys
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MISSLAP_BENCH_COMM")}
     env.update(MISSLAP_DIST_BACKEND="gloo", MISSLAP_BENCH_TRACE="1")
+    if transport:
+        env.update(MISSLAP_BENCH_COMM=transport)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
                         "--no-cpu", "--config", cfg, "--mode", mode], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -172,6 +178,9 @@ def test_bench_gpus_2_launches_itself_on_one_gpu_under_gloo(mode, cfg, gpu_lib):
         assert d["comm_kind"] == "custom" and d["rccl_nranks"] is None  # gloo-staged here; RCCL reports ncclCommCount
         assert d["comm_ranks_seen_by_every_rank"] == [2, 2]
         assert d["sharded_rounds_per_solve"] > 0 and d["exchanges_per_solve"] == 2 * d["sharded_rounds_per_solve"]
+        assert ("torch.distributed all-reduces" in d["rank_transport"]) == (transport is not None)
+        assert ("FALLBACK" in d["rank_transport"]) == (transport == "rccl")
+        assert ("falling back to torch.distributed" in r.stderr) == (transport == "rccl")
     else:
         assert d["comm_kind"] is None and d["exchanges_per_solve"] == 0
 

@@ -221,7 +221,7 @@ _DIST_GPU_CASES = ((1500, 0.02, 1, 0, 0, -1), (1500, 0.02, 2, 4, 8, 300), (1500,
                    (30000, 0.002, 4, 0, None, None))
 
 
-def _dist_gpu_worker(rank, world, port, out):
+def _dist_gpu_worker(rank, world, port, out, transport="staged"):
     import os
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -234,7 +234,10 @@ def _dist_gpu_worker(rank, world, port, out):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    comm = Comm.gloo_staged()  # custom communicator: device buffers staged through the host, reduced with gloo
+    # custom communicator: device buffers staged through the host and reduced with gloo -- or torch.distributed's own
+    # all-reduce called on the device buffers on the solver's stream (the transport bench.py falls back to; under the
+    # nccl backend that is the RCCL inside torch, here gloo takes the CUDA tensors)
+    comm = Comm.gloo_staged() if transport == "staged" else Comm.torch_collectives()
     res = []
     for n, dens, seed, ints, thr, smk in _DIST_GPU_CASES:
         loc, val = synth.gen_sparse(n, n, dens, seed=seed, integer_values=ints)
@@ -248,10 +251,11 @@ def _dist_gpu_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_sharded_driver_two_ranks_one_gpu(gpu_lib):
+@pytest.mark.parametrize("transport", ["staged", "torch"])
+def test_sharded_driver_two_ranks_one_gpu(transport, gpu_lib):
     """The real kernels behind the library's sharded solve (misslap_solve_sharded): two processes share cuda:0 and
-    exchange the best-bid buffers through a custom communicator (gloo, staged through the host; RCCL needs one GPU
-    per rank -- its world-1 smoke test is below).  Shard ranges, exchange on the solver's stream, replicated apply
+    exchange the best-bid buffers through a custom communicator (gloo, staged through the host -- or handed the device
+    buffers directly, Comm.torch_collectives; RCCL needs one GPU per rank -- its world-1 smoke test is below).  Shard ranges, exchange on the solver's stream, replicated apply
     and the replicated tail must reproduce the single-GPU / oracle result."""
     import socket
     import torch.multiprocessing as mp
@@ -260,7 +264,7 @@ def test_sharded_driver_two_ranks_one_gpu(gpu_lib):
         port = sk.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_dist_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_dist_gpu_worker, args=(r, 2, port, q, transport)) for r in range(2)]
     for p in procs:
         p.start()
     got = dict(q.get(timeout=300) for _ in procs)
